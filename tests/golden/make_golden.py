@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Regenerate the golden vectors in this directory.  Runs ONLY where /root/reference is mounted.
+
+Outputs (committed):
+  reference_zarr.npz       the reference's own 18 known-answer arrays
+                           (tests/test_data_kernels/*.zarr, tests/test_data_filter/*.zarr upstream),
+                           decoded from their Blosc/LZ4 zarr-v2 chunks to float32 numpy arrays.
+  reference_generated.npz  float64 outputs obtained by *importing the reference* (with a stub for its
+                           one missing import, xarray) and running its kernels / filter_func on the seeded
+                           inputs of gcm_filters_amd.testing.  Inputs are NOT stored -- tests rebuild them
+                           from the same seeds.  The case list is `CASES` below; its keys are the npz keys.
+  reference_spec.npz       n_steps defaults and Chebyshev coefficients p[] from the reference for a table
+                           of (shape, scale, dx_min, transition_width, ndim, n_steps).
+
+No reference source text is copied anywhere: only numbers leave this script.
+"""
+import ctypes
+import ctypes.util
+import json
+import os
+import struct
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+
+# ------------------------------------------------------------------------------------------------
+# zarr-v2 / Blosc-1 / LZ4 single-chunk decoder (no zarr / numcodecs in this image)
+# ------------------------------------------------------------------------------------------------
+def _lz4():
+    lib = ctypes.CDLL(ctypes.util.find_library("lz4") or "liblz4.so.1")
+    lib.LZ4_decompress_safe.restype = ctypes.c_int
+    lib.LZ4_decompress_safe.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+    return lib
+
+
+def blosc1_decompress(buf: bytes) -> bytes:
+    version, versionlz, flags, typesize, nbytes, blocksize, cbytes = struct.unpack_from("<BBBBIII", buf, 0)
+    assert cbytes == len(buf), (cbytes, len(buf))
+    if flags & 0x2:  # memcpyed
+        return buf[16:16 + nbytes]
+    assert (flags >> 5) == 1, "expected the LZ4 codec"
+    shuffled = bool(flags & 0x1)
+    nblocks = (nbytes + blocksize - 1) // blocksize
+    bstarts = struct.unpack_from(f"<{nblocks}I", buf, 16)
+    lz4 = _lz4()
+    out = bytearray()
+    for b in range(nblocks):
+        bsize = min(blocksize, nbytes - b * blocksize)
+        leftover = bsize != blocksize
+        # blosc splits a block into `typesize` streams unless it is the leftover block / split disabled
+        nsplits = typesize if (not (flags & 0x10) and not leftover and typesize <= 16 and bsize // typesize >= 128) else 1
+        pos = bstarts[b]
+        block = bytearray()
+        for _ in range(nsplits):
+            (csize,) = struct.unpack_from("<i", buf, pos)
+            pos += 4
+            want = bsize // nsplits
+            if csize == want:
+                block += buf[pos:pos + csize]
+            else:
+                dst = ctypes.create_string_buffer(want)
+                got = lz4.LZ4_decompress_safe(buf[pos:pos + csize], dst, csize, want)
+                assert got == want, (got, want)
+                block += dst.raw
+            pos += csize
+        if shuffled and typesize > 1:
+            n = bsize // typesize
+            arr = np.frombuffer(bytes(block[: n * typesize]), dtype=np.uint8).reshape(typesize, n).T.copy()
+            block = bytearray(arr.tobytes()) + block[n * typesize:]
+        out += block
+    assert len(out) == nbytes
+    return bytes(out)
+
+
+def read_zarr_array(path: str) -> np.ndarray:
+    meta = json.load(open(os.path.join(path, ".zarray")))
+    assert meta["zarr_format"] == 2 and meta["order"] == "C" and meta["chunks"] == meta["shape"]
+    assert meta["compressor"]["id"] == "blosc" and meta["filters"] is None
+    chunk = ".".join(["0"] * len(meta["shape"]))
+    raw = blosc1_decompress(open(os.path.join(path, chunk), "rb").read())
+    return np.frombuffer(raw, dtype=np.dtype(meta["dtype"])).reshape(meta["shape"]).copy()
+
+
+# ------------------------------------------------------------------------------------------------
+# import the reference (its only unavailable import is xarray; the array-level path never uses it)
+# ------------------------------------------------------------------------------------------------
+def import_reference():
+    xr = types.ModuleType("xarray")
+
+    class _Unused:
+        def __init__(self, *a, **k):
+            pass
+
+    xr.Dataset = xr.DataArray = _Unused
+    sys.modules.setdefault("xarray", xr)
+    sys.path.insert(0, REF)
+    import gcm_filters.filter as rf
+    import gcm_filters.kernels as rk
+    return rf, rk
+
+
+# ------------------------------------------------------------------------------------------------
+# case table for reference_generated.npz -- also imported by the tests to rebuild the inputs
+# ------------------------------------------------------------------------------------------------
+SMALL = (40, 64)
+
+
+def build_case(name: str):
+    """Return (grid_type, fields tuple, grid_vars, filter kwargs or None) for a case key."""
+    sys.path.insert(0, REPO)
+    from gcm_filters_amd import testing as T
+
+    parts = name.split("/")
+    grid, kind = parts[0], parts[1]
+    variant = parts[2] if len(parts) > 2 else "base"
+    shape = (128, 256) if variant == "full" else SMALL
+    vec = grid in T.VECTOR_GRIDS
+    if vec:
+        fields, gv = T.vector_case(grid, shape)
+    else:
+        f, gv = T.scalar_case(grid, shape)
+        fields = (f,)
+    if variant == "kappa":  # spatially varying kappa <= 1 with max exactly 1
+        if grid == "IRREGULAR_WITH_LAND":
+            gv["kappa_w"] = T.smooth_kappa(shape, 11)
+            gv["kappa_s"] = T.smooth_kappa(shape, 12)
+        elif grid == "VECTOR_C_GRID":
+            gv["kappa_iso"] = T.smooth_kappa(shape, 13)
+            gv["kappa_aniso"] = 0.5 * T.smooth_kappa(shape, 14)
+    if variant == "nanland":  # NaN on land cells of the input
+        mk = [k for k in gv if k.startswith("wet_mask")][0]
+        fields = tuple(np.where(gv[mk] == 0, np.nan, f) for f in fields)
+    if variant == "batched":
+        fields = tuple(np.stack([np.stack([T.random_field(shape, 1000 + 10 * a + b + 100 * c) for b in range(2)])
+                                 for a in range(3)]) for c, _ in enumerate(fields))
+    if variant == "f32":
+        fields = tuple(f.astype(np.float32) for f in fields)
+    if variant == "allf32":
+        fields = tuple(f.astype(np.float32) for f in fields)
+        gv = {k: v.astype(np.float32) for k, v in gv.items()}
+    if variant == "zeroarea" and grid == "VECTOR_C_GRID":
+        gv["area_u"] = gv["area_u"].copy()
+        gv["area_v"] = gv["area_v"].copy()
+        gv["area_u"][5:9, 7:12] = 0
+        gv["area_v"][20:22, 30:40] = 0
+    dimensional = grid in ("IRREGULAR_WITH_LAND", "MOM5U", "MOM5T", "TRIPOLAR_POP_WITH_LAND") or vec
+    dx_min = T.grid_dx_min(grid, gv) if dimensional else 1.0
+    fk = None
+    if kind == "gauss":
+        fk = dict(filter_scale=8.0 * dx_min, dx_min=dx_min, filter_shape="GAUSSIAN", n_steps=0)
+    elif kind == "gauss_ref":  # exactly the upstream validation-test filter (dx_min = 1 on every grid)
+        fk = dict(filter_scale=8.0, dx_min=1.0, filter_shape="GAUSSIAN", n_steps=0)
+    elif kind == "taper":
+        fk = dict(filter_scale=4.0 * dx_min, dx_min=dx_min, filter_shape="TAPER", n_steps=0)
+    elif kind == "lap":
+        fk = None
+    else:
+        raise KeyError(kind)
+    return grid, fields, gv, fk
+
+
+def case_names():
+    sys.path.insert(0, REPO)
+    from gcm_filters_amd import testing as T
+
+    names = []
+    for g in T.ALL_GRIDS:
+        names += [f"{g}/lap", f"{g}/gauss", f"{g}/taper", f"{g}/gauss/batched", f"{g}/gauss/f32",
+                  f"{g}/gauss/allf32"]
+        if g in ("MOM5U", "MOM5T"):
+            names += [f"{g}/lap/full", f"{g}/gauss_ref/full"]
+        if any(k.startswith("wet_mask") for k in T.FIXTURE_ARG_ORDER[g]):
+            names += [f"{g}/gauss/nanland", f"{g}/lap/nanland"]
+    names += ["IRREGULAR_WITH_LAND/lap/kappa", "IRREGULAR_WITH_LAND/taper/kappa",
+              "VECTOR_C_GRID/lap/kappa", "VECTOR_C_GRID/gauss/kappa", "VECTOR_C_GRID/lap/zeroarea"]
+    names += ["REGULAR/config1"]
+    return names
+
+
+SPEC_TABLE = [
+    # (shape, filter_scale, dx_min, transition_width, ndim, n_steps)
+    ("GAUSSIAN", 10.0, 1.0, np.pi, 2, 0), ("TAPER", 2.0, 1.0, np.pi, 1, 0),
+    ("GAUSSIAN", 4.0, 1.0, np.pi, 2, 16), ("GAUSSIAN", 8.0, 1.0, np.pi, 2, 0), ("GAUSSIAN", 50.0, 1.0, np.pi, 2, 0),
+    ("TAPER", 4.0, 1.0, np.pi, 2, 0), ("TAPER", 16.0, 1.0, np.pi, 2, 0), ("TAPER", 8.0, 1.0, 2.0, 2, 0),
+    ("TAPER", 14.4, 0.9, np.pi, 2, 0), ("GAUSSIAN", 8.0, 2.0, np.pi, 2, 0), ("GAUSSIAN", 3.0, 1.0, np.pi, 2, 0),
+    ("TAPER", 5.0, 1.0, np.pi, 2, 10), ("GAUSSIAN", 6.0, 1.0, np.pi, 3, 12), ("GAUSSIAN", 5.0, 1.0, np.pi, 1, 0),
+    ("TAPER", 32.0, 1.0, np.pi, 2, 0), ("TAPER", 6.0, 1.5, 1.5, 1, 0),
+]
+
+
+def main():
+    if not os.path.isdir(REF):
+        print("reference not mounted: nothing to do")
+        return 0
+    sys.path.insert(0, REPO)
+    rf, rk = import_reference()
+
+    # 1. the reference's own goldens
+    z = {}
+    for sub in ("test_data_kernels", "test_data_filter"):
+        d = os.path.join(REF, "tests", sub)
+        for entry in sorted(os.listdir(d)):
+            if entry.endswith(".zarr"):
+                z[f"{sub}/{entry[:-5]}"] = read_zarr_array(os.path.join(d, entry))
+    np.savez_compressed(os.path.join(HERE, "reference_zarr.npz"), **z)
+    print("reference_zarr.npz:", len(z), "arrays")
+
+    # 2. fp64 vectors from the imported reference
+    out = {}
+    for name in case_names():
+        if name == "REGULAR/config1":  # BASELINE config 1: REGULAR 512x512, Gaussian scale 4, n_steps 16
+            from gcm_filters_amd import testing as T
+            f = T.random_field((512, 512), 100)
+            n = 16
+            spec = rf._compute_filter_spec(4.0, 1.0, rf.FilterShape.GAUSSIAN, np.pi, 2, n)
+            res = rf._create_filter_func(spec, rk.ALL_KERNELS[rk.GridType.REGULAR])(f)
+            # 512x512 f64 is 2 MiB: keep a strided probe + checksums instead of the full plane
+            out[name + "/probe"] = res[::8, ::8].copy()
+            out[name + "/sums"] = np.array([res.sum(), (res * res).sum(), np.abs(res).max()])
+            continue
+        grid, fields, gv, fk = build_case(name)
+        gt = rk.GridType[grid]
+        cls = rk.ALL_KERNELS[gt]
+        args = [gv[k] for k in cls.required_grid_args()]
+        if fk is None:
+            lap = cls(**gv)
+            res = lap(*fields)
+        else:
+            shape = rf.FilterShape[fk["filter_shape"]]
+            n = rf._compute_n_steps_default(2, shape, fk["filter_scale"], fk["dx_min"], np.pi)
+            spec = rf._compute_filter_spec(fk["filter_scale"], fk["dx_min"], shape, np.pi, 2, n)
+            if len(fields) == 2:
+                res = rf._create_filter_func_vec(spec, cls)(*fields, *args)
+            else:
+                res = rf._create_filter_func(spec, cls)(*fields, *args)
+        res = np.stack(res) if isinstance(res, tuple) else np.asarray(res)
+        out[name] = res
+    np.savez_compressed(os.path.join(HERE, "reference_generated.npz"), **out)
+    print("reference_generated.npz:", len(out), "arrays,",
+          sum(v.nbytes for v in out.values()) // 1024, "KiB raw")
+
+    # 3. polynomial table
+    sp = {}
+    for row in SPEC_TABLE:
+        shape, scale, dx_min, tw, ndim, n = row
+        fs = rf.FilterShape[shape]
+        nd = int(rf._compute_n_steps_default(ndim, fs, scale, dx_min, tw)) if ndim <= 2 else n
+        nn = n if n >= 3 else nd
+        spec = rf._compute_filter_spec(scale, dx_min, fs, tw, ndim, nn)
+        key = f"{shape}|{scale!r}|{dx_min!r}|{tw!r}|{ndim}|{n}"
+        sp[key + "|p"] = np.asarray(spec.p)
+        sp[key + "|meta"] = np.array([nd, spec.n_steps, spec.s_max, spec.dx_min_sq], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "reference_spec.npz"), **sp)
+    print("reference_spec.npz:", len(sp) // 2, "rows")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
