@@ -1,0 +1,204 @@
+"""ctypes binding of libgcmf.so (the C ABI declared in include/gcmf.h).
+
+There is no CPU fallback: if the HIP library cannot be loaded (or no MI355X is visible when a plan is
+created) the calls raise.  ``Plan`` is the Python handle of a ``gcmf_plan`` -- the device-resident
+counterpart of one reference ``Laplacian(**grid_vars)`` object (gcm_filters/kernels.py __post_init__s).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgcmf.so")
+
+# status codes (include/gcmf.h)
+OK, ERR_INVALID_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
+ERR_KAPPA_W_GT1, ERR_KAPPA_S_GT1, ERR_KAPPA_NONE_ONE = 16, 17, 18
+ERR_WET_SOUTH_ROW, ERR_DXN_FOLD, ERR_DYN_FOLD = 19, 20, 21
+F32, F64 = 0, 1
+DEVICE_PTRS, OUT_F32 = 0x1, 0x2
+STEP_FIRST, STEP_LAST = 0x1, 0x2
+
+EXPORTS = [
+    "gcmf_plan_create", "gcmf_plan_destroy", "gcmf_grid_nplanes", "gcmf_grid_ncomp", "gcmf_grid_is_dimensional",
+    "gcmf_grid_is_tripolar", "gcmf_plan_rows", "gcmf_apply", "gcmf_laplacian", "gcmf_cheb_step", "gcmf_prepare",
+    "gcmf_last_timing", "gcmf_set_timing", "gcmf_set_tuning", "gcmf_last_error", "gcmf_version",
+]
+
+
+class PlanDesc(C.Structure):
+    _fields_ = [
+        ("grid_type", C.c_int32), ("dtype", C.c_int32), ("ny", C.c_int64), ("nx", C.c_int64),
+        ("row_begin", C.c_int64), ("row_end", C.c_int64), ("halo", C.c_int32), ("device", C.c_int32),
+        ("planes_on_device", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class GcmfError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libgcmf status {status}: {message}")
+        self.status = status
+        self.message = message
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load() -> C.CDLL:
+    """dlopen libgcmf.so, building it with hipcc first if the in-tree binary is missing."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            from ._build import build_library
+            build_library()
+        lib = C.CDLL(LIB_PATH)
+        vp, vpp = C.c_void_p, C.POINTER(C.c_void_p)
+        lib.gcmf_plan_create.argtypes = [C.POINTER(PlanDesc), vpp, C.c_int, vpp]
+        lib.gcmf_plan_create.restype = C.c_int
+        lib.gcmf_plan_destroy.argtypes = [vp]
+        lib.gcmf_plan_destroy.restype = None
+        for name in ("gcmf_grid_nplanes", "gcmf_grid_ncomp", "gcmf_grid_is_dimensional", "gcmf_grid_is_tripolar"):
+            getattr(lib, name).argtypes = [C.c_int]
+            getattr(lib, name).restype = C.c_int
+        lib.gcmf_plan_rows.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        lib.gcmf_plan_rows.restype = C.c_int
+        lib.gcmf_apply.argtypes = [vp, C.POINTER(C.c_double), C.c_int, C.c_double, vpp, vpp, C.c_int64, C.c_uint32, vp]
+        lib.gcmf_apply.restype = C.c_int
+        lib.gcmf_laplacian.argtypes = [vp, vpp, vpp, C.c_int64, C.c_uint32, vp]
+        lib.gcmf_laplacian.restype = C.c_int
+        lib.gcmf_cheb_step.argtypes = [vp, vpp, vpp, vpp, vpp, vpp, C.c_double, C.c_double, C.c_double, C.c_uint32,
+                                       C.c_uint32, C.c_int64, C.c_int64, C.c_int64, vp]
+        lib.gcmf_cheb_step.restype = C.c_int
+        lib.gcmf_prepare.argtypes = [vp, vpp, vpp, C.c_int64, C.c_int64, C.c_int64, vp]
+        lib.gcmf_prepare.restype = C.c_int
+        lib.gcmf_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        lib.gcmf_last_timing.restype = C.c_int
+        lib.gcmf_set_timing.argtypes = [vp, C.c_int]
+        lib.gcmf_set_timing.restype = C.c_int
+        lib.gcmf_set_tuning.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+        lib.gcmf_set_tuning.restype = C.c_int
+        lib.gcmf_last_error.argtypes = []
+        lib.gcmf_last_error.restype = C.c_char_p
+        lib.gcmf_version.argtypes = []
+        lib.gcmf_version.restype = C.c_int
+        _lib = lib
+        return lib
+
+
+def last_error() -> str:
+    return load().gcmf_last_error().decode("utf-8", "replace")
+
+
+def check(status: int):
+    if status != OK:
+        raise GcmfError(status, last_error())
+
+
+def _ptr_array(ptrs: Sequence[Optional[int]]):
+    arr = (C.c_void_p * max(len(ptrs), 1))()
+    for k, p in enumerate(ptrs):
+        arr[k] = p
+    return arr
+
+
+def np_dtype(code: int):
+    return np.float64 if code == F64 else np.float32
+
+
+def dtype_code(dt) -> int:
+    dt = np.dtype(dt)
+    if dt == np.float64:
+        return F64
+    if dt == np.float32:
+        return F32
+    raise TypeError(f"libgcmf computes in float32 or float64, not {dt}")
+
+
+class Plan:
+    """Owning handle of a gcmf_plan."""
+
+    def __init__(self, grid_type: int, dtype: int, ny: int, nx: int, planes: Sequence, *, device: int = 0,
+                 row_begin: int = 0, row_end: Optional[int] = None, halo: int = 0, planes_on_device: bool = False):
+        lib = load()
+        self._h = None
+        self.grid_type, self.dtype, self.ny, self.nx, self.device = int(grid_type), int(dtype), int(ny), int(nx), int(device)
+        self.ncomp = lib.gcmf_grid_ncomp(self.grid_type)
+        desc = PlanDesc(self.grid_type, self.dtype, self.ny, self.nx, int(row_begin),
+                        int(self.ny if row_end is None else row_end), int(halo), self.device,
+                        1 if planes_on_device else 0, 0)
+        if planes_on_device:
+            ptrs = [int(p) for p in planes]
+            keep = None
+        else:
+            keep = [np.ascontiguousarray(p, dtype=np_dtype(self.dtype)) for p in planes]
+            for a in keep:
+                if a.shape != (self.ny, self.nx):
+                    raise ValueError(f"grid plane has shape {a.shape}, expected {(self.ny, self.nx)}")
+            ptrs = [a.ctypes.data for a in keep]
+        out = C.c_void_p()
+        st = lib.gcmf_plan_create(C.byref(desc), _ptr_array(ptrs), len(ptrs), C.byref(out))
+        del keep
+        check(st)
+        self._h = out
+        ra, fo, ro = C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib.gcmf_plan_rows(self._h, C.byref(ra), C.byref(fo), C.byref(ro)))
+        self.rows_alloc, self.first_owned, self.rows_owned = ra.value, fo.value, ro.value
+
+    # -- lifetime ------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            load().gcmf_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- whole-filter / one-Laplacian calls ----------------------------------------------------
+    def apply(self, p: np.ndarray, c: float, ins: Sequence[int], outs: Sequence[int], nbatch: int, *,
+              device_ptrs: bool, out_f32: bool = False, stream: int = 0):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        flags = (DEVICE_PTRS if device_ptrs else 0) | (OUT_F32 if out_f32 else 0)
+        check(load().gcmf_apply(self._h, p.ctypes.data_as(C.POINTER(C.c_double)), len(p) - 1, float(c),
+                                _ptr_array(ins), _ptr_array(outs), int(nbatch), flags, C.c_void_p(stream or None)))
+
+    def laplacian(self, ins: Sequence[int], outs: Sequence[int], nbatch: int, *, device_ptrs: bool, stream: int = 0):
+        flags = DEVICE_PTRS if device_ptrs else 0
+        check(load().gcmf_laplacian(self._h, _ptr_array(ins), _ptr_array(outs), int(nbatch), flags,
+                                    C.c_void_p(stream or None)))
+
+    # -- row-slab building blocks (device pointers) --------------------------------------------
+    def cheb_step(self, t1, t2, fb_in, t0, fb_out, coef0, coef1, c, mode, nbatch, row_lo, row_hi, *,
+                  out_f32: bool = False, stream: int = 0):
+        n = self.ncomp
+        z = [None] * n
+        check(load().gcmf_cheb_step(self._h, _ptr_array(t1), _ptr_array(t2 or z), _ptr_array(fb_in or z),
+                                    _ptr_array(t0 or z), _ptr_array(fb_out), float(coef0), float(coef1), float(c),
+                                    int(mode), OUT_F32 if out_f32 else 0, int(nbatch), int(row_lo), int(row_hi),
+                                    C.c_void_p(stream or None)))
+
+    def prepare(self, ins, outs, nbatch, row_lo, row_hi, *, stream: int = 0):
+        check(load().gcmf_prepare(self._h, _ptr_array(ins), _ptr_array(outs), int(nbatch), int(row_lo), int(row_hi),
+                                  C.c_void_p(stream or None)))
+
+    # -- instrumentation -----------------------------------------------------------------------
+    def set_timing(self, enabled: bool):
+        check(load().gcmf_set_timing(self._h, 1 if enabled else 0))
+
+    def last_timing(self):
+        ms, n = C.c_float(), C.c_int()
+        check(load().gcmf_last_timing(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def set_tuning(self, rows_per_wave: int = 0):
+        check(load().gcmf_set_tuning(self._h, int(rows_per_wave), 0, 0))

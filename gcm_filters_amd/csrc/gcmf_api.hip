@@ -1,0 +1,418 @@
+// libgcmf C ABI: plan lifetime, the whole-polynomial apply loop and the per-step building blocks.
+// See include/gcmf.h for the contract and the reference interfaces each entry point replaces.
+#include "gcmf_internal.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace gcmf {
+
+static thread_local std::string g_err = "";
+
+void set_error(const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+size_t dtype_size(int dtype) { return dtype == GCMF_F64 ? 8 : 4; }
+
+struct GridInfo {
+  int nplanes, ncomp, dimensional, tripolar, area_weighted, kind;
+};
+static bool grid_info(int gt, GridInfo &gi) {
+  switch (gt) {
+    case GCMF_REGULAR: gi = {0, 1, 0, 0, 0, K_REG}; return true;
+    case GCMF_REGULAR_AREA_WEIGHTED: gi = {1, 1, 0, 0, 1, K_REG}; return true;
+    case GCMF_REGULAR_WITH_LAND: gi = {1, 1, 0, 0, 0, K_MASK}; return true;
+    case GCMF_REGULAR_WITH_LAND_AREA_WEIGHTED: gi = {2, 1, 0, 0, 1, K_MASK}; return true;
+    case GCMF_IRREGULAR_WITH_LAND: gi = {8, 1, 1, 0, 0, K_FLUX}; return true;
+    case GCMF_MOM5U: gi = {6, 1, 1, 0, 0, K_FLUX}; return true;
+    case GCMF_MOM5T: gi = {6, 1, 1, 0, 0, K_FLUX}; return true;
+    case GCMF_TRIPOLAR_REGULAR_WITH_LAND_AREA_WEIGHTED: gi = {2, 1, 0, 1, 1, K_MASK}; return true;
+    case GCMF_TRIPOLAR_POP_WITH_LAND: gi = {6, 1, 1, 1, 0, K_FLUX}; return true;
+    case GCMF_VECTOR_C_GRID: gi = {14, 2, 1, 0, 0, K_CGRID}; return true;
+    case GCMF_VECTOR_B_GRID: gi = {8, 2, 1, 0, 0, K_BGRID}; return true;
+  }
+  return false;
+}
+
+static int step_dispatch(gcmf_plan *pl, const StepArgs &a, hipStream_t s) {
+  return pl->ncomp == 1 ? launch_scalar_step(pl, a, s) : launch_vector_step(pl, a, s);
+}
+
+static int ensure_work(gcmf_plan *pl, size_t bytes) {
+  if (bytes <= pl->work_bytes) return GCMF_OK;
+  if (pl->work) {
+    GCMF_HIP(hipFree(pl->work));
+    pl->work = nullptr;
+    pl->work_bytes = 0;
+  }
+  GCMF_HIP(hipMalloc(&pl->work, bytes));
+  pl->work_bytes = bytes;
+  return GCMF_OK;
+}
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace gcmf
+
+using namespace gcmf;
+
+extern "C" {
+
+const char *gcmf_last_error(void) { return g_err.c_str(); }
+int gcmf_version(void) { return GCMF_VERSION; }
+
+int gcmf_grid_nplanes(int gt) {
+  GridInfo gi;
+  return grid_info(gt, gi) ? gi.nplanes : -1;
+}
+int gcmf_grid_ncomp(int gt) {
+  GridInfo gi;
+  return grid_info(gt, gi) ? gi.ncomp : -1;
+}
+int gcmf_grid_is_dimensional(int gt) {
+  GridInfo gi;
+  return grid_info(gt, gi) ? gi.dimensional : -1;
+}
+int gcmf_grid_is_tripolar(int gt) {
+  GridInfo gi;
+  return grid_info(gt, gi) ? gi.tripolar : -1;
+}
+
+void gcmf_plan_destroy(gcmf_plan *pl) {
+  if (!pl) return;
+  (void)hipSetDevice(pl->d.device);
+  if (pl->stream) (void)hipStreamSynchronize(pl->stream);
+  for (void *p : pl->owned) (void)hipFree(p);
+  if (pl->work) (void)hipFree(pl->work);
+  if (pl->ev0) (void)hipEventDestroy(pl->ev0);
+  if (pl->ev1) (void)hipEventDestroy(pl->ev1);
+  if (pl->stream) (void)hipStreamDestroy(pl->stream);
+  delete pl;
+}
+
+int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int nplanes, gcmf_plan **out) {
+  if (!desc || !out) {
+    set_error("gcmf_plan_create: null argument");
+    return GCMF_ERR_INVALID_ARG;
+  }
+  *out = nullptr;
+  GridInfo gi;
+  if (!grid_info(desc->grid_type, gi)) {
+    set_error("gcmf_plan_create: unknown grid_type %d", desc->grid_type);
+    return GCMF_ERR_INVALID_ARG;
+  }
+  if (nplanes != gi.nplanes || (nplanes > 0 && !planes)) {
+    set_error("gcmf_plan_create: grid type %d needs %d grid planes, got %d", desc->grid_type, gi.nplanes, nplanes);
+    return GCMF_ERR_INVALID_ARG;
+  }
+  if (desc->dtype != GCMF_F32 && desc->dtype != GCMF_F64) {
+    set_error("gcmf_plan_create: bad dtype %d", desc->dtype);
+    return GCMF_ERR_INVALID_ARG;
+  }
+  if (desc->ny < 1 || desc->nx < 1 || desc->ny > (1 << 30) || desc->nx > (1 << 30) ||
+      desc->ny * desc->nx > (int64_t)2000000000) {
+    set_error("gcmf_plan_create: bad grid shape (%lld, %lld)", (long long)desc->ny, (long long)desc->nx);
+    return GCMF_ERR_INVALID_ARG;
+  }
+  if (desc->row_begin < 0 || desc->row_end > desc->ny || desc->row_begin >= desc->row_end || desc->halo < 0) {
+    set_error("gcmf_plan_create: bad row slab [%lld, %lld) of %lld rows", (long long)desc->row_begin,
+              (long long)desc->row_end, (long long)desc->ny);
+    return GCMF_ERR_INVALID_ARG;
+  }
+  for (int k = 0; k < nplanes; ++k)
+    if (!planes[k]) {
+      set_error("gcmf_plan_create: grid plane %d is NULL", k);
+      return GCMF_ERR_INVALID_ARG;
+    }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    set_error("no HIP device available (%s)", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return GCMF_ERR_NO_DEVICE;
+  }
+  GCMF_HIP(hipSetDevice(desc->device));
+
+  gcmf_plan *pl = new gcmf_plan();
+  pl->d = *desc;
+  pl->kind = gi.kind;
+  pl->ncomp = gi.ncomp;
+  pl->tripolar = gi.tripolar;
+  pl->area_weighted = gi.area_weighted;
+  pl->dimensional = gi.dimensional;
+  pl->full = (desc->row_begin == 0 && desc->row_end == desc->ny);
+  int64_t gs = 0, gn = 0;
+  if (!pl->full) {
+    if (desc->halo < 1) {
+      delete pl;
+      set_error("gcmf_plan_create: a partial row slab needs halo >= 1");
+      return GCMF_ERR_INVALID_ARG;
+    }
+    gs = (pl->tripolar && desc->row_begin == 0) ? 0 : desc->halo;
+    gn = (pl->tripolar && desc->row_end == desc->ny) ? 0 : desc->halo;
+  }
+  pl->rows_owned = desc->row_end - desc->row_begin;
+  pl->rows_alloc = gs + pl->rows_owned + gn;
+  pl->first_owned = gs;
+  Geom &g = pl->g;
+  g.nx = (int)desc->nx;
+  g.rows = (int)pl->rows_alloc;
+  g.south_wrap = pl->full && !pl->tripolar;
+  g.north_wrap = pl->full && !pl->tripolar;
+  g.fold = pl->tripolar && desc->row_end == desc->ny;
+  g.area_weighted = pl->area_weighted;
+
+  auto fail = [&](int rc) {
+    gcmf_plan_destroy(pl);
+    return rc;
+  };
+#define PLAN_HIP(call)                                                                 \
+  do {                                                                                 \
+    hipError_t e2_ = (call);                                                           \
+    if (e2_ != hipSuccess) {                                                           \
+      set_error("%s failed: %s", #call, hipGetErrorString(e2_));                       \
+      return fail(GCMF_ERR_HIP);                                                       \
+    }                                                                                  \
+  } while (0)
+  PLAN_HIP(hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking));
+  PLAN_HIP(hipEventCreate(&pl->ev0));
+  PLAN_HIP(hipEventCreate(&pl->ev1));
+
+  // stage the raw grid planes on the device (temporaries), fold them, free the temporaries
+  const size_t plane_bytes = (size_t)desc->ny * desc->nx * dtype_size(desc->dtype);
+  std::vector<const void *> dplanes(nplanes, nullptr);
+  std::vector<void *> staged;
+  int rc = GCMF_OK;
+  for (int k = 0; k < nplanes && rc == GCMF_OK; ++k) {
+    if (desc->planes_on_device) {
+      dplanes[k] = planes[k];
+      continue;
+    }
+    int dup = -1;  // the same host array passed twice (e.g. wet_mask_t is wet_mask_q) is uploaded once
+    for (int q = 0; q < k; ++q)
+      if (planes[q] == planes[k]) dup = q;
+    if (dup >= 0) {
+      dplanes[k] = dplanes[dup];
+      continue;
+    }
+    void *p = nullptr;
+    hipError_t e3 = hipMalloc(&p, plane_bytes);
+    if (e3 == hipSuccess) {
+      staged.push_back(p);
+      e3 = hipMemcpyAsync(p, planes[k], plane_bytes, hipMemcpyHostToDevice, pl->stream);
+    }
+    if (e3 != hipSuccess) {
+      set_error("staging grid plane %d failed: %s", k, hipGetErrorString(e3));
+      rc = GCMF_ERR_HIP;
+    }
+    dplanes[k] = p;
+  }
+  if (rc == GCMF_OK) rc = precompute(pl, dplanes.data(), desc->planes_on_device ? nullptr : planes);
+  (void)hipStreamSynchronize(pl->stream);
+  for (void *p : staged) (void)hipFree(p);
+  if (rc != GCMF_OK) return fail(rc);
+  *out = pl;
+  return GCMF_OK;
+#undef PLAN_HIP
+}
+
+int gcmf_plan_rows(const gcmf_plan *pl, int64_t *rows_alloc, int64_t *first_owned, int64_t *rows_owned) {
+  if (!pl) return GCMF_ERR_INVALID_ARG;
+  if (rows_alloc) *rows_alloc = pl->rows_alloc;
+  if (first_owned) *first_owned = pl->first_owned;
+  if (rows_owned) *rows_owned = pl->rows_owned;
+  return GCMF_OK;
+}
+
+int gcmf_set_timing(gcmf_plan *pl, int enabled) {
+  if (!pl) return GCMF_ERR_INVALID_ARG;
+  pl->timing = enabled != 0;
+  return GCMF_OK;
+}
+int gcmf_last_timing(const gcmf_plan *pl, float *ms_total, int *n_launches) {
+  if (!pl) return GCMF_ERR_INVALID_ARG;
+  if (ms_total) *ms_total = pl->last_ms;
+  if (n_launches) *n_launches = pl->last_launches;
+  return GCMF_OK;
+}
+int gcmf_set_tuning(gcmf_plan *pl, int rows_per_wave, int, int) {
+  if (!pl) return GCMF_ERR_INVALID_ARG;
+  if (rows_per_wave > 0) pl->rows_per_wave = rows_per_wave;
+  return GCMF_OK;
+}
+
+int gcmf_cheb_step(gcmf_plan *pl, const void *const *t1, const void *const *t2, const void *const *fbar_in,
+                   void *const *t0, void *const *fbar_out, double coef0, double coef1, double c, uint32_t mode,
+                   uint32_t flags, int64_t nbatch, int64_t row_lo, int64_t row_hi, void *stream) {
+  if (!pl || !t1 || !fbar_out) {
+    set_error("gcmf_cheb_step: null argument");
+    return GCMF_ERR_INVALID_ARG;
+  }
+  if (row_lo < 0 || row_hi > pl->rows_alloc || row_lo > row_hi) {
+    set_error("gcmf_cheb_step: rows [%lld, %lld) outside the slab allocation of %lld rows", (long long)row_lo,
+              (long long)row_hi, (long long)pl->rows_alloc);
+    return GCMF_ERR_INVALID_ARG;
+  }
+  std::lock_guard<std::mutex> lk(pl->mu);
+  GCMF_HIP(hipSetDevice(pl->d.device));
+  StepArgs a{};
+  for (int k = 0; k < pl->ncomp; ++k) {
+    a.t1[k] = t1[k];
+    a.t2[k] = t2 ? t2[k] : nullptr;
+    a.fb_in[k] = fbar_in ? fbar_in[k] : nullptr;
+    a.t0[k] = t0 ? t0[k] : nullptr;
+    a.fb_out[k] = fbar_out[k];
+  }
+  a.coef0 = coef0;
+  a.coef1 = coef1;
+  a.c = c;
+  a.mode = mode & (GCMF_STEP_FIRST | GCMF_STEP_LAST);
+  a.fb_is_f32 = (pl->d.dtype == GCMF_F32) && (flags & GCMF_OUT_F32);
+  a.nbatch = nbatch;
+  a.row_lo = (int)row_lo;
+  a.row_hi = (int)row_hi;
+  return step_dispatch(pl, a, (hipStream_t)stream);
+}
+
+int gcmf_prepare(gcmf_plan *pl, const void *const *in, void *const *out, int64_t nbatch, int64_t row_lo,
+                 int64_t row_hi, void *stream) {
+  if (!pl || !in || !out) return GCMF_ERR_INVALID_ARG;
+  if (row_lo < 0 || row_hi > pl->rows_alloc || row_lo > row_hi) return GCMF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(pl->mu);
+  GCMF_HIP(hipSetDevice(pl->d.device));
+  return launch_prepare(pl, in, out, nbatch, (int)row_lo, (int)row_hi, (hipStream_t)stream);
+}
+
+// Shared driver of gcmf_apply and gcmf_laplacian.
+static int run_whole(gcmf_plan *pl, const double *p, int n_steps, double c, const void *const *in, void *const *out,
+                     int64_t nbatch, uint32_t flags, void *stream, bool lapl_only) {
+  if (!pl || !in || !out || nbatch < 0 || (!lapl_only && (!p || n_steps < 1))) {
+    set_error("gcmf_apply: bad argument");
+    return GCMF_ERR_INVALID_ARG;
+  }
+  for (int k = 0; k < pl->ncomp; ++k)
+    if (!in[k] || !out[k]) {
+      set_error("gcmf_apply: null component pointer");
+      return GCMF_ERR_INVALID_ARG;
+    }
+  if (!pl->full) {
+    set_error("gcmf_apply / gcmf_laplacian need a plan covering the whole grid; use gcmf_cheb_step on row slabs");
+    return GCMF_ERR_INVALID_ARG;
+  }
+  if (nbatch == 0) return GCMF_OK;
+  std::lock_guard<std::mutex> lk(pl->mu);
+  GCMF_HIP(hipSetDevice(pl->d.device));
+  const bool on_dev = flags & GCMF_DEVICE_PTRS;
+  // device pointers: run on exactly the caller's stream (NULL = the HIP default stream) so the work is
+  // ordered with the caller's own kernels; host pointers: the plan's private stream unless one is given
+  hipStream_t s = (on_dev || stream) ? (hipStream_t)stream : pl->stream;
+  const bool f32 = pl->d.dtype == GCMF_F32;
+  const bool fb32 = f32 && (flags & GCMF_OUT_F32);
+  const size_t ts = dtype_size(pl->d.dtype);
+  const size_t fbs = lapl_only ? ts : ((f32 && !fb32) ? 8 : ts);  // element size of fbar == element size of `out`
+  const size_t ncell = (size_t)nbatch * pl->d.ny * pl->d.nx;
+  const int nc = pl->ncomp;
+  const bool prep = pl->area_weighted && !lapl_only;
+
+  // work layout per component: [A][B][fbar] (+ [prepared T0]) (+ host staging: [in][out])
+  const size_t szT = align_up(ncell * ts, 256), szF = align_up(ncell * fbs, 256);
+  size_t per = 0;
+  const size_t oA = per; per += szT;
+  const size_t oB = per; per += szT;
+  const size_t oF = per; per += szF;
+  const size_t oP = per; if (prep) per += szT;
+  const size_t oIn = per; if (!on_dev) per += szT;
+  const size_t oOut = per; if (!on_dev) per += szF;
+  int rc = ensure_work(pl, per * nc);
+  if (rc) return rc;
+  char *w = (char *)pl->work;
+  const void *din[2];
+  void *dout[2], *A[2], *B[2], *F[2], *Pp[2];
+  for (int k = 0; k < nc; ++k) {
+    char *base = w + per * k;
+    A[k] = base + oA;
+    B[k] = base + oB;
+    F[k] = base + oF;
+    Pp[k] = base + oP;
+    if (on_dev) {
+      din[k] = in[k];
+      dout[k] = out[k];
+    } else {
+      din[k] = base + oIn;
+      dout[k] = base + oOut;
+      GCMF_HIP(hipMemcpyAsync(base + oIn, in[k], ncell * ts, hipMemcpyHostToDevice, s));
+    }
+  }
+  const int rows = (int)pl->rows_alloc;
+  int launches = 0;
+  if (pl->timing) GCMF_HIP(hipEventRecord(pl->ev0, s));
+  if (lapl_only) {
+    StepArgs a{};
+    for (int k = 0; k < nc; ++k) { a.t1[k] = din[k]; a.t0[k] = dout[k]; a.fb_out[k] = nullptr; }
+    a.mode = STEP_LAPL;
+    a.nbatch = nbatch;
+    a.row_lo = 0;
+    a.row_hi = rows;
+    if ((rc = step_dispatch(pl, a, s))) return rc;
+    ++launches;
+  } else {
+    const void *x0[2] = {din[0], din[1]};
+    if (prep) {  // T_0 = field * area
+      if ((rc = launch_prepare(pl, din, Pp, nbatch, 0, rows, s))) return rc;
+      ++launches;
+      for (int k = 0; k < nc; ++k) x0[k] = Pp[k];
+    }
+    // step k reads T_{k-1} (stencil) and T_{k-2} (centre) and overwrites T_{k-2}'s buffer with T_k:
+    //   k=1: X0 -> A      k=2: (A, X0) -> B      k=3: (B, A) -> A      k=4: (A, B) -> B ...
+    for (int k = 1; k <= n_steps; ++k) {
+      StepArgs a{};
+      a.mode = (k == 1 ? GCMF_STEP_FIRST : 0u) | (k == n_steps ? GCMF_STEP_LAST : 0u);
+      a.coef0 = (k == 1) ? p[0] : p[k];
+      a.coef1 = p[1];
+      a.c = c;
+      a.fb_is_f32 = fb32;
+      a.nbatch = nbatch;
+      a.row_lo = 0;
+      a.row_hi = rows;
+      for (int q = 0; q < nc; ++q) {
+        if (k == 1) { a.t1[q] = x0[q]; a.t2[q] = nullptr; a.t0[q] = A[q]; }
+        else if (k == 2) { a.t1[q] = A[q]; a.t2[q] = x0[q]; a.t0[q] = B[q]; }
+        else if (k % 2) { a.t1[q] = B[q]; a.t2[q] = A[q]; a.t0[q] = A[q]; }
+        else { a.t1[q] = A[q]; a.t2[q] = B[q]; a.t0[q] = B[q]; }
+        a.fb_in[q] = F[q];
+        a.fb_out[q] = (k == n_steps) ? dout[q] : F[q];
+      }
+      if ((rc = step_dispatch(pl, a, s))) return rc;
+      ++launches;
+    }
+  }
+  if (pl->timing) GCMF_HIP(hipEventRecord(pl->ev1, s));
+  pl->last_launches = launches;
+  if (!on_dev) {
+    for (int k = 0; k < nc; ++k)
+      GCMF_HIP(hipMemcpyAsync(out[k], dout[k], ncell * fbs, hipMemcpyDeviceToHost, s));
+    GCMF_HIP(hipStreamSynchronize(s));
+  }
+  if (pl->timing) {
+    GCMF_HIP(hipEventSynchronize(pl->ev1));
+    GCMF_HIP(hipEventElapsedTime(&pl->last_ms, pl->ev0, pl->ev1));
+  }
+  return GCMF_OK;
+}
+
+int gcmf_apply(gcmf_plan *pl, const double *p, int n_steps, double c, const void *const *in, void *const *out,
+               int64_t nbatch, uint32_t flags, void *stream) {
+  return run_whole(pl, p, n_steps, c, in, out, nbatch, flags, stream, false);
+}
+
+int gcmf_laplacian(gcmf_plan *pl, const void *const *in, void *const *out, int64_t nbatch, uint32_t flags,
+                   void *stream) {
+  return run_whole(pl, nullptr, 0, 0.0, in, out, nbatch, flags, stream, true);
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+// Internal declarations shared by the libgcmf translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "gcmf.h"
+
+namespace gcmf {
+
+// Stencil families.  Every reference Laplacian maps onto one of them after plan-time folding.
+enum Kind : int {
+  K_REG = 0,   // REGULAR, REGULAR_AREA_WEIGHTED: 5-point, no coefficients              (40 B/cell.step f64)
+  K_MASK = 1,  // *_WITH_LAND regular grids + tripolar regular: 1 byte of neighbour bits (41 B)
+  K_FLUX = 2,  // IRREGULAR / POP / MOM5U / MOM5T: east-face, north-face, 1/area planes  (64 B)
+  K_CGRID = 3, // VECTOR_C_GRID: 14 folded planes
+  K_BGRID = 4  // VECTOR_B_GRID: 8 folded planes
+};
+
+// internal mode bit on top of GCMF_STEP_FIRST / GCMF_STEP_LAST
+constexpr unsigned STEP_LAPL = 0x100u;  // t0 = L(t1) only (gcmf_laplacian)
+
+constexpr int MAX_COEF = 14;
+
+void set_error(const char *fmt, ...);
+const char *hip_err_name(hipError_t e);
+
+#define GCMF_HIP(call)                                                                    \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      ::gcmf::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? GCMF_ERR_NO_DEVICE : GCMF_ERR_HIP; \
+    }                                                                                     \
+  } while (0)
+
+// Device-side view of the slab geometry + coefficient planes, passed by value to kernels.
+struct Geom {
+  int nx;          // columns (never sharded; x is periodic)
+  int rows;        // rows in the slab allocation (owned + ghost)
+  int south_wrap;  // row 0's southern neighbour is row rows-1 (single slab, periodic in y)
+  int north_wrap;  // row rows-1's northern neighbour is row 0
+  int fold;        // row rows-1's northern neighbour is itself mirrored in x (tripole seam)
+  int area_weighted;
+  const void *coef[MAX_COEF];  // K_FLUX: cE, cN, ra;  K_CGRID: 14;  K_BGRID: 8
+  const uint8_t *mbits;        // K_MASK: bit0 wet, bit1 E wet, bit2 W wet, bit3 N wet, bit4 S wet
+  const void *area;            // prepare / finalize plane (area-weighted types)
+};
+
+// Arguments of one recurrence step (device pointers, per component).
+struct StepArgs {
+  const void *t1[2];
+  const void *t2[2];
+  const void *fb_in[2];
+  void *t0[2];
+  void *fb_out[2];
+  double coef0, coef1, c;
+  unsigned mode;
+  int fb_is_f32;  // f32 plans only: fbar arrays are f32 (GCMF_OUT_F32)
+  int64_t nbatch;
+  int row_lo, row_hi;
+};
+
+}  // namespace gcmf
+
+struct gcmf_plan {
+  gcmf_plan_desc d{};
+  int kind = 0;
+  int ncomp = 1;
+  bool tripolar = false;
+  bool area_weighted = false;
+  bool dimensional = false;
+  bool full = true;  // single slab covering the whole grid
+  int64_t rows_alloc = 0, first_owned = 0, rows_owned = 0;
+  gcmf::Geom g{};
+  std::vector<void *> owned;  // device allocations freed at destroy
+  // work buffers of gcmf_apply (grow-only)
+  void *work = nullptr;
+  size_t work_bytes = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timing = false;
+  float last_ms = 0.f;
+  int last_launches = 0;
+  int rows_per_wave = 0;
+  std::mutex mu;
+};
+
+namespace gcmf {
+size_t dtype_size(int dtype);
+// kernel launchers (defined in gcmf_scalar.hip / gcmf_vector.hip)
+int launch_scalar_step(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
+int launch_vector_step(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
+int launch_prepare(gcmf_plan *pl, const void *const *in, void *const *out, int64_t nbatch, int row_lo,
+                   int row_hi, hipStream_t s);
+// plan-time precompute (gcmf_precompute.hip): fills pl->g from the raw global planes (device pointers)
+int precompute(gcmf_plan *pl, const void *const *dplanes, const void *const *hplanes_or_null);
+}  // namespace gcmf

@@ -1,0 +1,396 @@
+"""``Filter`` -- drop-in for ``gcm_filters.Filter`` (reference gcm_filters/filter.py) on MI355X.
+
+Host side (this file): the filter-polynomial fit (n_steps, s_max, Chebyshev coefficients p) and the
+xarray / array front door.  Device side (libgcmf): the whole n_steps recurrence and the Laplacian stencils.
+Names, signatures, defaults, exceptions and warnings follow the reference so that existing user code and
+the reference's own tests read the same.
+"""
+from __future__ import annotations
+
+import enum
+import warnings
+from dataclasses import dataclass, field
+from typing import Iterable, NamedTuple
+
+import numpy as np
+
+from .kernels import (
+    ALL_KERNELS,
+    AreaWeightedMixin,
+    BaseScalarLaplacian,
+    BaseVectorLaplacian,
+    GridType,
+    _is_torch,
+)
+
+FilterShape = enum.Enum("FilterShape", ["GAUSSIAN", "TAPER"])
+
+# coefficients of the default-n_steps rule, keyed [shape][ndim] (reference filter.py:28-37)
+filter_params = {
+    FilterShape.GAUSSIAN: {
+        1: {"offset": 0.8, "factor": 0.0, "exponent": 1},
+        2: {"offset": 1.1, "factor": 0.0, "exponent": 1},
+    },
+    FilterShape.TAPER: {
+        1: {"offset": 2.2, "factor": 0.6, "exponent": 2.5},
+        2: {"offset": 3.2, "factor": 0.7, "exponent": 2.7},
+    },
+}
+
+
+class TargetSpec(NamedTuple):
+    s_max: float
+    filter_scale: float
+    transition_width: float
+
+
+class FilterSpec(NamedTuple):
+    n_steps: int
+    s_max: float
+    p: Iterable[float]
+    dx_min_sq: float
+
+
+# ------------------------------------------------------------------------------------------------
+# target transfer functions F(t), t in [-1, 1]  <->  s = k^2 = s_max (t + 1) / 2
+# ------------------------------------------------------------------------------------------------
+def _gaussian_target(target_spec: TargetSpec):
+    """exp(-k^2 L^2 / 24) (reference filter.py:47-50)."""
+    s_max, scale = target_spec.s_max, target_spec.filter_scale
+    return lambda t: np.exp(-(s_max * (t + 1) / 2) * scale ** 2 / 24)
+
+
+def _pchip_slopes(x, y):
+    """Fritsch-Carlson monotone slopes with the three-point end formula SciPy's PchipInterpolator uses."""
+    h = np.diff(x)
+    m = np.diff(y) / h
+    n = len(x)
+    d = np.zeros(n)
+    for k in range(1, n - 1):
+        if m[k - 1] * m[k] > 0:
+            w1, w2 = 2 * h[k] + h[k - 1], h[k] + 2 * h[k - 1]
+            d[k] = (w1 + w2) / (w1 / m[k - 1] + w2 / m[k])
+
+    def end(h0, h1, m0, m1):
+        s = ((2 * h0 + h1) * m0 - h0 * m1) / (h0 + h1)
+        if np.sign(s) != np.sign(m0):
+            return 0.0
+        if np.sign(m0) != np.sign(m1) and abs(s) > 3 * abs(m0):
+            return 3 * m0
+        return s
+
+    d[0] = end(h[0], h[1], m[0], m[1])
+    d[-1] = end(h[-1], h[-2], m[-1], m[-2])
+    return d
+
+
+def _pchip(x, y):
+    """Piecewise-cubic Hermite interpolant through (x, y) with PCHIP slopes; returns a vectorised callable."""
+    x = np.asarray(x, dtype=float)
+    y = np.asarray(y, dtype=float)
+    d = _pchip_slopes(x, y)
+    h = np.diff(x)
+    m = np.diff(y) / h
+    # local cubic  y_k + d_k s + c2 s^2 + c3 s^3,  s = q - x_k
+    c2 = (3 * m - 2 * d[:-1] - d[1:]) / h
+    c3 = (d[:-1] + d[1:] - 2 * m) / h ** 2
+
+    def ev(q):
+        q = np.asarray(q, dtype=float)
+        k = np.clip(np.searchsorted(x, q, side="right") - 1, 0, len(x) - 2)
+        s = q - x[k]
+        return y[k] + s * (d[k] + s * (c2[k] + s * c3[k]))
+
+    return ev
+
+
+def _taper_target(target_spec: TargetSpec):
+    """1 for k <= 2 pi/(X L), 0 for k >= 2 pi/L, PCHIP in between (reference filter.py:53-65)."""
+    s_max, scale, width = target_spec
+    knots = [0, 2 * np.pi / (width * scale), 2 * np.pi / scale, 8 * np.sqrt(s_max)]
+    fk = _pchip(knots, [1, 1, 0, 0])
+    return lambda t: fk(np.sqrt((t + 1) * (s_max / 2)))
+
+
+_target_function = {FilterShape.GAUSSIAN: _gaussian_target, FilterShape.TAPER: _taper_target}
+
+
+def _compute_n_steps_default(ndim, filter_shape, filter_scale, dx_min, transition_width):
+    """Default polynomial degree for 1-D / 2-D filters (reference filter.py:74-89)."""
+    prm = filter_params[filter_shape][ndim]
+    per_unit = prm["offset"] + prm["factor"] * ((np.pi / transition_width) ** prm["exponent"])
+    return max(np.ceil(per_unit * (filter_scale / dx_min)).astype(int), 3)
+
+
+def _cheb_T(x, n):
+    """Rows T_0(x) .. T_n(x) by the three-term recurrence."""
+    T = np.empty((n + 1, len(x)))
+    T[0] = 1.0
+    if n >= 1:
+        T[1] = x
+    for k in range(2, n + 1):
+        T[k] = 2 * x * T[k - 1] - T[k - 2]
+    return T
+
+
+def _compute_filter_spec(filter_scale, dx_min, filter_shape, transition_width=np.pi, ndim=2, n_steps=0):
+    """Chebyshev coefficients of the degree-n_steps polynomial that best fits the target on [-1, 1]
+    subject to p(-1) = 1 (mean conservation) and p(1) = F(1)  (reference filter.py:99-151).
+
+    Galerkin projection onto phi_i = T_i - T_{i+2} (Shen 1995) with Chebyshev-Gauss quadrature on
+    n_steps + 1 nodes; the boundary values are carried by a linear lifting."""
+    n = int(n_steps)
+    s_max = ndim * (2 / dx_min) ** 2
+    F = _target_function[filter_shape](TargetSpec(s_max, filter_scale, transition_width))
+    # quadrature: x_q = cos(pi (2q - 1) / (2 (n + 1))), q = 1..n+1, equal weights pi / (n + 1)
+    nq = n + 1
+    xq = np.cos(np.pi * np.arange(1, 2 * nq, 2) / (2.0 * nq))
+    wq = np.full(nq, np.pi / nq)
+    T = _cheb_T(xq, n)
+    F1 = F(np.asarray(1.0))
+    resid = F(xq) - ((1 - xq) / 2 + F1 * (xq + 1) / 2)
+    phi = T[: n - 1] - T[2: n + 1]
+    b = (phi * (wq * resid)).sum(axis=1)
+    # <phi_i, phi_j>_w : pi/2 (2 delta_ij - delta_{i,j+-2}), with the T_0 term doubling the (0,0) entry
+    M = (np.pi / 2) * (2 * np.eye(n - 1) - np.diag(np.ones(n - 3), 2) - np.diag(np.ones(n - 3), -2))
+    M[0, 0] = 3 * np.pi / 2
+    c_hat = np.linalg.solve(M, b)
+    p = np.zeros(n + 1)
+    p[: n - 1] += c_hat          # + c_i T_i
+    p[2:] -= c_hat               # - c_i T_{i+2}
+    p[0] += (1 + F1) / 2         # lifting (1 - x)/2 + F(1)(1 + x)/2 in the Chebyshev basis
+    p[1] -= (1 - F1) / 2
+    return FilterSpec(n, s_max, p, dx_min ** 2)
+
+
+# ------------------------------------------------------------------------------------------------
+# the operator interface xarray.apply_ufunc calls (reference filter.py:154-291)
+# ------------------------------------------------------------------------------------------------
+def _create_filter_func(filter_spec: FilterSpec, Laplacian):
+    """Returns ``filter_func(field, *grid_args)``: first argument the field (last two axes = y, x; leading
+    axes are independent batches), then the grid variables in ``Laplacian.required_grid_args()`` order."""
+
+    def filter_func(field, *args):
+        assert len(args) == len(Laplacian.required_grid_args())
+        laplacian = Laplacian(*args)  # device plan: cached while the grid arrays are unchanged
+        return laplacian._run([field], spec=filter_spec)[0]
+
+    return filter_func
+
+
+def _create_filter_func_vec(filter_spec: FilterSpec, Laplacian):
+    """Returns ``filter_func_vec(u, v, *grid_args) -> (u_filtered, v_filtered)``."""
+
+    def filter_func_vec(ufield, vfield, *args):
+        assert len(args) == len(Laplacian.required_grid_args())
+        laplacian = Laplacian(*args)
+        u, v = laplacian._run([ufield, vfield], spec=filter_spec)
+        return (u, v)
+
+    return filter_func_vec
+
+
+def _xarray():
+    try:
+        import xarray as xr
+        return xr
+    except ImportError:
+        return None
+
+
+def _is_bare_array(x) -> bool:
+    return isinstance(x, np.ndarray) or _is_torch(x)
+
+
+@dataclass
+class Filter:
+    """A class for applying diffusion-based smoothing filters to gridded data.
+
+    Parameters
+    ----------
+    filter_scale : float
+        The filter scale, which has different meaning depending on filter shape
+    dx_min : float
+        The smallest grid spacing. Should have same units as ``filter_scale``
+    n_steps : int, optional
+        Number of total steps in the filter (``0``: chosen automatically)
+    filter_shape : FilterShape
+        ``GAUSSIAN``: target :math:`e^{-(k L)^2/24}`; ``TAPER``: sharp cut-off at scale L
+    transition_width : float, optional
+        Width of the transition region of the Taper filter (> 1)
+    ndim : int, optional
+        Dimension of the grid the Laplacian acts on
+    grid_type : GridType
+    grid_vars : dict
+        Grid variables required by ``grid_type`` (see ``required_grid_vars``); xarray DataArrays, numpy
+        arrays or torch tensors (host or MI355X-resident)
+
+    Attributes
+    ----------
+    filter_spec: FilterSpec
+    """
+
+    filter_scale: float
+    dx_min: float
+    filter_shape: FilterShape = FilterShape.GAUSSIAN
+    transition_width: float = np.pi
+    ndim: int = 2
+    n_steps: int = 0
+    grid_type: GridType = GridType.REGULAR
+    grid_vars: dict = field(default_factory=dict, repr=False)
+
+    def __post_init__(self):
+        self.Laplacian = ALL_KERNELS[self.grid_type]
+
+        if issubclass(self.Laplacian, AreaWeightedMixin) and self.dx_min != 1:
+            raise ValueError(
+                "Provided Laplacian is for simple fixed factor filtering, "
+                "where transformed field is filtered on a regular grid with dx = dy = 1. "
+                "dx_min must be set to 1."
+            )
+        if self.transition_width <= 1:
+            raise ValueError("Transition width must be > 1.")
+
+        if self.ndim > 2:
+            if self.n_steps < 3:
+                raise ValueError("When ndim > 2, you must set n_steps manually")
+            n_steps_default = self.n_steps
+        else:
+            n_steps_default = _compute_n_steps_default(
+                self.ndim, self.filter_shape, self.filter_scale, self.dx_min, self.transition_width
+            )
+        if self.n_steps < 3:
+            self.n_steps = n_steps_default
+        if self.n_steps < n_steps_default:
+            warnings.warn("You have set n_steps below the default. Results might not be accurate.", stacklevel=2)
+
+        self.filter_spec = _compute_filter_spec(
+            self.filter_scale, self.dx_min, self.filter_shape, self.transition_width, self.ndim, self.n_steps
+        )
+
+        if not set(self.Laplacian.required_grid_args()) == set(self.grid_vars):
+            raise ValueError(
+                f"Provided `grid_vars` {list(self.grid_vars)} do not match expected "
+                f"{list(self.Laplacian.required_grid_args())}"
+            )
+        xr = _xarray()
+        if xr is not None and all(isinstance(v, (xr.DataArray, xr.Variable)) for v in self.grid_vars.values()):
+            self.grid_ds = xr.Dataset({name: da for name, da in self.grid_vars.items()})
+        else:
+            self.grid_ds = dict(self.grid_vars)
+
+    # -- cosmetics ----------------------------------------------------------------------------
+    def plot_shape(self, ax=None):
+        """Plot the shape of the target filter and approximation."""
+        import matplotlib.pyplot as plt
+
+        s_max = self.filter_spec.s_max
+        F = _target_function[self.filter_shape](TargetSpec(s_max, self.filter_scale, self.transition_width))
+        x = np.linspace(-1, 1, 10001)
+        k = np.sqrt(s_max * (x + 1) / 2)
+        if ax is None:
+            _, ax = plt.subplots()
+        ax.plot(k, F(x), "g", label="target filter", linewidth=4)
+        approx = (np.asarray(self.filter_spec.p)[:, None] * _cheb_T(x, self.filter_spec.n_steps)).sum(axis=0)
+        ax.plot(k, approx, "m", label="approximation", linewidth=4)
+        ax.axvline(2 * np.pi / self.filter_scale, color="k", label="filter cutoff wavenumber", linewidth=2)
+        ax.set_xlim(left=0)
+        if self.filter_scale / self.dx_min > 10:
+            ax.set_xlim(right=4 * np.pi / self.filter_scale)
+        ax.set_ylim(bottom=-0.1)
+        ax.set_ylim(top=1.1)
+        ax.set_xlabel("Wavenumber k", fontsize=18)
+        ax.grid(True)
+        ax.legend()
+
+    # -- scalar fields ------------------------------------------------------------------------
+    def apply(self, ds, dims=None):
+        """Filter an ``xarray.DataArray`` / ``xarray.Dataset`` with a scalar Laplacian across ``dims``
+        (two names, latitude-like dimension first).
+
+        Extension: a bare ``numpy.ndarray`` or ``torch.Tensor`` (``dims`` omitted) is filtered over its
+        last two axes (y, x), leading axes being independent batches -- exactly what ``apply_ufunc`` hands
+        to ``filter_func``; an MI355X-resident tensor is filtered in place in HBM and returned as a tensor.
+        """
+        if issubclass(self.Laplacian, BaseVectorLaplacian):
+            raise ValueError(
+                f"Provided Laplacian {self.Laplacian} is a vector Laplacian. "
+                f"The ``.apply`` method is only suitable for scalar Laplacians."
+            )
+        if _is_bare_array(ds):
+            return _create_filter_func(self.filter_spec, self.Laplacian)(ds, *self._grid_args_bare())
+        xr = _xarray()
+        if xr is not None and isinstance(ds, xr.Dataset):
+            filtered = ds.copy(deep=True)
+            any_filtered = False
+            for key, var in filtered.variables.items():
+                if all(dim in var.dims for dim in dims):
+                    filtered[key] = self._apply_to_dataarray(var, dims=dims)
+                    any_filtered = True
+            if not any_filtered:
+                warnings.warn(
+                    f"No variables in the dataset had all of the given "
+                    f"dimensions ({dims}), so nothing was filtered.",
+                    stacklevel=2,
+                )
+            return filtered
+        return self._apply_to_dataarray(ds, dims=dims)
+
+    def _grid_args_bare(self):
+        return [self.grid_vars[name] for name in self.Laplacian.required_grid_args()]
+
+    def _grid_args_xr(self):
+        xr = _xarray()
+        names = self.Laplacian.required_grid_args()
+        if isinstance(self.grid_ds, dict):
+            missing_dims = [n for n in names if not hasattr(self.grid_ds[n], "dims")]
+            if missing_dims:
+                raise TypeError(f"grid_vars {missing_dims} must be xarray DataArrays to filter xarray objects")
+        return [self.grid_ds[name] for name in names]
+
+    def _apply_to_dataarray(self, field, dims):
+        xr = _xarray()
+        if xr is None:
+            raise ImportError("xarray is required to filter xarray objects; pass a numpy array or torch tensor instead")
+        filter_func = _create_filter_func(self.filter_spec, self.Laplacian)
+        grid_args = self._grid_args_xr()
+        assert len(dims) == 2
+        n_args = 1 + len(grid_args)
+        return xr.apply_ufunc(
+            filter_func,
+            field,
+            *grid_args,
+            input_core_dims=n_args * [dims],
+            output_core_dims=[dims],
+            output_dtypes=[field.dtype],
+            dask="parallelized",
+        )
+
+    # -- vector fields ------------------------------------------------------------------------
+    def apply_to_vector(self, ufield, vfield, dims=None):
+        """Filter a vector field (u, v) with a vector Laplacian across ``dims``; bare arrays as in ``apply``."""
+        if not issubclass(self.Laplacian, BaseVectorLaplacian):
+            raise ValueError(
+                f"Provided Laplacian {self.Laplacian} is a scalar Laplacian. "
+                f"The ``.apply_to_vector`` method is only suitable for vector Laplacians."
+            )
+        filter_func_vec = _create_filter_func_vec(self.filter_spec, self.Laplacian)
+        if _is_bare_array(ufield) and _is_bare_array(vfield):
+            return filter_func_vec(ufield, vfield, *self._grid_args_bare())
+        xr = _xarray()
+        if xr is None:
+            raise ImportError("xarray is required to filter xarray objects; pass numpy arrays or torch tensors instead")
+        grid_args = self._grid_args_xr()
+        assert len(dims) == 2
+        n_args = 2 + len(grid_args)
+        (ufield_smooth, vfield_smooth) = xr.apply_ufunc(
+            filter_func_vec,
+            ufield,
+            vfield,
+            *grid_args,
+            input_core_dims=n_args * [dims],
+            output_core_dims=2 * [dims],
+            output_dtypes=[ufield.dtype, vfield.dtype],
+            dask="parallelized",
+        )
+        return (ufield_smooth, vfield_smooth)

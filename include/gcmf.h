@@ -1,0 +1,183 @@
+/*
+ * gcmf.h -- C ABI of libgcmf, the MI355X (gfx950) implementation of the gcm-filters hot path.
+ *
+ * Drop-in boundary.  The reference (pure Python) has no FFI; the operator interface this library
+ * replaces is the pair of closures created per Filter and called by xarray.apply_ufunc with raw
+ * arrays whose last two axes are (y, x):
+ *
+ *     filter_func(field, *grid_args)            -> ndarray      gcm_filters/filter.py:177-212
+ *     filter_func_vec(u, v, *grid_args)         -> (nd, nd)     gcm_filters/filter.py:242-289
+ *
+ * and the kernel plug-in protocol they drive                      gcm_filters/kernels.py:43-104
+ *
+ *     Laplacian(**grid_vars)   validation + precompute            -> gcmf_plan_create
+ *     .prepare / .__call__ / .finalize                            -> gcmf_laplacian (one application)
+ *     the n_steps recurrence around them                          -> gcmf_apply (whole polynomial)
+ *
+ * Everything is plain pointers and sizes; no torch / numpy types.  All entry points are thread-safe
+ * with respect to *different* plans; calls on one plan are serialised by a per-plan mutex.
+ *
+ * Array conventions: C order, (nbatch, ny, nx) with x fastest.  Grid planes are 2-D (ny, nx) and
+ * shared by every batch entry.  "Rows" are indices along y (the slow, sharded axis).
+ */
+#ifndef GCMF_H
+#define GCMF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCMF_VERSION 1
+
+/* ---- status codes -------------------------------------------------------------------------- */
+typedef enum gcmf_status {
+  GCMF_OK = 0,
+  GCMF_ERR_INVALID_ARG = 1, /* bad pointer / size / enum / plane count                        */
+  GCMF_ERR_HIP = 2,         /* a HIP runtime call failed; text in gcmf_last_error()           */
+  GCMF_ERR_NO_DEVICE = 3,   /* no gfx950 device visible                                       */
+  GCMF_ERR_UNSUPPORTED = 4,
+  /* Validation failures of the reference's Laplacian constructors.  The Python layer turns
+   * them into the reference's exception type and message.                                   */
+  GCMF_ERR_KAPPA_W_GT1 = 16,    /* ValueError  kernels.py:262-266                             */
+  GCMF_ERR_KAPPA_S_GT1 = 17,    /* ValueError  kernels.py:268-272                             */
+  GCMF_ERR_KAPPA_NONE_ONE = 18, /* ValueError  kernels.py:274-281                             */
+  GCMF_ERR_WET_SOUTH_ROW = 19,  /* AssertionError kernels.py:458-459, 521-522                 */
+  GCMF_ERR_DXN_FOLD = 20,       /* AssertionError kernels.py:551-554                          */
+  GCMF_ERR_DYN_FOLD = 21        /* AssertionError kernels.py:559-562                          */
+} gcmf_status;
+
+/* ---- enums --------------------------------------------------------------------------------- */
+/* Values equal the reference's GridType enum values (gcm_filters/kernels.py:13-28). */
+typedef enum gcmf_grid_type {
+  GCMF_REGULAR = 1,
+  GCMF_REGULAR_AREA_WEIGHTED = 2,
+  GCMF_REGULAR_WITH_LAND = 3,
+  GCMF_REGULAR_WITH_LAND_AREA_WEIGHTED = 4,
+  GCMF_IRREGULAR_WITH_LAND = 5,
+  GCMF_MOM5U = 6,
+  GCMF_MOM5T = 7,
+  GCMF_TRIPOLAR_REGULAR_WITH_LAND_AREA_WEIGHTED = 8,
+  GCMF_TRIPOLAR_POP_WITH_LAND = 9,
+  GCMF_VECTOR_C_GRID = 10,
+  GCMF_VECTOR_B_GRID = 11
+} gcmf_grid_type;
+
+typedef enum gcmf_dtype { GCMF_F32 = 0, GCMF_F64 = 1 } gcmf_dtype;
+
+/* gcmf_apply / gcmf_laplacian flags */
+#define GCMF_DEVICE_PTRS 0x1u /* in/out are device pointers on the plan's device (else host)  */
+#define GCMF_OUT_F32 0x2u     /* f32 plan only: write f32 output (default: f64, as NumPy >= 2 */
+                              /* promotes p[k]*T)                       */
+
+/* Chebyshev step modes for gcmf_cheb_step */
+#define GCMF_STEP_FIRST 0x1u /* T1 = A(T0);            fbar  = p0*T0 + p1*T1                  */
+#define GCMF_STEP_LAST 0x2u  /* fbar result is finalised (divided by area) into fbar_out      */
+
+typedef struct gcmf_plan gcmf_plan;
+
+/* ---- plan ---------------------------------------------------------------------------------- */
+typedef struct gcmf_plan_desc {
+  int32_t grid_type;  /* gcmf_grid_type                                                        */
+  int32_t dtype;      /* gcmf_dtype of the grid planes, the recurrence state T_k and L(f)      */
+  int64_t ny, nx;     /* GLOBAL grid shape                                                     */
+  int64_t row_begin;  /* rows [row_begin, row_end) of the global grid are owned by this plan   */
+  int64_t row_end;    /*   single GPU: 0, ny                                                   */
+  int32_t halo;       /* ghost rows kept on each slab edge that has a neighbour (0: one GPU)   */
+  int32_t device;     /* HIP device ordinal                                                    */
+  int32_t planes_on_device; /* grid planes are device pointers on `device`                     */
+  int32_t reserved;
+} gcmf_plan_desc;
+
+/*
+ * Build a plan = the reference's `Laplacian(**grid_vars)` (kernels.py __post_init__ methods):
+ * validates the grid planes, folds masks / kappas / metric ratios into coefficient planes resident
+ * in HBM, and sizes the recurrence state.  `planes` holds `nplanes` GLOBAL (ny, nx) arrays of
+ * `desc->dtype`, in the order of `required_grid_args()` of the reference class (kernels.py:58-63):
+ *
+ *   REGULAR: -            REGULAR_AREA_WEIGHTED: area      REGULAR_WITH_LAND: wet_mask
+ *   REGULAR_WITH_LAND_AREA_WEIGHTED / TRIPOLAR_REGULAR_...: area, wet_mask
+ *   IRREGULAR_WITH_LAND: wet_mask,dxw,dyw,dxs,dys,area,kappa_w,kappa_s
+ *   MOM5U: wet_mask,dxt,dyt,dxu,dyu,area_u      MOM5T: wet_mask,dxt,dyt,dxu,dyu,area_t
+ *   TRIPOLAR_POP_WITH_LAND: wet_mask,dxe,dye,dxn,dyn,tarea
+ *   VECTOR_C_GRID: wet_mask_t,wet_mask_q,dxT,dyT,dxCu,dyCu,dxCv,dyCv,dxBu,dyBu,area_u,area_v,
+ *                  kappa_iso,kappa_aniso
+ *   VECTOR_B_GRID: DXU,DYU,HUS,HUW,HTE,HTN,UAREA,TAREA
+ *
+ * Returns GCMF_OK or a status; validation failures return the GCMF_ERR_KAPPA_x / GCMF_ERR_WET_x /
+ * GCMF_ERR_Dxx_FOLD codes and create no plan.
+ */
+int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int nplanes, gcmf_plan **out);
+void gcmf_plan_destroy(gcmf_plan *plan);
+
+/* Static facts (no device needed). */
+int gcmf_grid_nplanes(int grid_type);        /* number of grid planes, -1 if unknown           */
+int gcmf_grid_ncomp(int grid_type);          /* 1 scalar, 2 vector                             */
+int gcmf_grid_is_dimensional(int grid_type); /* kernels.py `is_dimensional`                    */
+int gcmf_grid_is_tripolar(int grid_type);
+
+/* Local (slab) geometry of a plan: rows allocated incl. ghosts, index of the first owned row
+ * inside the allocation, number of owned rows.  State arrays passed to gcmf_cheb_step have
+ * `rows_alloc` rows per batch entry. */
+int gcmf_plan_rows(const gcmf_plan *plan, int64_t *rows_alloc, int64_t *first_owned, int64_t *rows_owned);
+
+/* ---- whole filter: the body of filter_func / filter_func_vec (filter.py:185-210, 250-289) ---- */
+/*
+ * out = finalize( sum_k p[k] T_k ),  T_0 = prepare(in), T_1 = A(T_0), T_k = 2 A(T_{k-1}) - T_{k-2},
+ * A(x) = -x - c L(x).   `p` has n_steps+1 entries (host memory), n_steps >= 1.
+ * `c` = 2/s_max (dimensional Laplacians) or 2/(s_max*dx_min^2)   (filter.py:170-173).
+ * `in` / `out`: ncomp pointers (1 scalar, 2 vector) to (nbatch, ny, nx) arrays; `in` has the plan
+ * dtype and is not modified; `out` is f64 unless the plan is f32 and GCMF_OUT_F32 is given.
+ * Only valid on single-slab plans (row_begin = 0, row_end = ny).
+ * `stream`: hipStream_t to run on.  With GCMF_DEVICE_PTRS the work is enqueued asynchronously on exactly
+ * that stream (NULL = the HIP default stream), ordered with the caller's other work on it.  With host
+ * pointers the call stages through HBM and is synchronous (NULL = a private stream of the plan).
+ */
+int gcmf_apply(gcmf_plan *plan, const double *p, int n_steps, double c, const void *const *in,
+               void *const *out, int64_t nbatch, uint32_t flags, void *stream);
+
+/* One application of the Laplacian: `ALL_KERNELS[grid_type](**grid_vars)(field)` (kernels.py
+ * __call__ methods; no prepare/finalize).  `out` has the plan dtype. */
+int gcmf_laplacian(gcmf_plan *plan, const void *const *in, void *const *out, int64_t nbatch,
+                   uint32_t flags, void *stream);
+
+/* ---- building blocks for the multi-GPU (row-slab) driver; device pointers only --------------- */
+/*
+ * One Chebyshev step on rows [row_lo, row_hi) of the slab allocation (see gcmf_plan_rows):
+ *   t1:      T_{k-1}  (stencil input; rows row_lo-1 .. row_hi must be valid or wrap/fold)
+ *   t2:      T_{k-2}  (centre only; ignored with GCMF_STEP_FIRST)
+ *   fbar_in: running sum (centre only; ignored with GCMF_STEP_FIRST)
+ *   t0:      T_k out  (may alias t2; may be NULL with GCMF_STEP_LAST)
+ *   fbar_out: running sum out (may alias fbar_in); with GCMF_STEP_LAST it receives finalize(fbar)
+ * coef0 = p[k] (or p[0] with FIRST), coef1 = p[1] (FIRST only).
+ * fbar arrays are f64 for f64 plans; for f32 plans f64 unless GCMF_OUT_F32.
+ * Asynchronous on `stream` (NULL = the HIP default stream).
+ */
+int gcmf_cheb_step(gcmf_plan *plan, const void *const *t1, const void *const *t2,
+                   const void *const *fbar_in, void *const *t0, void *const *fbar_out, double coef0,
+                   double coef1, double c, uint32_t mode, uint32_t flags, int64_t nbatch,
+                   int64_t row_lo, int64_t row_hi, void *stream);
+
+/* T_0 = prepare(field) = field * area for the AREA_WEIGHTED grid types (kernels.py:100-101),
+ * a copy otherwise; rows [row_lo,row_hi) of the slab allocation. */
+int gcmf_prepare(gcmf_plan *plan, const void *const *in, void *const *out, int64_t nbatch,
+                 int64_t row_lo, int64_t row_hi, void *stream);
+
+/* ---- timing of the last gcmf_apply (hipEvents on the stream the kernels ran on) -------------- */
+/* ms_total: whole recurrence; n_launches: kernel launches it took. */
+int gcmf_last_timing(const gcmf_plan *plan, float *ms_total, int *n_launches);
+/* Enable/disable event timing inside gcmf_apply (adds two hipEventRecord per call). */
+int gcmf_set_timing(gcmf_plan *plan, int enabled);
+
+/* Tunables (0 keeps the default): rows marched per wave. */
+int gcmf_set_tuning(gcmf_plan *plan, int rows_per_wave, int reserved0, int reserved1);
+
+/* Last error text of the calling thread (never NULL). */
+const char *gcmf_last_error(void);
+int gcmf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCMF_H */
