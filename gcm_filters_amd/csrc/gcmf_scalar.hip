@@ -240,7 +240,7 @@ static int launch_k(gcmf_plan *pl, const StepArgs &a, hipStream_t s) {
   P.rows = g.rows;
   P.row_lo = a.row_lo;
   P.row_hi = a.row_hi;
-  P.rpw = pl->rows_per_wave > 0 ? pl->rows_per_wave : 8;
+  P.rpw = pl->rows_per_wave > 0 ? pl->rows_per_wave : 1;  // measured: 1 row per wave is fastest (L2 serves the 3x T1 row reuse)
   P.bstride = (long long)g.rows * g.nx;
   P.south_wrap = g.south_wrap;
   P.north_wrap = g.north_wrap;

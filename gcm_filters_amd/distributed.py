@@ -1,0 +1,274 @@
+"""Multi-GPU filter: row slabs along y, one process per MI355X, halo rows exchanged over RCCL / xGMI.
+
+The reference has no spatial decomposition (its only parallelism is dask over non-core dims,
+gcm_filters/filter.py:478-486); this module is the MI355X-native extension the north star asks for.
+
+Decomposition.  Rank r owns a contiguous block of rows of every (ny, nx) plane; x is never
+split, so x-periodicity and the tripole fold (row ny-1 reads [ny-1, nx-1-i]) stay rank-local.  Every
+Laplacian has stencil radius 1, so one Chebyshev step invalidates one ghost row per side.  Instead of a
+(latency-bound, 28.8 KB) exchange per step, ranks carry `halo` = s ghost rows and exchange every s steps
+(communication-avoiding / s-step halos): between exchanges each step recomputes a ghost zone that shrinks by
+one row, costing s(s-1)/2 extra rows of work per side per cycle (0.3 % at s=8 on a 2400-row slab).
+
+  * both recurrence states T_{k-1} and T_{k-2} need ghosts (ghost rows of T_k are recomputed from them);
+    the running sum fbar does not (centre-only);
+  * non-tripolar grids are periodic in y: ring neighbours (rank 0 <-> rank P-1 wrap);
+  * tripolar grids: rank 0 has no southern neighbour (row 0 is land), rank P-1 folds locally;
+  * grid coefficients need no exchange: every rank folds its slab (+ghost rows) from the global planes.
+
+Messages per exchange and direction: ncomp * nbatch * s rows * nx * sizeof(T) * 2 states, one contiguous
+buffer per peer (P2P send/recv; with 2 ranks both directions share one message so ordering is trivial).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .filter import FilterShape, _compute_filter_spec, _compute_n_steps_default
+from .kernels import ALL_KERNELS, GridType
+
+
+def slab_bounds(ny: int, world: int, rank: int):
+    """Balanced contiguous split of ny rows."""
+    base, rem = divmod(ny, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+class HipSlabEngine:
+    """Executes slab steps on the MI355X through libgcmf (gcmf_prepare / gcmf_cheb_step)."""
+
+    def __init__(self, grid_type: GridType, dtype_code: int, ny: int, nx: int, planes: Sequence[np.ndarray],
+                 row_begin: int, row_end: int, halo: int, device: int):
+        self.plan = _lib.Plan(grid_type.value, dtype_code, ny, nx, planes, device=device, row_begin=row_begin,
+                              row_end=row_end, halo=halo)
+        self.rows_alloc, self.first_owned, self.rows_owned = (self.plan.rows_alloc, self.plan.first_owned,
+                                                              self.plan.rows_owned)
+
+    @staticmethod
+    def _ptrs(tensors):
+        return None if tensors is None else [t.data_ptr() for t in tensors]
+
+    def _stream(self):
+        import torch
+        return torch.cuda.current_stream().cuda_stream
+
+    def prepare(self, ins, outs, nbatch, row_lo, row_hi):
+        self.plan.prepare(self._ptrs(ins), self._ptrs(outs), nbatch, row_lo, row_hi, stream=self._stream())
+
+    def step(self, t1, t2, fb_in, t0, fb_out, coef0, coef1, c, mode, nbatch, row_lo, row_hi):
+        self.plan.cheb_step(self._ptrs(t1), self._ptrs(t2), self._ptrs(fb_in), self._ptrs(t0), self._ptrs(fb_out),
+                            coef0, coef1, c, mode, nbatch, row_lo, row_hi, stream=self._stream())
+
+
+class SlabFilter:
+    """One rank's share of a filter over a (ny, nx) grid cut into `world` row slabs.
+
+    Parameters mirror ``Filter``: ``grid_type`` (name or GridType), ``grid_vars`` = GLOBAL (ny, nx) host arrays
+    (every rank folds its own slab from them), ``filter_kwargs`` = filter_scale, dx_min, filter_shape, ...
+    ``engine_factory`` is for tests only (CPU stand-in for the HIP engine on the gloo backend).
+    """
+
+    def __init__(self, grid_type, grid_vars: Dict[str, np.ndarray], filter_kwargs: dict, ny: int, nx: int, *,
+                 halo: Optional[int] = None, dtype=np.float64, group=None, device=None, engine_factory=None,
+                 rank: Optional[int] = None, world: Optional[int] = None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.grid_type = GridType[grid_type] if isinstance(grid_type, str) else grid_type
+        self.lap_cls = ALL_KERNELS[self.grid_type]
+        self.ncomp = self.lap_cls._NCOMP
+        self.ny, self.nx = int(ny), int(nx)
+        self.np_dtype = np.dtype(dtype)
+        self.dtype_code = _lib.dtype_code(self.np_dtype)
+        self.tripolar = bool(_lib.load().gcmf_grid_is_tripolar(self.grid_type.value))
+        self.area_weighted = self.grid_type.name.endswith("AREA_WEIGHTED")
+
+        fk = dict(filter_kwargs)
+        shape = fk.get("filter_shape", FilterShape.GAUSSIAN)
+        shape = FilterShape[shape] if isinstance(shape, str) else shape
+        tw, ndim = fk.get("transition_width", np.pi), fk.get("ndim", 2)
+        n = int(fk.get("n_steps", 0))
+        if n < 3:
+            n = int(_compute_n_steps_default(ndim, shape, fk["filter_scale"], fk["dx_min"], tw))
+        self.spec = _compute_filter_spec(fk["filter_scale"], fk["dx_min"], shape, tw, ndim, n)
+        self.n_steps = n
+        self.c = 2 / self.spec.s_max if self.lap_cls.is_dimensional else 2 / (self.spec.s_max * self.spec.dx_min_sq)
+
+        self.row_begin, self.row_end = slab_bounds(self.ny, self.world, self.rank)
+        min_rows = self.ny // self.world
+        if min_rows < 1:
+            raise ValueError(f"{self.ny} rows cannot be split over {self.world} ranks")
+        if self.world == 1:
+            self.halo = 0
+        else:
+            self.halo = int(halo) if halo else 8
+            self.halo = max(1, min(self.halo, min_rows))
+        planes = [np.ascontiguousarray(np.asarray(grid_vars[k]), dtype=self.np_dtype)
+                  for k in self.lap_cls.required_grid_args()]
+        if device is None:
+            device = torch.cuda.current_device() if torch.cuda.is_available() else -1
+        self.device = torch.device("cuda", device) if device >= 0 else torch.device("cpu")
+        factory = engine_factory or HipSlabEngine
+        self.engine = factory(self.grid_type, self.dtype_code, self.ny, self.nx, planes, self.row_begin, self.row_end,
+                              self.halo, device)
+        self.rows_alloc, self.first_owned, self.rows_owned = (self.engine.rows_alloc, self.engine.first_owned,
+                                                              self.engine.rows_owned)
+        # neighbours; None where the slab edge is a physical boundary (tripolar) or there is a single rank
+        P, r = self.world, self.rank
+        self.gs = self.first_owned                                   # southern ghost rows
+        self.gn = self.rows_alloc - self.first_owned - self.rows_owned  # northern ghost rows
+        self.south = ((r - 1) % P) if (P > 1 and self.gs > 0) else None
+        self.north = ((r + 1) % P) if (P > 1 and self.gn > 0) else None
+        self.tdtype = torch.float64 if self.np_dtype == np.float64 else torch.float32
+        self._bufs = {}
+        self.kernel_ms = 0.0
+        self.kernel_launches = 0
+        self.exchanges = 0
+        self.time_kernels = False  # bench.py: bracket every step launch with events on the launch stream
+
+    # -- data movement helpers -----------------------------------------------------------------
+    def scatter_from_global(self, fields: Sequence[np.ndarray]):
+        """Own rows of GLOBAL (..., ny, nx) host arrays -> list of device tensors (nbatch, rows_owned, nx)."""
+        out = []
+        for f in fields:
+            f = np.asarray(f)
+            loc = f[..., self.row_begin:self.row_end, :].reshape(-1, self.rows_owned, self.nx)
+            out.append(self.torch.from_numpy(np.ascontiguousarray(loc, dtype=self.np_dtype)).to(self.device))
+        return out
+
+    def gather_to_global(self, local: Sequence):
+        """All-gather filtered slabs back into GLOBAL (nbatch, ny, nx) host arrays (every rank gets them)."""
+        res = []
+        for t in local:
+            nb = t.shape[0]
+            full = np.empty((nb, self.ny, self.nx), dtype=np.float64 if t.dtype == self.torch.float64 else np.float32)
+            for src in range(self.world):
+                b, e = slab_bounds(self.ny, self.world, src)
+                buf = t.contiguous() if src == self.rank else self.torch.empty((nb, e - b, self.nx), dtype=t.dtype,
+                                                                              device=t.device)
+                if self.world > 1:
+                    self.dist.broadcast(buf, src=self._global_rank(src), group=self.group)
+                full[:, b:e, :] = buf.cpu().numpy()
+            res.append(full)
+        return res
+
+    def _global_rank(self, r):
+        return self.dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def _state(self, nbatch: int):
+        key = nbatch
+        if key not in self._bufs:
+            t = self.torch
+            shape = (self.ncomp, nbatch, self.rows_alloc, self.nx)
+            mk = lambda dt: t.zeros(shape, dtype=dt, device=self.device)
+            self._bufs[key] = dict(X=mk(self.tdtype), A=mk(self.tdtype), B=mk(self.tdtype), F=mk(t.float64),
+                                   O=mk(t.float64))
+        return self._bufs[key]
+
+    # -- halo exchange -------------------------------------------------------------------------
+    def _exchange(self, tensors: List):
+        """Refresh all `halo` ghost rows of every tensor in `tensors` (each (ncomp, nbatch, rows_alloc, nx))."""
+        if self.world == 1 or (self.south is None and self.north is None):
+            return
+        t, dist = self.torch, self.dist
+        s, fo, ro = self.halo, self.first_owned, self.rows_owned
+        top = [x[:, :, fo + ro - s: fo + ro, :] for x in tensors]      # -> northern neighbour's south ghosts
+        bot = [x[:, :, fo: fo + s, :] for x in tensors]                # -> southern neighbour's north ghosts
+        ghost_s = [x[:, :, 0: s, :] for x in tensors] if self.gs else []
+        ghost_n = [x[:, :, fo + ro: fo + ro + s, :] for x in tensors] if self.gn else []
+        sends: Dict[int, List] = {}
+        recvs: Dict[int, List] = {}
+        # fixed order inside a peer's message: [what I send north | what I send south]; the receiver unpacks
+        # [peer's northward rows -> my south ghosts | peer's southward rows -> my north ghosts]
+        if self.north is not None:
+            sends.setdefault(self.north, []).extend(top)
+        if self.south is not None:
+            sends.setdefault(self.south, []).extend(bot)
+        if self.south is not None:
+            recvs.setdefault(self.south, []).extend(ghost_s)
+        if self.north is not None:
+            recvs.setdefault(self.north, []).extend(ghost_n)
+        # RCCL moves device buffers directly over xGMI; under gloo (CPU tests, or several ranks sharing one GPU
+        # in the single-GPU parity test) the packed buffers are staged through host memory
+        stage = self.device.type == "cuda" and dist.get_backend(self.group) == "gloo"
+        ops, unpack = [], []
+        for peer, parts in sends.items():
+            buf = t.cat([p.reshape(-1) for p in parts])
+            if stage:
+                buf = buf.cpu()
+            ops.append(dist.P2POp(dist.isend, buf, self._global_rank(peer), group=self.group))
+        for peer, parts in recvs.items():
+            n = sum(p.numel() for p in parts)
+            buf = t.empty(n, dtype=parts[0].dtype, device="cpu" if stage else parts[0].device)
+            ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(peer), group=self.group))
+            unpack.append((buf, parts))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        for buf, parts in unpack:
+            off = 0
+            if stage:
+                buf = buf.to(self.device)
+            for p in parts:
+                p.copy_(buf[off: off + p.numel()].view(p.shape))
+                off += p.numel()
+        self.exchanges += 1
+
+    # -- the filter ----------------------------------------------------------------------------
+    def apply_local(self, local: Sequence):
+        """Filter this rank's rows.  `local`: ncomp tensors (nbatch, rows_owned, nx) on the device.  Returns
+        ncomp float64 tensors of the same shape (views into an internal buffer, valid until the next call)."""
+        t = self.torch
+        assert len(local) == self.ncomp
+        nbatch = int(local[0].shape[0])
+        st = self._state(nbatch)
+        X, A, B, F, O = st["X"], st["A"], st["B"], st["F"], st["O"]
+        fo, ro, s = self.first_owned, self.rows_owned, self.halo
+        for k in range(self.ncomp):
+            X[k, :, fo: fo + ro, :].copy_(local[k].to(self.tdtype))
+        comps = lambda buf: [buf[k] for k in range(self.ncomp)]
+        if self.area_weighted:  # T_0 = field * area on the owned rows; its ghosts arrive with the first exchange
+            self.engine.prepare(comps(X), comps(X), nbatch, fo, fo + ro)
+        p = np.asarray(self.spec.p, dtype=np.float64)
+        n = self.n_steps
+        valid = {id(X): 0, id(A): 0, id(B): 0}   # valid ghost rows per state buffer
+        t1, t2 = X, None
+        events = []
+        for k in range(1, n + 1):
+            if k == 1:
+                t0 = A
+            elif k == 2:
+                t0 = B
+            else:
+                t0 = t2  # T_k overwrites T_{k-2} (centre-only read)
+            if self.world > 1 and valid[id(t1)] == 0:
+                self._exchange([t1] if t2 is None else [t1, t2])
+                valid[id(t1)] = s
+                if t2 is not None:
+                    valid[id(t2)] = s
+            v_out = (valid[id(t1)] - 1) if self.world > 1 else 0
+            lo = fo - (v_out if self.gs else 0)
+            hi = fo + ro + (v_out if self.gn else 0)
+            mode = (_lib.STEP_FIRST if k == 1 else 0) | (_lib.STEP_LAST if k == n else 0)
+            if self.time_kernels:
+                e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+                e0.record()
+            self.engine.step(comps(t1), None if t2 is None else comps(t2), comps(F), comps(t0),
+                             comps(O) if k == n else comps(F), p[0] if k == 1 else p[k], p[1], self.c, mode,
+                             nbatch, lo, hi)
+            if self.time_kernels:
+                e1.record()
+                events.append((e0, e1))
+            valid[id(t0)] = v_out
+            t1, t2 = t0, t1
+        if events:
+            t.cuda.synchronize()
+            self.kernel_ms += sum(a.elapsed_time(b) for a, b in events)
+            self.kernel_launches += len(events)
+        return [O[k][:, fo: fo + ro, :] for k in range(self.ncomp)]

@@ -1,0 +1,60 @@
+"""TEST-ONLY stand-in for the HIP slab engine of gcm_filters_amd.distributed, so that the row-slab / halo
+choreography can run under the gloo backend on CPU.  It executes a slab step by embedding the slab rows at
+their global positions in a poisoned (ny, nx) array and applying the ORACLE's global Laplacian: rows whose
+stencil only touches valid rows come out right, anything that reads a stale/ghost row picks up the poison."""
+import numpy as np
+
+from oracle import gcmf_oracle as O
+
+POISON = 1e30
+STEP_FIRST, STEP_LAST = 1, 2
+
+
+class OracleSlabEngine:
+    def __init__(self, grid_type, dtype_code, ny, nx, planes, row_begin, row_end, halo, device):
+        self.name = grid_type.name
+        self.ny, self.nx = ny, nx
+        names = O.GRID_ARGS[self.name]
+        self.gv = dict(zip(names, planes))
+        self.lap = O.make_laplacian(self.name, self.gv)
+        tripolar = self.name.startswith("TRIPOLAR")
+        full = row_begin == 0 and row_end == ny
+        gs = 0 if (full or (tripolar and row_begin == 0)) else halo
+        gn = 0 if (full or (tripolar and row_end == ny)) else halo
+        self.rows_owned = row_end - row_begin
+        self.rows_alloc = gs + self.rows_owned + gn
+        self.first_owned = gs
+        self.gidx = (np.arange(self.rows_alloc) + row_begin - gs) % ny
+        self.area = self.gv["area"] if self.name in O.AREA_WEIGHTED else None
+
+    def _embed(self, x):  # (nbatch, rows_alloc, nx) -> (nbatch, ny, nx)
+        g = np.full((x.shape[0], self.ny, self.nx), POISON, dtype=x.dtype)
+        g[:, self.gidx, :] = x
+        return g
+
+    def prepare(self, ins, outs, nbatch, row_lo, row_hi):
+        for i, o in zip(ins, outs):
+            a = 1 if self.area is None else self.area[self.gidx[row_lo:row_hi]]
+            o.numpy()[:, row_lo:row_hi, :] = i.numpy()[:, row_lo:row_hi, :] * a
+
+    def step(self, t1, t2, fb_in, t0, fb_out, coef0, coef1, c, mode, nbatch, row_lo, row_hi):
+        x = [self._embed(t.numpy()) for t in t1]
+        with np.errstate(all="ignore"):
+            L = self.lap(*x)
+        L = L if isinstance(L, tuple) else (L,)
+        rows = slice(row_lo, row_hi)
+        for k in range(len(t1)):
+            l_loc = L[k][:, self.gidx, :][:, rows, :]
+            xc = t1[k].numpy()[:, rows, :]
+            a = -xc - c * l_loc
+            if mode & STEP_FIRST:
+                tk = a
+                fb = coef0 * xc + coef1 * a
+            else:
+                tk = 2 * a - t2[k].numpy()[:, rows, :]
+                fb = fb_in[k].numpy()[:, rows, :] + coef0 * tk
+            if mode & STEP_LAST and self.area is not None:
+                fb = fb / self.area[self.gidx[rows]]
+            if not (mode & STEP_LAST):
+                t0[k].numpy()[:, rows, :] = tk
+            fb_out[k].numpy()[:, rows, :] = fb

@@ -1,0 +1,108 @@
+"""Row-slab decomposition + s-step halo exchange on CPU: world_size 2 and 3 over gloo, the per-slab step
+executed by a test-only oracle engine (tests/slab_engines.py).  Checks that the halo choreography of
+gcm_filters_amd.distributed reproduces the single-domain oracle filter."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gcm_filters_amd import testing as T
+from gcm_filters_amd.distributed import SlabFilter, slab_bounds
+from oracle import gcmf_oracle as O
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+CASES = [
+    # grid, shape, halo, nbatch
+    ("REGULAR", (24, 16), 1, 1),
+    ("REGULAR", (24, 16), 4, 2),
+    ("REGULAR_WITH_LAND_AREA_WEIGHTED", (22, 16), 3, 1),
+    ("IRREGULAR_WITH_LAND", (25, 18), 2, 2),
+    ("TRIPOLAR_POP_WITH_LAND", (24, 16), 3, 1),
+    ("TRIPOLAR_REGULAR_WITH_LAND_AREA_WEIGHTED", (24, 16), 8, 1),
+    ("MOM5U", (24, 16), 2, 1),
+    ("VECTOR_C_GRID", (24, 16), 3, 1),
+    ("VECTOR_B_GRID", (23, 16), 2, 2),
+]
+
+
+def _problem(grid, shape, nbatch):
+    vec = grid in T.VECTOR_GRIDS
+    gv = T.vector_grid_vars(grid, shape) if vec else T.scalar_grid_vars(grid, shape)
+    ncomp = 2 if vec else 1
+    fields = [np.stack([T.random_field(shape, 7 + 10 * c + b) for b in range(nbatch)]) for c in range(ncomp)]
+    dimensional = O.DIMENSIONAL[grid]
+    dx = T.grid_dx_min(grid, gv) if dimensional else 1.0
+    fk = dict(filter_scale=5.0 * dx, dx_min=dx, filter_shape="GAUSSIAN")
+    return gv, fields, fk
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from slab_engines import OracleSlabEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    errs = {}
+    try:
+        for grid, shape, halo, nbatch in CASES:
+            gv, fields, fk = _problem(grid, shape, nbatch)
+            sf = SlabFilter(grid, gv, fk, shape[0], shape[1], halo=halo, engine_factory=OracleSlabEngine, device=-1)
+            local = sf.scatter_from_global(fields)
+            out = sf.apply_local(local)
+            got = sf.gather_to_global(out)
+            spec = O.make_spec(fk["filter_scale"], fk["dx_min"], "GAUSSIAN")
+            assert spec.n_steps == sf.n_steps
+            with np.errstate(all="ignore"):
+                if len(fields) == 2:
+                    want = O.filter_func_vec(spec, grid, fields[0], fields[1], gv)
+                else:
+                    want = (O.filter_func(spec, grid, fields[0], gv),)
+            e = max(float(np.abs(g - w).max() / np.abs(w).max()) for g, w in zip(got, want))
+            errs[f"{grid}-{shape}-h{halo}-b{nbatch}"] = (e, sf.exchanges, sf.n_steps, sf.halo)
+        if rank == 0:
+            q.put(errs)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_filter_matches_single_domain(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    for p in procs:
+        assert p.exitcode == 0, f"worker exit code {p.exitcode}"
+    errs = q.get()
+    assert len(errs) == len(CASES)
+    for name, (e, nex, n, halo) in errs.items():
+        assert e < 1e-12, (name, e)
+        assert nex == -(-n // halo), (name, nex, n, halo)  # one exchange per `halo` steps
+
+
+def test_slab_bounds_cover_grid():
+    for ny in (7, 24, 2400):
+        for world in (1, 2, 3, 8):
+            if ny < world:
+                continue
+            edges = [slab_bounds(ny, world, r) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == ny
+            assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+            sizes = [e - b for b, e in edges]
+            assert max(sizes) - min(sizes) <= 1
