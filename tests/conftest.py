@@ -10,6 +10,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 GOLDEN = os.path.join(REPO, "tests", "golden")
 sys.path.insert(0, GOLDEN)
+sys.path.insert(0, os.path.join(REPO, "tests"))
 
 
 def pytest_configure(config):

@@ -1,0 +1,225 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/gcmf.h declares, the host-side
+Filter logic (polynomial fit, defaults, error / warning contract) matches the reference, and the xarray
+adapter reproduces apply_ufunc semantics (against a test-only xarray model with an oracle-backed filter_func)."""
+import os
+import re
+import sys
+import warnings
+
+import numpy as np
+import pytest
+
+import make_golden as MG
+from gcm_filters_amd import Filter, FilterShape, GridType, _lib, required_grid_vars, testing as T
+from gcm_filters_amd import filter as F
+from gcm_filters_amd.kernels import ALL_KERNELS, AreaWeightedMixin, BaseScalarLaplacian, BaseVectorLaplacian
+from oracle import gcmf_oracle as O
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------------------------------------------
+# C ABI
+# ---------------------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(REPO, "include", "gcmf.h")).read()
+    declared = set(re.findall(r"^\s*(?:const\s+)?(?:int|void|char)\s*\*?\s*(gcmf_\w+)\s*\(", header, flags=re.M))
+    assert declared, "no declarations parsed"
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libgcmf.so does not export {name}"
+    assert declared == set(_lib.EXPORTS)
+    assert lib.gcmf_version() == 1
+
+
+def test_static_grid_facts_match_reference_table():
+    lib = _lib.load()
+    for name, val in O.GRID_TYPE_VALUES.items():
+        assert GridType[name].value == val
+        assert lib.gcmf_grid_nplanes(val) == len(O.GRID_ARGS[name])
+        assert lib.gcmf_grid_ncomp(val) == (2 if name in O.VECTOR else 1)
+        assert bool(lib.gcmf_grid_is_dimensional(val)) == O.DIMENSIONAL[name]
+        assert bool(lib.gcmf_grid_is_tripolar(val)) == name.startswith("TRIPOLAR")
+    assert lib.gcmf_grid_nplanes(99) == -1
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_no_cpu_fallback():
+    """Without an MI355X the product path fails loudly (status GCMF_ERR_NO_DEVICE), it never computes on the CPU."""
+    f, gv = T.scalar_case("REGULAR_WITH_LAND", (8, 8))
+    with pytest.raises(_lib.GcmfError) as ei:
+        ALL_KERNELS[GridType.REGULAR_WITH_LAND](**gv)
+    assert ei.value.status == _lib.ERR_NO_DEVICE
+    with pytest.raises(_lib.GcmfError):
+        Filter(filter_scale=4, dx_min=1).apply(np.zeros((8, 8)))
+
+
+def test_bad_arguments_are_rejected_before_touching_the_device():
+    import ctypes as C
+    lib = _lib.load()
+    out = C.c_void_p()
+    desc = _lib.PlanDesc(99, _lib.F64, 8, 8, 0, 8, 0, 0, 0, 0)
+    assert lib.gcmf_plan_create(C.byref(desc), None, 0, C.byref(out)) == _lib.ERR_INVALID_ARG
+    assert b"grid_type" in lib.gcmf_last_error()
+    desc = _lib.PlanDesc(GridType.REGULAR_WITH_LAND.value, _lib.F64, 8, 8, 0, 8, 0, 0, 0, 0)
+    assert lib.gcmf_plan_create(C.byref(desc), None, 0, C.byref(out)) == _lib.ERR_INVALID_ARG
+    desc = _lib.PlanDesc(GridType.REGULAR.value, 7, 8, 8, 0, 8, 0, 0, 0, 0)
+    assert lib.gcmf_plan_create(C.byref(desc), None, 0, C.byref(out)) == _lib.ERR_INVALID_ARG
+    desc = _lib.PlanDesc(GridType.REGULAR.value, _lib.F64, 8, 8, 4, 2, 0, 0, 0, 0)
+    assert lib.gcmf_plan_create(C.byref(desc), None, 0, C.byref(out)) == _lib.ERR_INVALID_ARG
+
+
+# ---------------------------------------------------------------------------------------------------
+# kernel registry (upstream tests/test_kernels.py:39-61, 285-299)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("grid", T.ALL_GRIDS)
+def test_registry(grid):
+    cls = ALL_KERNELS[GridType[grid]]
+    assert required_grid_vars(GridType[grid]) == list(O.GRID_ARGS[grid])
+    assert cls.required_grid_args() == list(O.GRID_ARGS[grid])
+    assert cls.is_dimensional == O.DIMENSIONAL[grid]
+    assert issubclass(cls, BaseVectorLaplacian) == (grid in O.VECTOR)
+    assert issubclass(cls, BaseScalarLaplacian) == (grid not in O.VECTOR)
+    assert issubclass(cls, AreaWeightedMixin) == (grid in O.AREA_WEIGHTED)
+
+
+# ---------------------------------------------------------------------------------------------------
+# filter polynomial (upstream tests/test_filter.py:13-92)
+# ---------------------------------------------------------------------------------------------------
+def test_filter_spec_known_answers():
+    f = Filter(filter_scale=10.0, dx_min=1.0, filter_shape=FilterShape.GAUSSIAN, transition_width=np.pi, ndim=2)
+    assert f.filter_spec.n_steps == 11 and f.filter_spec.s_max == 8.0
+    np.testing.assert_allclose(f.filter_spec.p,
+                               [0.09887381, -0.19152534, 0.1748326, -0.14975371, 0.12112337, -0.09198484, 0.0662522,
+                                -0.04479323, 0.02895827, -0.0173953, 0.00995974, -0.00454758], rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(f.filter_spec.dx_min_sq, 1.0)
+    f = Filter(filter_scale=2.0, dx_min=1.0, filter_shape=FilterShape.TAPER, transition_width=np.pi, ndim=1)
+    assert f.filter_spec.n_steps == 6 and f.filter_spec.s_max == 4.0
+    np.testing.assert_allclose(f.filter_spec.p, [0.83380304, -0.23622724, -0.06554041, 0.01593978, 0.00481014,
+                                                 -0.00495532, 0.00168445], rtol=1e-7, atol=1e-7)
+    assert F._compute_n_steps_default(2, FilterShape.GAUSSIAN, 1.5, 1, np.pi) >= 3
+
+
+@pytest.mark.parametrize("row", MG.SPEC_TABLE, ids=lambda r: f"{r[0]}-{r[1]}-{r[2]}-{r[4]}-{r[5]}")
+def test_filter_spec_matches_reference_table(row, golden_spec):
+    shape, scale, dx_min, tw, ndim, n = row
+    key = f"{shape}|{scale!r}|{dx_min!r}|{tw!r}|{ndim}|{n}"
+    nd, nn, s_max, dxsq = golden_spec[key + "|meta"]
+    flt = Filter(filter_scale=scale, dx_min=dx_min, filter_shape=FilterShape[shape], transition_width=tw, ndim=ndim,
+                 n_steps=n)
+    assert flt.n_steps == int(nn) and flt.filter_spec.n_steps == int(nn)
+    assert flt.filter_spec.s_max == s_max and flt.filter_spec.dx_min_sq == dxsq
+    np.testing.assert_allclose(flt.filter_spec.p, golden_spec[key + "|p"], rtol=0, atol=5e-14)
+    assert abs(sum((-1) ** k * c for k, c in enumerate(flt.filter_spec.p)) - 1) < 1e-13  # p(-1) = 1
+
+
+def test_own_pchip_equals_scipy():
+    from scipy.interpolate import PchipInterpolator
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        x = np.sort(rng.random(6)) * 10 + np.arange(6)
+        y = rng.normal(size=6)
+        q = np.linspace(x[0], x[-1], 301)
+        np.testing.assert_allclose(F._pchip(x, y)(q), PchipInterpolator(x, y)(q), rtol=1e-12, atol=1e-13)
+
+
+# ---------------------------------------------------------------------------------------------------
+# constructor contract (upstream tests/test_filter.py:140-169, 284-290)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("grid", T.ALL_GRIDS)
+def test_constructor_contract(grid):
+    vec = grid in T.VECTOR_GRIDS
+    gv = T.vector_grid_vars(grid, (8, 8)) if vec else T.scalar_grid_vars(grid, (8, 8))
+    gt = GridType[grid]
+    args = dict(filter_scale=3.0, dx_min=1.0, n_steps=0, filter_shape=FilterShape.GAUSSIAN)
+    flt = Filter(grid_type=gt, grid_vars=gv, **args)
+    assert flt.n_steps == int(O.n_steps_default(2, "GAUSSIAN", 3.0, 1.0))
+    for name in gv:
+        with pytest.raises(ValueError, match=r"Provided `grid_vars` .*"):
+            Filter(grid_type=gt, grid_vars={k: v for k, v in gv.items() if k != name}, **args)
+    with pytest.raises(ValueError, match=r"Transition width .*"):
+        Filter(grid_type=gt, grid_vars=gv, **dict(args, transition_width=1))
+    with pytest.raises(ValueError, match=r"When ndim > 2, you .*"):
+        Filter(grid_type=gt, grid_vars=gv, **dict(args, ndim=3))
+    with pytest.warns(UserWarning, match=r"You have set n_steps .*"):
+        Filter(grid_type=gt, grid_vars=gv, **dict(args, n_steps=3))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        Filter(grid_type=gt, grid_vars=gv, **dict(args, n_steps=16))  # above the default: silent
+    if grid in O.AREA_WEIGHTED:
+        with pytest.raises(ValueError, match=r"Provided Laplacian .*"):
+            Filter(grid_type=gt, grid_vars=gv, **dict(args, dx_min=3))
+    if vec:
+        with pytest.raises(ValueError, match=r"Provided Laplacian *"):
+            flt.apply(np.zeros((8, 8)))
+    else:
+        with pytest.raises(ValueError, match=r"Provided Laplacian *"):
+            flt.apply_to_vector(np.zeros((8, 8)), np.zeros((8, 8)))
+
+
+# ---------------------------------------------------------------------------------------------------
+# xarray front door (upstream tests/test_filter.py:172-252) against the test-only xarray model
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture
+def xr_model(monkeypatch):
+    import fake_xarray
+    monkeypatch.setitem(sys.modules, "xarray", fake_xarray)
+
+    def oracle_filter_func(spec, Laplacian):
+        o = O.FilterSpec(spec.n_steps, spec.s_max, np.asarray(spec.p), spec.dx_min_sq)
+        names = Laplacian.required_grid_args()
+        return lambda field, *args: O.filter_func(o, Laplacian.GRID_TYPE.name, field, dict(zip(names, args)))
+
+    def oracle_filter_func_vec(spec, Laplacian):
+        o = O.FilterSpec(spec.n_steps, spec.s_max, np.asarray(spec.p), spec.dx_min_sq)
+        names = Laplacian.required_grid_args()
+        return lambda u, v, *args: O.filter_func_vec(o, Laplacian.GRID_TYPE.name, u, v, dict(zip(names, args)))
+
+    monkeypatch.setattr(F, "_create_filter_func", oracle_filter_func)
+    monkeypatch.setattr(F, "_create_filter_func_vec", oracle_filter_func_vec)
+    return fake_xarray
+
+
+def test_application_to_dataset(xr_model):
+    xr = xr_model
+    rng = np.random.default_rng(0)
+    ds = xr.Dataset(data_vars=dict(spatial=(("y", "x"), rng.normal(size=(30, 40))),
+                                   temporal=(("time",), rng.normal(size=(10,))),
+                                   spatiotemporal=(("time", "y", "x"), rng.normal(size=(10, 30, 40))),
+                                   transposed=(("y", "time", "x"), rng.normal(size=(30, 10, 40)))))
+    flt = Filter(filter_scale=4, dx_min=1, filter_shape=FilterShape.GAUSSIAN, grid_type=GridType.REGULAR)
+    out = flt.apply(ds, ["y", "x"])
+    assert np.array_equal(out.temporal.data, ds.temporal.data)
+    assert not np.allclose(out.spatial.data, ds.spatial.data)
+    spec = O.make_spec(4, 1, "GAUSSIAN")
+    np.testing.assert_allclose(out.spatial.data, O.filter_func(spec, "REGULAR", ds.spatial.data, {}), rtol=1e-12)
+    assert out.spatiotemporal.dims == ("time", "y", "x")
+    np.testing.assert_allclose(out.spatiotemporal.data.mean(axis=(1, 2)), ds.spatiotemporal.data.mean(axis=(1, 2)),
+                               atol=1e-12)
+    # core dims are moved to the end, exactly like xarray.apply_ufunc does
+    assert out.transposed.dims == ("time", "y", "x")
+    np.testing.assert_allclose(out.transposed.data[3],
+                               O.filter_func(spec, "REGULAR", ds.transposed.data[:, 3, :], {}), rtol=1e-12)
+    assert np.array_equal(ds.spatial.data, xr.Dataset(ds._vars).spatial.data)  # input untouched
+    with pytest.warns(UserWarning, match=r".* nothing was filtered."):
+        flt.apply(ds, ["foo", "bar"])
+    with pytest.warns(UserWarning, match=r".* nothing was filtered."):
+        flt.apply(ds, ["yy", "x"])
+
+
+def test_dataarray_with_grid_vars_and_vector(xr_model):
+    xr = xr_model
+    f, gv = T.scalar_case("IRREGULAR_WITH_LAND", (20, 24))
+    gvx = {k: xr.DataArray(v, dims=["y", "x"]) for k, v in gv.items()}
+    flt = Filter(filter_scale=3.0, dx_min=1.0, grid_type=GridType.IRREGULAR_WITH_LAND, grid_vars=gvx)
+    out = flt.apply(xr.DataArray(f, dims=["y", "x"]), dims=["y", "x"])
+    np.testing.assert_allclose(out.data, O.filter_func(O.make_spec(3.0, 1.0), "IRREGULAR_WITH_LAND", f, gv), rtol=1e-12)
+    with pytest.raises(AssertionError):
+        flt.apply(xr.DataArray(f, dims=["y", "x"]), dims=["y"])
+    (u, v), gvv = T.vector_case("VECTOR_B_GRID", (20, 24))
+    fv = Filter(filter_scale=5.0, dx_min=1.0, n_steps=10, filter_shape=FilterShape.TAPER, grid_type=GridType.VECTOR_B_GRID,
+                grid_vars={k: xr.DataArray(a, dims=["y", "x"]) for k, a in gvv.items()})
+    uo, vo = fv.apply_to_vector(xr.DataArray(u, dims=["y", "x"]), xr.DataArray(v, dims=["y", "x"]), dims=["y", "x"])
+    wu, wv = O.filter_func_vec(O.make_spec(5.0, 1.0, "TAPER", n_steps=10), "VECTOR_B_GRID", u, v, gvv)
+    np.testing.assert_allclose(uo.data, wu, rtol=1e-12)
+    np.testing.assert_allclose(vo.data, wv, rtol=1e-12)
