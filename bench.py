@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-steps", type=int, default=12, help="Laplacian steps of the CPU sample")
     ap.add_argument("--rows-per-wave", type=int, default=0)
+    ap.add_argument("--xcd-remap", type=int, default=-1)
     args = ap.parse_args()
 
     import torch
@@ -141,8 +142,8 @@ def main():
         lap = ALL_KERNELS[GridType[grid]](*[wl["grid_vars"][k] for k in ALL_KERNELS[GridType[grid]].required_grid_args()])
         from gcm_filters_amd import _lib
         plan = lap._plan(_lib.F64 if itemsize == 8 else _lib.F32, (args.ny, args.nx), local_rank)
-        if args.rows_per_wave:
-            plan.set_tuning(args.rows_per_wave)
+        if args.rows_per_wave or args.xcd_remap >= 0:
+            plan.set_tuning(args.rows_per_wave, args.xcd_remap)
         plan.set_timing(True)
         d_in = [torch.from_numpy(f).to(dev) for f in wl["fields"]]
         run = (lambda: flt.apply_to_vector(d_in[0], d_in[1])) if len(d_in) == 2 else (lambda: flt.apply(d_in[0]))

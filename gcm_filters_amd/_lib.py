@@ -200,5 +200,5 @@ class Plan:
         check(load().gcmf_last_timing(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
-    def set_tuning(self, rows_per_wave: int = 0):
-        check(load().gcmf_set_tuning(self._h, int(rows_per_wave), 0, 0))
+    def set_tuning(self, rows_per_wave: int = 0, xcd_remap: int = -1):
+        check(load().gcmf_set_tuning(self._h, int(rows_per_wave), int(xcd_remap), 0))

@@ -240,9 +240,10 @@ int gcmf_last_timing(const gcmf_plan *pl, float *ms_total, int *n_launches) {
   if (n_launches) *n_launches = pl->last_launches;
   return GCMF_OK;
 }
-int gcmf_set_tuning(gcmf_plan *pl, int rows_per_wave, int, int) {
+int gcmf_set_tuning(gcmf_plan *pl, int rows_per_wave, int xcd_remap, int) {
   if (!pl) return GCMF_ERR_INVALID_ARG;
   if (rows_per_wave > 0) pl->rows_per_wave = rows_per_wave;
+  if (xcd_remap >= 0) pl->xcd_remap = xcd_remap;
   return GCMF_OK;
 }
 

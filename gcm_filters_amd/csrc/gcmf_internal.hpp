@@ -88,6 +88,7 @@ struct gcmf_plan {
   float last_ms = 0.f;
   int last_launches = 0;
   int rows_per_wave = 0;
+  int xcd_remap = 1;
   std::mutex mu;
 };
 

@@ -69,6 +69,7 @@ template <typename T, typename FB> struct ScalarP {
   const uint8_t *mbits;
   const T *area;
   int nx, rows, row_lo, row_hi, rpw;
+  int ntx, ntiles, per_xcd;  // tile grid: ntx x-chunks per row group, ntiles total, tiles per XCD (0 = no remap)
   long long bstride;
   int south_wrap, north_wrap, fold, area_weighted;
   unsigned mode;
@@ -78,15 +79,22 @@ template <typename T, typename FB> struct ScalarP {
 template <typename T, typename FB, int KIND, int VEC>
 __global__ __launch_bounds__(256) void k_scalar_step(const ScalarP<T, FB> P) {
   const int lane = threadIdx.x;
-  const int strip = blockIdx.y * blockDim.y + threadIdx.y;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), so give XCD k
+  // the k-th contiguous band of row groups; the j+-1 rows a workgroup re-reads were then fetched into the SAME
+  // XCD's L2 by its neighbours instead of being pulled from HBM/MALL again by another XCD.
+  int tile = blockIdx.x;
+  if (P.per_xcd > 0) tile = (tile & 7) * P.per_xcd + (tile >> 3);
+  if (tile >= P.ntiles) return;
+  const int ty = tile / P.ntx, tx = tile - ty * P.ntx;
+  const int strip = ty * blockDim.y + threadIdx.y;
   const int jb = P.row_lo + strip * P.rpw;
   if (jb >= P.row_hi) return;  // wave-uniform
   const int je = min(jb + P.rpw, P.row_hi);
   const int nx = P.nx;
-  const int i0r = (blockIdx.x * 64 + lane) * VEC;
+  const int i0r = (tx * 64 + lane) * VEC;
   const bool active = i0r < nx;
   const int i0 = active ? i0r : 0;
-  const long long boff = (long long)blockIdx.z * P.bstride;
+  const long long boff = (long long)blockIdx.y * P.bstride;
   const T *t1 = P.t1 + boff;
   const int iw = (i0 == 0) ? nx - 1 : i0 - 1;
   const int ie = (i0 + VEC >= nx) ? 0 : i0 + VEC;
@@ -240,7 +248,7 @@ static int launch_k(gcmf_plan *pl, const StepArgs &a, hipStream_t s) {
   P.rows = g.rows;
   P.row_lo = a.row_lo;
   P.row_hi = a.row_hi;
-  P.rpw = pl->rows_per_wave > 0 ? pl->rows_per_wave : 1;  // measured: 1 row per wave is fastest (L2 serves the 3x T1 row reuse)
+  P.rpw = pl->rows_per_wave > 0 ? pl->rows_per_wave : 2;  // measured on MI355X: 1-4 rows per wave within noise, 8+ slower
   P.bstride = (long long)g.rows * g.nx;
   P.south_wrap = g.south_wrap;
   P.north_wrap = g.north_wrap;
@@ -254,7 +262,11 @@ static int launch_k(gcmf_plan *pl, const StepArgs &a, hipStream_t s) {
   if (nrows <= 0 || a.nbatch <= 0) return GCMF_OK;
   const int nstrips = (nrows + P.rpw - 1) / P.rpw;
   dim3 block(64, 4, 1);
-  dim3 grid((g.nx + 64 * VEC - 1) / (64 * VEC), (nstrips + 3) / 4, (unsigned)a.nbatch);
+  P.ntx = (g.nx + 64 * VEC - 1) / (64 * VEC);
+  const int nty = (nstrips + 3) / 4;
+  P.ntiles = P.ntx * nty;
+  P.per_xcd = (pl->xcd_remap && nty >= 16) ? (P.ntiles + 7) / 8 : 0;
+  dim3 grid(P.per_xcd ? 8 * P.per_xcd : P.ntiles, (unsigned)a.nbatch, 1);
   hipLaunchKernelGGL((k_scalar_step<T, FB, KIND, VEC>), grid, block, 0, s, P);
   GCMF_HIP(hipGetLastError());
   return GCMF_OK;

@@ -170,8 +170,8 @@ int gcmf_last_timing(const gcmf_plan *plan, float *ms_total, int *n_launches);
 /* Enable/disable event timing inside gcmf_apply (adds two hipEventRecord per call). */
 int gcmf_set_timing(gcmf_plan *plan, int enabled);
 
-/* Tunables (0 keeps the default): rows marched per wave. */
-int gcmf_set_tuning(gcmf_plan *plan, int rows_per_wave, int reserved0, int reserved1);
+/* Tunables: rows marched per wave (0 keeps the default); XCD-aware tile order (1 on, 0 off, <0 keep). */
+int gcmf_set_tuning(gcmf_plan *plan, int rows_per_wave, int xcd_remap, int reserved1);
 
 /* Last error text of the calling thread (never NULL). */
 const char *gcmf_last_error(void);
