@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=12, help="Laplacian steps of the CPU sample")
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--xcd-remap", type=int, default=-1)
+    ap.add_argument("--multi", type=int, default=0, help="recurrence steps fused per HBM pass (0 = library default, 1 = off)")
+    ap.add_argument("--strip", type=int, default=0, help="rows per wave strip of the temporally blocked kernel (0 = auto)")
     args = ap.parse_args()
 
     import torch
@@ -142,8 +144,8 @@ def main():
         lap = ALL_KERNELS[GridType[grid]](*[wl["grid_vars"][k] for k in ALL_KERNELS[GridType[grid]].required_grid_args()])
         from gcm_filters_amd import _lib
         plan = lap._plan(_lib.F64 if itemsize == 8 else _lib.F32, (args.ny, args.nx), local_rank)
-        if args.rows_per_wave or args.xcd_remap >= 0:
-            plan.set_tuning(args.rows_per_wave, args.xcd_remap)
+        if args.rows_per_wave or args.xcd_remap >= 0 or args.multi or args.strip:
+            plan.set_tuning(args.rows_per_wave, args.xcd_remap, args.multi, args.strip)
         plan.set_timing(True)
         d_in = [torch.from_numpy(f).to(dev) for f in wl["fields"]]
         run = (lambda: flt.apply_to_vector(d_in[0], d_in[1])) if len(d_in) == 2 else (lambda: flt.apply(d_in[0]))
@@ -210,8 +212,11 @@ def main():
         b_alg = B_ALG[grid](w)
         cells_per_launch = (cells // world) if world > 1 else cells
         if launches and kernel_ms > 0:
+            # a launch of the temporally blocked kernel advances several steps: price every launch with the
+            # cell-steps it processed (sum over launches = cells * n_steps per filter application)
             avg_ms = kernel_ms / launches
-            achieved = b_alg * cells_per_launch / (avg_ms * 1e-3) / 1e9
+            steps_per_launch = n_steps * args.steps / launches
+            achieved = b_alg * cells_per_launch * steps_per_launch / (avg_ms * 1e-3) / 1e9
             traffic = None
             tf = os.path.join(REPO, "profiles", "hbm_traffic.json")
             if os.path.exists(tf):
@@ -222,7 +227,8 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "kernel": "k_scalar_step" if grid != "VECTOR_C_GRID" else "k_cgrid_step",
-                               "avg_launch_ms": avg_ms, "alg_bytes_per_launch": b_alg * cells_per_launch,
+                               "avg_launch_ms": avg_ms, "steps_per_launch": steps_per_launch,
+                               "alg_bytes_per_launch": b_alg * cells_per_launch * steps_per_launch,
                                "alg_bytes_per_cell_step": b_alg}
         else:
             out["roofline"] = None

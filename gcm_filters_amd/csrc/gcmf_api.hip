@@ -240,10 +240,14 @@ int gcmf_last_timing(const gcmf_plan *pl, float *ms_total, int *n_launches) {
   if (n_launches) *n_launches = pl->last_launches;
   return GCMF_OK;
 }
-int gcmf_set_tuning(gcmf_plan *pl, int rows_per_wave, int xcd_remap, int) {
+int gcmf_set_tuning(gcmf_plan *pl, int rows_per_wave, int xcd_remap, int multi_s) {
   if (!pl) return GCMF_ERR_INVALID_ARG;
   if (rows_per_wave > 0) pl->rows_per_wave = rows_per_wave;
   if (xcd_remap >= 0) pl->xcd_remap = xcd_remap;
+  if (multi_s > 0) {
+    pl->multi_s = multi_s & 0xFF;          // low byte: steps per pass
+    pl->strip_rows = (multi_s >> 8);       // rest: rows per strip (0 = auto)
+  }
   return GCMF_OK;
 }
 
@@ -322,9 +326,12 @@ static int run_whole(gcmf_plan *pl, const double *p, int n_steps, double c, cons
 
   // work layout per component: [A][B][fbar] (+ [prepared T0]) (+ host staging: [in][out])
   const size_t szT = align_up(ncell * ts, 256), szF = align_up(ncell * fbs, 256);
+  const bool use_multi = !lapl_only && pl->multi_s >= 2 && n_steps >= 2 && multi_supported(pl, 2);
   size_t per = 0;
   const size_t oA = per; per += szT;
   const size_t oB = per; per += szT;
+  const size_t oC = per; if (use_multi) per += szT;
+  const size_t oD = per; if (use_multi) per += szT;
   const size_t oF = per; per += szF;
   const size_t oP = per; if (prep) per += szT;
   const size_t oIn = per; if (!on_dev) per += szT;
@@ -333,11 +340,13 @@ static int run_whole(gcmf_plan *pl, const double *p, int n_steps, double c, cons
   if (rc) return rc;
   char *w = (char *)pl->work;
   const void *din[2];
-  void *dout[2], *A[2], *B[2], *F[2], *Pp[2];
+  void *dout[2], *A[2], *B[2], *Cb[2], *Db[2], *F[2], *Pp[2];
   for (int k = 0; k < nc; ++k) {
     char *base = w + per * k;
     A[k] = base + oA;
     B[k] = base + oB;
+    Cb[k] = base + oC;
+    Db[k] = base + oD;
     F[k] = base + oF;
     Pp[k] = base + oP;
     if (on_dev) {
@@ -363,6 +372,52 @@ static int run_whole(gcmf_plan *pl, const double *p, int n_steps, double c, cons
     ++launches;
   } else {
     const void *x0[2] = {din[0], din[1]};
+    if (use_multi) {
+      // Temporally blocked schedule (scalar kinds): each launch advances S steps and reads/writes every plane
+      // once.  prepare/finalize are fused into the first / last launch.  State buffers rotate through a pool
+      // of four because a launch may not overwrite the planes its neighbours' halos are still reading.
+      void *pool[4] = {A[0], B[0], Cb[0], Db[0]};
+      const void *u = x0[0], *v = nullptr;
+      int k = 1;
+      while (k <= n_steps) {
+        const int left = n_steps - k + 1;
+        int S = 1;
+        const int cand[5] = {8, 6, 4, 3, 2};
+        for (int q = 0; q < 5; ++q)
+          if (cand[q] <= left && cand[q] <= pl->multi_s && multi_supported(pl, cand[q])) { S = cand[q]; break; }
+        void *fr[2] = {nullptr, nullptr};
+        int nf = 0;
+        for (int q = 0; q < 4 && nf < 2; ++q)
+          if (pool[q] != u && pool[q] != v) fr[nf++] = pool[q];
+        const bool is_last = (k + S - 1 == n_steps);
+        if (S >= 2) {
+          MultiArgs m{};
+          m.u0 = u; m.v0 = v; m.uo = fr[0]; m.vo = fr[1];
+          m.fb_in = F[0]; m.fb_out = is_last ? dout[0] : F[0];
+          m.first = (k == 1); m.last = is_last; m.S = S; m.fb_is_f32 = fb32;
+          for (int t = 0; t < S; ++t) m.pk[t] = p[k + t];
+          m.p0 = p[0]; m.c = c; m.nbatch = nbatch; m.row_lo = 0; m.row_hi = rows;
+          if ((rc = launch_scalar_multi(pl, m, s))) return rc;
+          u = fr[0]; v = fr[1];
+        } else {
+          StepArgs a1{};
+          a1.mode = (k == 1 ? GCMF_STEP_FIRST : 0u) | (is_last ? GCMF_STEP_LAST : 0u);
+          a1.coef0 = (k == 1) ? p[0] : p[k]; a1.coef1 = p[1]; a1.c = c; a1.fb_is_f32 = fb32; a1.nbatch = nbatch;
+          a1.row_lo = 0; a1.row_hi = rows;
+          const void *src = u;
+          if (k == 1 && prep) {  // the single-step kernel wants T_0 = field*area materialised
+            if ((rc = launch_prepare(pl, din, Pp, nbatch, 0, rows, s))) return rc;
+            ++launches;
+            src = Pp[0];
+          }
+          a1.t1[0] = src; a1.t2[0] = v; a1.t0[0] = fr[0]; a1.fb_in[0] = F[0]; a1.fb_out[0] = is_last ? dout[0] : F[0];
+          if ((rc = step_dispatch(pl, a1, s))) return rc;
+          v = src; u = fr[0];
+        }
+        ++launches;
+        k += S;
+      }
+    } else {
     if (prep) {  // T_0 = field * area
       if ((rc = launch_prepare(pl, din, Pp, nbatch, 0, rows, s))) return rc;
       ++launches;
@@ -390,6 +445,7 @@ static int run_whole(gcmf_plan *pl, const double *p, int n_steps, double c, cons
       }
       if ((rc = step_dispatch(pl, a, s))) return rc;
       ++launches;
+    }
     }
   }
   if (pl->timing) GCMF_HIP(hipEventRecord(pl->ev1, s));

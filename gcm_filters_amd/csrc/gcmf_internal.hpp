@@ -66,6 +66,19 @@ struct StepArgs {
   int row_lo, row_hi;
 };
 
+// Arguments of one temporally blocked launch: S recurrence steps in one pass (scalar kinds, one component).
+struct MultiArgs {
+  const void *u0, *v0;      // T_{k-1}, T_{k-2}
+  void *uo, *vo;            // T_{k-1+S}, T_{k-2+S}  (must not alias u0 / v0)
+  const void *fb_in;
+  void *fb_out;
+  double pk[8];             // coefficients of the S steps (p[k] .. p[k+S-1]); with `first`: p[1] .. p[S]
+  double p0, c;
+  int S, first, last, fb_is_f32;
+  int64_t nbatch;
+  int row_lo, row_hi;
+};
+
 }  // namespace gcmf
 
 struct gcmf_plan {
@@ -89,6 +102,8 @@ struct gcmf_plan {
   int last_launches = 0;
   int rows_per_wave = 0;
   int xcd_remap = 1;
+  int multi_s = 4;     // steps fused per pass by the temporally blocked kernel (1 = off)
+  int strip_rows = 0;  // rows per wave strip of that kernel (0 = auto)
   std::mutex mu;
 };
 
@@ -97,6 +112,8 @@ size_t dtype_size(int dtype);
 // kernel launchers (defined in gcmf_scalar.hip / gcmf_vector.hip)
 int launch_scalar_step(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 int launch_vector_step(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
+int launch_scalar_multi(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
+bool multi_supported(const gcmf_plan *pl, int S);
 int launch_prepare(gcmf_plan *pl, const void *const *in, void *const *out, int64_t nbatch, int row_lo,
                    int row_hi, hipStream_t s);
 // plan-time precompute (gcmf_precompute.hip): fills pl->g from the raw global planes (device pointers)

@@ -1,0 +1,407 @@
+// Temporally blocked scalar Chebyshev kernels: S recurrence steps per pass over HBM.
+//
+// The single-step kernel (gcmf_scalar.hip) moves B_alg = 5w + coefficients bytes per cell per step and is
+// already at ~0.9 of the achievable HBM rate, so the only way to go faster is to touch HBM less often.
+// Here ONE launch advances the recurrence by S steps ("levels") while streaming every plane once:
+//
+//   * a wave owns a window of 64*VEC contiguous cells in x and MARCHES north through a strip of rows;
+//   * time skewing along y: in the iteration that loads row r of T_{k-1}, level t (1..S) produces row r-t of
+//     T_{k-1+t} from the 3-row register window of level t-1 -- all levels live in registers, nothing but the
+//     final two states and fbar is ever written back;
+//   * shrinking window along x: east/west neighbours come from the adjacent lane (wave shuffles); the
+//     outermost lanes go stale by one cell per level, so windows overlap by M >= S cells per side and only
+//     the interior 64*VEC - 2M cells are stored.  No LDS, no barriers, no inter-wave communication;
+//   * strips overlap by S rows per side in y for the same reason (periodic wrap, or ghost rows in the
+//     multi-GPU slab case -- this kernel IS the "exchange every S steps" ghost-zone scheme, at wave level).
+//
+// HBM traffic per cell per step drops from 8w (flux form) to ~(9w / S) * overlap, e.g. 64 B -> ~21 B at S=4.
+// Arithmetic per level is identical to the single-step kernel (same operation order, fbar accumulated step
+// by step in its storage precision), so results are BIT-IDENTICAL to S single steps.
+//
+// Reference semantics per level: gcm_filters/filter.py:162-175,192-206 + the Laplacians of kernels.py (see
+// gcmf_scalar.hip for the per-kind citations).
+#include "gcmf_internal.hpp"
+
+#include <cfloat>
+#include <type_traits>
+
+namespace gcmf {
+
+template <typename T> struct MLim;
+template <> struct MLim<float> { static __device__ __forceinline__ float big() { return FLT_MAX; } };
+template <> struct MLim<double> { static __device__ __forceinline__ double big() { return DBL_MAX; } };
+
+template <typename T> __device__ __forceinline__ T msan(T x) {  // numpy.nan_to_num
+  if (x != x) return T(0);
+  if (x > MLim<T>::big()) return MLim<T>::big();
+  if (x < -MLim<T>::big()) return -MLim<T>::big();
+  return x;
+}
+
+template <typename T, int VEC> struct alignas((sizeof(T) * VEC) > 16 ? 16 : (sizeof(T) * VEC)) MPack { T s[VEC]; };
+template <typename T, int VEC> __device__ __forceinline__ void mload(T (&d)[VEC], const T *p) {
+  const MPack<T, VEC> v = *reinterpret_cast<const MPack<T, VEC> *>(p);
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) d[k] = v.s[k];
+}
+template <typename T, int VEC> __device__ __forceinline__ void mstore(T *p, const T (&d)[VEC]) {
+  MPack<T, VEC> v;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) v.s[k] = d[k];
+  *reinterpret_cast<MPack<T, VEC> *>(p) = v;
+}
+
+constexpr int MAX_S = 8;
+
+template <typename T, typename FB> struct MultiP {
+  const T *u0;      // T_{k-1}
+  const T *v0;      // T_{k-2}            (unused when first)
+  T *uo;            // T_{k-1+S}          (unused when last)
+  T *vo;            // T_{k-2+S}          (unused when last)
+  const FB *fb_in;  // running sum in     (unused when first)
+  FB *fb_out;       // running sum out / finalised result when last
+  const T *cE, *cN, *ra;
+  const uint8_t *mbits;
+  const T *area;
+  int nx, rows, out_lo, out_hi;
+  int H, nwx, nstrips, nwaves;
+  int wrap, first, last, area_weighted;
+  long long bstride;
+  double pk[MAX_S];  // coefficient of level t (1-based) at pk[t-1]
+  double p0;         // first only
+  double c;
+};
+
+template <typename T, typename FB, int KIND, int S>
+__global__ __launch_bounds__(256, (S > 4 || (sizeof(T) == 8 && S > 3)) ? 1 : 2) void k_scalar_multi(const MultiP<T, FB> P) {
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int W = 64 * VEC;
+  constexpr int M = (S + VEC - 1) / VEC * VEC;  // x margin, multiple of VEC so that windows stay 16-byte aligned
+  constexpr int WI = W - 2 * M;
+  constexpr bool SAN = (KIND != K_REG);
+
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= P.nwaves) return;
+  const int wx = wid % P.nwx, st = wid / P.nwx;
+  const int nx = P.nx, rows = P.rows;
+  const int a = P.out_lo + st * P.H;
+  const int b = min(a + P.H, P.out_hi);
+  const long long boff = (long long)blockIdx.y * P.bstride;
+
+  // this lane's VEC columns (periodic in x) and whether it stores
+  const int pos = wx * WI - M + lane * VEC;  // unwrapped position of the lane's first cell
+  int col = pos % nx;
+  if (col < 0) col += nx;
+  const bool keep = (lane * VEC >= M) && (lane * VEC < W - M) && (pos < nx);
+  const T c = (T)P.c;
+  const bool first = P.first, last = P.last;
+
+  // ---- register-resident state ----
+  T G[S][3][VEC];      // level t (0..S-1): rows (old, mid, new) as the stencil sees them (nan_to_num'ed)
+  T R[S][2][VEC];      // raw (old, mid) of the same levels: the "-x" and "T_{k-2}" operands keep NaNs
+  T Vp[VEC];           // raw T_{k-2} of the row that is `mid` at level 0
+  T cEq[S + 1][VEC], cEwq[S + 1], cNq[S + 2][VEC], raq[S + 1][VEC];  // coefficient rows by lag (row r - lag)
+  unsigned Bq[S + 1];  // mask bits by lag
+  FB Fq[S + 1][VEC];   // fbar accumulators by lag
+#pragma unroll
+  for (int t = 0; t < S; ++t) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      G[t][0][k] = G[t][1][k] = G[t][2][k] = T(0);
+      R[t][0][k] = R[t][1][k] = T(0);
+    }
+  }
+#pragma unroll
+  for (int l = 0; l <= S; ++l) {
+    cEwq[l] = T(0);
+    Bq[l] = 0u;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { cEq[l][k] = T(0); raq[l][k] = T(0); Fq[l][k] = FB(0); }
+  }
+#pragma unroll
+  for (int l = 0; l <= S + 1; ++l) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) cNq[l][k] = T(0);
+  }
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) Vp[k] = T(0);
+
+  // one row of operands in flight
+  struct Row {
+    T u[VEC], v[VEC], ce[VEC], cn[VEC], ra[VEC], ar[VEC];
+    FB fb[VEC];
+    unsigned bits;
+  };
+  auto load_row = [&](Row &x, int r) {
+    int jr = r;
+    bool outside = false;
+    if (P.wrap) {
+      jr = r % rows;
+      if (jr < 0) jr += rows;
+    } else if (r < 0 || r >= rows) {
+      outside = true;
+      jr = r < 0 ? 0 : rows - 1;
+    }
+    const long long ro = (long long)jr * nx + col;
+    mload<T, VEC>(x.u, P.u0 + boff + ro);
+    if (!first) {
+      mload<T, VEC>(x.v, P.v0 + boff + ro);
+      mload<FB, VEC>(x.fb, P.fb_in + boff + ro);
+    }
+    if (KIND == K_FLUX) {
+      if (!outside) {
+        mload<T, VEC>(x.ce, P.cE + ro);
+        mload<T, VEC>(x.cn, P.cN + ro);
+        mload<T, VEC>(x.ra, P.ra + ro);
+      } else {  // beyond a closed boundary: no flux
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) x.ce[k] = x.cn[k] = x.ra[k] = T(0);
+      }
+    }
+    if (KIND == K_MASK) {
+      unsigned bb = 0;
+      const uint8_t *mp = P.mbits + ro;
+      if (VEC == 2) bb = *reinterpret_cast<const unsigned short *>(mp);
+      else bb = *reinterpret_cast<const unsigned *>(mp);
+      x.bits = outside ? 0u : bb;
+    }
+    if (first && P.area_weighted) mload<T, VEC>(x.ar, P.area + ro);
+  };
+
+  const int r_begin = a - S, r_end = b + S;  // rows loaded by this strip: [a-S, b+S)
+  Row nxt;
+  load_row(nxt, r_begin);
+
+  for (int r = r_begin; r < r_end; ++r) {
+    // ---- take delivery of row r, start fetching row r+1 ----
+    Row cur = nxt;
+    if (r + 1 < r_end) load_row(nxt, r + 1);
+
+    // insert row r at lag 0 / as level-0 `new`
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      T u = cur.u[k];
+      if (first && P.area_weighted) u = u * cur.ar[k];  // prepare(): field * area (kernels.py:100-101)
+      G[0][2][k] = SAN ? msan(u) : u;
+      // raw copy of `new` is parked in Vp's partner below after the levels ran (see rotation)
+      cur.u[k] = u;
+    }
+    if (KIND == K_FLUX) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) { cEq[0][k] = cur.ce[k]; cNq[0][k] = cur.cn[k]; raq[0][k] = cur.ra[k]; }
+      cEwq[0] = __shfl_up(cur.ce[VEC - 1], 1, 64);
+    }
+    if (KIND == K_MASK) Bq[0] = cur.bits;
+    if (!first) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) Fq[0][k] = cur.fb[k];
+    }
+
+    // ---- levels 1..S: level t produces row r-t ----
+    T newraw[S + 1][VEC];  // raw value produced by level t this iteration (t=0: the loaded row)
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) newraw[0][k] = cur.u[k];
+#pragma unroll
+    for (int t = 1; t <= S; ++t) {
+      const T(&gS)[VEC] = G[t - 1][0];
+      const T(&gC)[VEC] = G[t - 1][1];
+      const T(&gN)[VEC] = G[t - 1][2];
+      const T wv = __shfl_up(gC[VEC - 1], 1, 64);
+      const T ev = __shfl_down(gC[0], 1, 64);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const T xC = gC[k];
+        const T xW = (k == 0) ? wv : gC[k > 0 ? k - 1 : 0];
+        const T xE = (k == VEC - 1) ? ev : gC[k < VEC - 1 ? k + 1 : k];
+        T L;
+        if (KIND == K_REG) {
+          L = T(-4) * xC + xE;
+          L = L + xW;
+          L = L + gN[k];
+          L = L + gS[k];
+        } else if (KIND == K_MASK) {
+          const unsigned bb = (Bq[t] >> (8 * k)) & 0xFFu;
+          const T mC = (bb & 1u) ? xC : T(0);
+          const T wf = (T)__popc((bb >> 1) & 0xFu);
+          L = -wf * mC + ((bb & 2u) ? xE : T(0));
+          L = L + ((bb & 4u) ? xW : T(0));
+          L = L + ((bb & 8u) ? gN[k] : T(0));
+          L = L + ((bb & 16u) ? gS[k] : T(0));
+          L = (bb & 1u) ? L : T(0);
+        } else {
+          const T cw = (k == 0) ? cEwq[t] : cEq[t][k > 0 ? k - 1 : 0];
+          const T fe = (xE - xC) * cEq[t][k];
+          const T fw = (xC - xW) * cw;
+          const T fn = (gN[k] - xC) * cNq[t][k];
+          const T fs = (xC - gS[k]) * cNq[t + 1][k];
+          L = (fe - fw + fn - fs) * raq[t][k];
+        }
+        const T x = R[t - 1][1][k];  // raw centre of level t-1
+        const T av = -x - c * L;
+        T tk;
+        if (t == 1 && first) {
+          tk = av;
+          if (std::is_same<FB, T>::value) Fq[1][k] = (FB)((T)P.p0 * x + (T)P.pk[0] * av);
+          else Fq[1][k] = (FB)(P.p0 * (double)x + P.pk[0] * (double)av);
+        } else {
+          const T x2 = (t == 1) ? Vp[k] : R[t >= 2 ? t - 2 : 0][0][k];
+          tk = T(2) * av - x2;
+          if (std::is_same<FB, T>::value) Fq[t][k] = Fq[t][k] + (FB)((T)P.pk[t - 1] * tk);
+          else Fq[t][k] = Fq[t][k] + (FB)(P.pk[t - 1] * (double)tk);
+        }
+        newraw[t][k] = tk;
+        if (t < S) G[t][2][k] = SAN ? msan(tk) : tk;
+      }
+    }
+
+    // ---- stores: T_{k-1+S} row r-S, T_{k-2+S} row r-S+1, fbar row r-S ----
+    {
+      const int ju = r - S;
+      if (keep && ju >= a && ju < b) {
+        int jj = ju;
+        if (P.wrap) { jj = ju % rows; if (jj < 0) jj += rows; }
+        const long long off = boff + (long long)jj * nx + col;
+        if (!last) {
+          mstore<T, VEC>(P.uo + off, newraw[S]);
+        } else if (P.area_weighted) {  // finalize(): / area (kernels.py:103-104)
+          T ar[VEC];
+          mload<T, VEC>(ar, P.area + (long long)jj * nx + col);
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) Fq[S][k] = Fq[S][k] / (FB)ar[k];
+        }
+        mstore<FB, VEC>(P.fb_out + off, Fq[S]);
+      }
+      const int jv = r - S + 1;
+      if (!last && keep && jv >= a && jv < b) {
+        int jj = jv;
+        if (P.wrap) { jj = jv % rows; if (jj < 0) jj += rows; }
+        mstore<T, VEC>(P.vo + boff + (long long)jj * nx + col, newraw[S - 1]);
+      }
+    }
+
+    // ---- rotate the windows ----
+#pragma unroll
+    for (int t = 0; t < S; ++t) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        G[t][0][k] = G[t][1][k];
+        G[t][1][k] = G[t][2][k];
+        R[t][0][k] = R[t][1][k];
+        R[t][1][k] = newraw[t][k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) Vp[k] = first ? T(0) : cur.v[k];
+#pragma unroll
+    for (int l = S; l >= 1; --l) {
+      cEwq[l] = cEwq[l - 1];
+      Bq[l] = Bq[l - 1];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        cEq[l][k] = cEq[l - 1][k];
+        raq[l][k] = raq[l - 1][k];
+        Fq[l][k] = Fq[l - 1][k];
+      }
+    }
+#pragma unroll
+    for (int l = S + 1; l >= 1; --l) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) cNq[l][k] = cNq[l - 1][k];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+template <typename T, typename FB, int KIND, int S>
+static int launch_multi_s(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int W = 64 * VEC;
+  constexpr int M = (S + VEC - 1) / VEC * VEC;
+  constexpr int WI = W - 2 * M;
+  const Geom &g = pl->g;
+  MultiP<T, FB> P;
+  P.u0 = (const T *)a.u0;
+  P.v0 = (const T *)a.v0;
+  P.uo = (T *)a.uo;
+  P.vo = (T *)a.vo;
+  P.fb_in = (const FB *)a.fb_in;
+  P.fb_out = (FB *)a.fb_out;
+  P.cE = (const T *)g.coef[0];
+  P.cN = (const T *)g.coef[1];
+  P.ra = (const T *)g.coef[2];
+  P.mbits = g.mbits;
+  P.area = (const T *)g.area;
+  P.nx = g.nx;
+  P.rows = g.rows;
+  P.out_lo = a.row_lo;
+  P.out_hi = a.row_hi;
+  const int nrows = a.row_hi - a.row_lo;
+  if (nrows <= 0 || a.nbatch <= 0) return GCMF_OK;
+  P.nwx = (g.nx + WI - 1) / WI;
+  // strip height: enough waves to fill 256 CUs x 4 SIMDs x (1|2) waves, but at least 4S rows so that the
+  // 2S rows of warm-up per strip stay a modest overhead
+  int H = pl->strip_rows;
+  if (H <= 0) {
+    const long long target = 2048;
+    long long want = (target + (long long)P.nwx * a.nbatch - 1) / ((long long)P.nwx * a.nbatch);  // strips wanted
+    if (want < 1) want = 1;
+    H = (int)((nrows + want - 1) / want);
+    if (H < 4 * S) H = 4 * S;
+  }
+  if (H > nrows) H = nrows;
+  P.H = H;
+  P.nstrips = (nrows + H - 1) / H;
+  P.nwaves = P.nwx * P.nstrips;
+  P.wrap = g.south_wrap && g.north_wrap;
+  P.first = a.first;
+  P.last = a.last;
+  P.area_weighted = g.area_weighted;
+  P.bstride = (long long)g.rows * g.nx;
+  for (int t = 0; t < MAX_S; ++t) P.pk[t] = t < S ? a.pk[t] : 0.0;
+  P.p0 = a.p0;
+  P.c = a.c;
+  dim3 block(256), grid((P.nwaves + 3) / 4, (unsigned)a.nbatch);
+  hipLaunchKernelGGL((k_scalar_multi<T, FB, KIND, S>), grid, block, 0, s, P);
+  GCMF_HIP(hipGetLastError());
+  return GCMF_OK;
+}
+
+template <typename T, typename FB, int KIND> static int launch_multi_k(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
+  switch (a.S) {
+    case 2: return launch_multi_s<T, FB, KIND, 2>(pl, a, s);
+    case 3: return launch_multi_s<T, FB, KIND, 3>(pl, a, s);
+    case 4: return launch_multi_s<T, FB, KIND, 4>(pl, a, s);
+    case 6: return launch_multi_s<T, FB, KIND, 6>(pl, a, s);
+    case 8: return launch_multi_s<T, FB, KIND, 8>(pl, a, s);
+  }
+  set_error("launch_scalar_multi: unsupported S=%d", a.S);
+  return GCMF_ERR_INVALID_ARG;
+}
+
+template <typename T, typename FB> static int launch_multi_t(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
+  switch (pl->kind) {
+    case K_REG: return launch_multi_k<T, FB, K_REG>(pl, a, s);
+    case K_MASK: return launch_multi_k<T, FB, K_MASK>(pl, a, s);
+    case K_FLUX: return launch_multi_k<T, FB, K_FLUX>(pl, a, s);
+  }
+  set_error("launch_scalar_multi: plan is not a scalar kind");
+  return GCMF_ERR_INVALID_ARG;
+}
+
+bool multi_supported(const gcmf_plan *pl, int S) {
+  if (pl->ncomp != 1) return false;
+  if (!(S == 2 || S == 3 || S == 4 || S == 6 || S == 8)) return false;
+  const int vec = pl->d.dtype == GCMF_F64 ? 2 : 4;
+  if (pl->g.nx % vec) return false;
+  if (pl->g.fold) return false;  // the tripole seam couples mirrored columns: handled by the single-step kernel
+  return true;
+}
+
+int launch_scalar_multi(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
+  if (pl->d.dtype == GCMF_F64) return launch_multi_t<double, double>(pl, a, s);
+  if (a.fb_is_f32) return launch_multi_t<float, float>(pl, a, s);
+  return launch_multi_t<float, double>(pl, a, s);
+}
+
+}  // namespace gcmf

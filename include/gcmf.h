@@ -170,8 +170,10 @@ int gcmf_last_timing(const gcmf_plan *plan, float *ms_total, int *n_launches);
 /* Enable/disable event timing inside gcmf_apply (adds two hipEventRecord per call). */
 int gcmf_set_timing(gcmf_plan *plan, int enabled);
 
-/* Tunables: rows marched per wave (0 keeps the default); XCD-aware tile order (1 on, 0 off, <0 keep). */
-int gcmf_set_tuning(gcmf_plan *plan, int rows_per_wave, int xcd_remap, int reserved1);
+/* Tunables: rows marched per wave of the single-step kernel (0 keeps the default); XCD-aware tile order
+ * (1 on, 0 off, <0 keep); temporal blocking: low byte = recurrence steps fused per HBM pass (1 = off,
+ * 2,3,4,6,8), higher bits = rows per wave strip (0 = auto); 0 keeps the default. */
+int gcmf_set_tuning(gcmf_plan *plan, int rows_per_wave, int xcd_remap, int multi);
 
 /* Last error text of the calling thread (never NULL). */
 const char *gcmf_last_error(void);
