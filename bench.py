@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--xcd-remap", type=int, default=-1)
     ap.add_argument("--multi", type=int, default=0, help="recurrence steps fused per HBM pass (0 = library default, 1 = off)")
     ap.add_argument("--strip", type=int, default=0, help="rows per wave strip of the temporally blocked kernel (0 = auto)")
+    ap.add_argument("--prefetch", type=int, default=0, help="operand rows in flight per wave (0 = default)")
     args = ap.parse_args()
 
     import torch
@@ -144,8 +145,8 @@ def main():
         lap = ALL_KERNELS[GridType[grid]](*[wl["grid_vars"][k] for k in ALL_KERNELS[GridType[grid]].required_grid_args()])
         from gcm_filters_amd import _lib
         plan = lap._plan(_lib.F64 if itemsize == 8 else _lib.F32, (args.ny, args.nx), local_rank)
-        if args.rows_per_wave or args.xcd_remap >= 0 or args.multi or args.strip:
-            plan.set_tuning(args.rows_per_wave, args.xcd_remap, args.multi, args.strip)
+        if args.rows_per_wave or args.xcd_remap >= 0 or args.multi or args.strip or args.prefetch:
+            plan.set_tuning(args.rows_per_wave, args.xcd_remap, args.multi or 4, args.strip, args.prefetch)
         plan.set_timing(True)
         d_in = [torch.from_numpy(f).to(dev) for f in wl["fields"]]
         run = (lambda: flt.apply_to_vector(d_in[0], d_in[1])) if len(d_in) == 2 else (lambda: flt.apply(d_in[0]))

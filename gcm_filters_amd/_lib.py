@@ -200,6 +200,8 @@ class Plan:
         check(load().gcmf_last_timing(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
-    def set_tuning(self, rows_per_wave: int = 0, xcd_remap: int = -1, multi_s: int = 0, strip_rows: int = 0):
+    def set_tuning(self, rows_per_wave: int = 0, xcd_remap: int = -1, multi_s: int = 0, strip_rows: int = 0,
+                   prefetch_rows: int = 0):
         check(load().gcmf_set_tuning(self._h, int(rows_per_wave), int(xcd_remap),
-                                     (int(multi_s) & 0xFF) | (int(strip_rows) << 8)))
+                                     (int(multi_s) & 0xFF) | ((int(strip_rows) & 0xFFFF) << 8)
+                                     | ((int(prefetch_rows) & 0xF) << 24)))

@@ -245,8 +245,9 @@ int gcmf_set_tuning(gcmf_plan *pl, int rows_per_wave, int xcd_remap, int multi_s
   if (rows_per_wave > 0) pl->rows_per_wave = rows_per_wave;
   if (xcd_remap >= 0) pl->xcd_remap = xcd_remap;
   if (multi_s > 0) {
-    pl->multi_s = multi_s & 0xFF;          // low byte: steps per pass
-    pl->strip_rows = (multi_s >> 8);       // rest: rows per strip (0 = auto)
+    pl->multi_s = multi_s & 0xFF;               // low byte: steps per pass
+    pl->strip_rows = (multi_s >> 8) & 0xFFFF;   // bits 8..23: rows per strip (0 = auto)
+    pl->prefetch_rows = (multi_s >> 24) & 0xF;  // bits 24..27: operand rows in flight per wave (0 = default)
   }
   return GCMF_OK;
 }

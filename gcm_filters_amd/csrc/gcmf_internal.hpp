@@ -104,6 +104,7 @@ struct gcmf_plan {
   int xcd_remap = 1;
   int multi_s = 4;     // steps fused per pass by the temporally blocked kernel (1 = off)
   int strip_rows = 0;  // rows per wave strip of that kernel (0 = auto)
+  int prefetch_rows = 0;  // rows of operands in flight per wave (0 = default per S)
   std::mutex mu;
 };
 

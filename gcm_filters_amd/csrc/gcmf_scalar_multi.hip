@@ -51,6 +51,47 @@ template <typename T, int VEC> __device__ __forceinline__ void mstore(T *p, cons
   *reinterpret_cast<MPack<T, VEC> *>(p) = v;
 }
 
+// lane i <- lane i-1 / lane i+1 of the same wave by DPP (one VALU move per dword; no LDS crossbar round trip).
+// The outermost lanes keep their own value -- they are margin lanes whose results are never stored.
+__device__ __forceinline__ int dpp_up_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }    // wave_shr:1
+__device__ __forceinline__ int dpp_down_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }  // wave_shl:1
+__device__ __forceinline__ double from_lower_lane(double v) {
+  return __hiloint2double(dpp_up_i(__double2hiint(v)), dpp_up_i(__double2loint(v)));
+}
+__device__ __forceinline__ double from_upper_lane(double v) {
+  return __hiloint2double(dpp_down_i(__double2hiint(v)), dpp_down_i(__double2loint(v)));
+}
+__device__ __forceinline__ float from_lower_lane(float v) { return __int_as_float(dpp_up_i(__float_as_int(v))); }
+__device__ __forceinline__ float from_upper_lane(float v) { return __int_as_float(dpp_down_i(__float_as_int(v))); }
+
+// nan_to_num that also reports what it removed (bit0: was NaN, bit1: was +-inf), so the raw value can be
+// rebuilt later from the sanitised one without keeping a second copy in registers.  Written as selects
+// (v_cmp + v_cndmask), not branches: this runs for every value of every level.
+template <typename T> __device__ __forceinline__ T msan_flag(T x, unsigned &f) {
+  const bool isn = (x != x);
+  const bool big = (__builtin_fabs(x) > MLim<T>::big());  // false for NaN
+  f = (isn ? 1u : 0u) | (big ? 2u : 0u);
+  const T clamped = big ? __builtin_copysign(MLim<T>::big(), x) : x;
+  return isn ? T(0) : clamped;
+}
+template <> __device__ __forceinline__ float msan_flag<float>(float x, unsigned &f) {
+  const bool isn = (x != x);
+  const bool big = (__builtin_fabsf(x) > FLT_MAX);
+  f = (isn ? 1u : 0u) | (big ? 2u : 0u);
+  const float clamped = big ? __builtin_copysignf(FLT_MAX, x) : x;
+  return isn ? 0.f : clamped;
+}
+template <typename T> __device__ __forceinline__ T unsan(T g, unsigned f) {
+  const T inf = __builtin_copysign((T)__builtin_inf(), g);
+  const T r = (f & 2u) ? inf : g;
+  return (f & 1u) ? (T)__builtin_nan("") : r;
+}
+template <> __device__ __forceinline__ float unsan<float>(float g, unsigned f) {
+  const float inf = __builtin_copysignf(__builtin_inff(), g);
+  const float r = (f & 2u) ? inf : g;
+  return (f & 1u) ? __builtin_nanf("") : r;
+}
+
 constexpr int MAX_S = 8;
 
 template <typename T, typename FB> struct MultiP {
@@ -72,8 +113,8 @@ template <typename T, typename FB> struct MultiP {
   double c;
 };
 
-template <typename T, typename FB, int KIND, int S>
-__global__ __launch_bounds__(256, (S > 4 || (sizeof(T) == 8 && S > 3)) ? 1 : 2) void k_scalar_multi(const MultiP<T, FB> P) {
+template <typename T, typename FB, int KIND, int S, int D>
+__global__ __launch_bounds__(256, (S > 4) ? 1 : 2) void k_scalar_multi(const MultiP<T, FB> P) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int W = 64 * VEC;
   constexpr int M = (S + VEC - 1) / VEC * VEC;  // x margin, multiple of VEC so that windows stay 16-byte aligned
@@ -99,22 +140,20 @@ __global__ __launch_bounds__(256, (S > 4 || (sizeof(T) == 8 && S > 3)) ? 1 : 2) 
 
   // ---- register-resident state ----
   T G[S][3][VEC];      // level t (0..S-1): rows (old, mid, new) as the stencil sees them (nan_to_num'ed)
-  T R[S][2][VEC];      // raw (old, mid) of the same levels: the "-x" and "T_{k-2}" operands keep NaNs
+  unsigned Rf[S];      // 2 flag bits per (slot old/mid, cell) of the same levels: what nan_to_num removed, so
+                       // that the raw "-x" and "T_{k-2}" operands (which keep NaN/inf) can be rebuilt
   T Vp[VEC];           // raw T_{k-2} of the row that is `mid` at level 0
-  T cEq[S + 1][VEC], cEwq[S + 1], cNq[S + 2][VEC], raq[S + 1][VEC];  // coefficient rows by lag (row r - lag)
+  T cEq[S + 1][VEC], cNq[S + 2][VEC], raq[S + 1][VEC];  // coefficient rows by lag >= 1 (row r - lag)
   unsigned Bq[S + 1];  // mask bits by lag
   FB Fq[S + 1][VEC];   // fbar accumulators by lag
 #pragma unroll
   for (int t = 0; t < S; ++t) {
+    Rf[t] = 0u;
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-      G[t][0][k] = G[t][1][k] = G[t][2][k] = T(0);
-      R[t][0][k] = R[t][1][k] = T(0);
-    }
+    for (int k = 0; k < VEC; ++k) G[t][0][k] = G[t][1][k] = G[t][2][k] = T(0);
   }
 #pragma unroll
   for (int l = 0; l <= S; ++l) {
-    cEwq[l] = T(0);
     Bq[l] = 0u;
 #pragma unroll
     for (int k = 0; k < VEC; ++k) { cEq[l][k] = T(0); raq[l][k] = T(0); Fq[l][k] = FB(0); }
@@ -132,83 +171,95 @@ __global__ __launch_bounds__(256, (S > 4 || (sizeof(T) == 8 && S > 3)) ? 1 : 2) 
     T u[VEC], v[VEC], ce[VEC], cn[VEC], ra[VEC], ar[VEC];
     FB fb[VEC];
     unsigned bits;
+    bool closed;
   };
-  auto load_row = [&](Row &x, int r) {
+  // Row r of T_{k-1} travels with the centre-only operands of row r-1 (T_{k-2}, fbar, coefficients, mask bits):
+  // level 1 is the first consumer of those and it works on row r-1, so delivering them one row late saves a
+  // whole lag-0 register stage.
+  auto row_index = [&](int r, bool &outside) {
     int jr = r;
-    bool outside = false;
-    if (P.wrap) {
-      jr = r % rows;
-      if (jr < 0) jr += rows;
+    outside = false;
+    if (P.wrap) {  // |r| never leaves (-rows, 2 rows): one conditional add instead of an integer division
+      jr = r < 0 ? r + rows : (r >= rows ? r - rows : r);
     } else if (r < 0 || r >= rows) {
       outside = true;
       jr = r < 0 ? 0 : rows - 1;
     }
-    const long long ro = (long long)jr * nx + col;
+    return jr;
+  };
+  auto load_row = [&](Row &x, int r) {
+    bool out_u, out_c;
+    const long long ro = (long long)row_index(r, out_u) * nx + col;
+    const long long rc = (long long)row_index(r - 1, out_c) * nx + col;
     mload<T, VEC>(x.u, P.u0 + boff + ro);
     if (!first) {
-      mload<T, VEC>(x.v, P.v0 + boff + ro);
-      mload<FB, VEC>(x.fb, P.fb_in + boff + ro);
+      mload<T, VEC>(x.v, P.v0 + boff + rc);
+      mload<FB, VEC>(x.fb, P.fb_in + boff + rc);
     }
     if (KIND == K_FLUX) {
-      if (!outside) {
-        mload<T, VEC>(x.ce, P.cE + ro);
-        mload<T, VEC>(x.cn, P.cN + ro);
-        mload<T, VEC>(x.ra, P.ra + ro);
-      } else {  // beyond a closed boundary: no flux
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) x.ce[k] = x.cn[k] = x.ra[k] = T(0);
-      }
+      mload<T, VEC>(x.ce, P.cE + rc);
+      mload<T, VEC>(x.cn, P.cN + rc);
+      mload<T, VEC>(x.ra, P.ra + rc);
+      x.closed = out_c;  // beyond a closed boundary: no flux (coefficients zeroed on delivery)
     }
     if (KIND == K_MASK) {
       unsigned bb = 0;
-      const uint8_t *mp = P.mbits + ro;
+      const uint8_t *mp = P.mbits + rc;
       if (VEC == 2) bb = *reinterpret_cast<const unsigned short *>(mp);
       else bb = *reinterpret_cast<const unsigned *>(mp);
-      x.bits = outside ? 0u : bb;
+      x.bits = out_c ? 0u : bb;
     }
     if (first && P.area_weighted) mload<T, VEC>(x.ar, P.area + ro);
   };
 
-  const int r_begin = a - S, r_end = b + S;  // rows loaded by this strip: [a-S, b+S)
-  Row nxt;
-  load_row(nxt, r_begin);
+  // flag layout in Rf[t]: bits [2k, 2k+1] = cell k of slot `old`, bits [2*VEC + 2k, ..+1] = cell k of slot `mid`
+  constexpr unsigned OLD_MASK = (1u << (2 * VEC)) - 1u;
 
-  for (int r = r_begin; r < r_end; ++r) {
-    // ---- take delivery of row r, start fetching row r+1 ----
-    Row cur = nxt;
-    if (r + 1 < r_end) load_row(nxt, r + 1);
-
-    // insert row r at lag 0 / as level-0 `new`
+  // ---- one row-iteration, part 1: move the delivered row into the lag-0 / level-0 slots (frees its prefetch
+  //      registers so that the next load into them can be issued before the arithmetic starts) ----
+  unsigned newflags[S];  // flags of the value each level (0..S-1) produced for its `new` slot
+  T out_v[VEC], out_u[VEC];  // raw outputs of levels S-1 and S (the two states written back)
+  auto consume = [&](const Row &cur) {
+    newflags[0] = 0u;
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       T u = cur.u[k];
       if (first && P.area_weighted) u = u * cur.ar[k];  // prepare(): field * area (kernels.py:100-101)
-      G[0][2][k] = SAN ? msan(u) : u;
-      // raw copy of `new` is parked in Vp's partner below after the levels ran (see rotation)
-      cur.u[k] = u;
+      if (SAN) {
+        unsigned f;
+        G[0][2][k] = msan_flag(u, f);
+        newflags[0] |= f << (2 * k);
+      } else {
+        G[0][2][k] = u;
+      }
+      if (S == 1) out_v[k] = u;
     }
     if (KIND == K_FLUX) {
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) { cEq[0][k] = cur.ce[k]; cNq[0][k] = cur.cn[k]; raq[0][k] = cur.ra[k]; }
-      cEwq[0] = __shfl_up(cur.ce[VEC - 1], 1, 64);
+      for (int k = 0; k < VEC; ++k) {
+        cEq[1][k] = cur.closed ? T(0) : cur.ce[k];
+        cNq[1][k] = cur.closed ? T(0) : cur.cn[k];
+        raq[1][k] = cur.closed ? T(0) : cur.ra[k];
+      }
     }
-    if (KIND == K_MASK) Bq[0] = cur.bits;
-    if (!first) {
+    if (KIND == K_MASK) Bq[1] = cur.bits;
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) Fq[0][k] = cur.fb[k];
+    for (int k = 0; k < VEC; ++k) {
+      Fq[1][k] = first ? FB(0) : cur.fb[k];
+      Vp[k] = first ? T(0) : cur.v[k];
     }
+  };
 
-    // ---- levels 1..S: level t produces row r-t ----
-    T newraw[S + 1][VEC];  // raw value produced by level t this iteration (t=0: the loaded row)
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) newraw[0][k] = cur.u[k];
+  // ---- part 2: levels 1..S (level t produces row r-t), stores, window rotation ----
+  auto compute = [&](int r) {
 #pragma unroll
     for (int t = 1; t <= S; ++t) {
       const T(&gS)[VEC] = G[t - 1][0];
       const T(&gC)[VEC] = G[t - 1][1];
       const T(&gN)[VEC] = G[t - 1][2];
-      const T wv = __shfl_up(gC[VEC - 1], 1, 64);
-      const T ev = __shfl_down(gC[0], 1, 64);
+      const T wv = from_lower_lane(gC[VEC - 1]);
+      const T ev = from_upper_lane(gC[0]);
+      unsigned nf = 0u;
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         const T xC = gC[k];
@@ -230,14 +281,15 @@ __global__ __launch_bounds__(256, (S > 4 || (sizeof(T) == 8 && S > 3)) ? 1 : 2) 
           L = L + ((bb & 16u) ? gS[k] : T(0));
           L = (bb & 1u) ? L : T(0);
         } else {
-          const T cw = (k == 0) ? cEwq[t] : cEq[t][k > 0 ? k - 1 : 0];
+          const T cw = (k == 0) ? from_lower_lane(cEq[t][VEC - 1]) : cEq[t][k > 0 ? k - 1 : 0];
           const T fe = (xE - xC) * cEq[t][k];
           const T fw = (xC - xW) * cw;
           const T fn = (gN[k] - xC) * cNq[t][k];
           const T fs = (xC - gS[k]) * cNq[t + 1][k];
           L = (fe - fw + fn - fs) * raq[t][k];
         }
-        const T x = R[t - 1][1][k];  // raw centre of level t-1
+        // raw centre of level t-1 (NaN/inf survive in "-x", filter.py:171-173)
+        const T x = SAN ? unsan(xC, (Rf[t - 1] >> (2 * VEC + 2 * k)) & 3u) : xC;
         const T av = -x - c * L;
         T tk;
         if (t == 1 && first) {
@@ -245,57 +297,59 @@ __global__ __launch_bounds__(256, (S > 4 || (sizeof(T) == 8 && S > 3)) ? 1 : 2) 
           if (std::is_same<FB, T>::value) Fq[1][k] = (FB)((T)P.p0 * x + (T)P.pk[0] * av);
           else Fq[1][k] = (FB)(P.p0 * (double)x + P.pk[0] * (double)av);
         } else {
-          const T x2 = (t == 1) ? Vp[k] : R[t >= 2 ? t - 2 : 0][0][k];
+          T x2;
+          if (t == 1) x2 = Vp[k];
+          else x2 = SAN ? unsan(G[t >= 2 ? t - 2 : 0][0][k], (Rf[t >= 2 ? t - 2 : 0] >> (2 * k)) & 3u) : G[t >= 2 ? t - 2 : 0][0][k];
           tk = T(2) * av - x2;
           if (std::is_same<FB, T>::value) Fq[t][k] = Fq[t][k] + (FB)((T)P.pk[t - 1] * tk);
           else Fq[t][k] = Fq[t][k] + (FB)(P.pk[t - 1] * (double)tk);
         }
-        newraw[t][k] = tk;
-        if (t < S) G[t][2][k] = SAN ? msan(tk) : tk;
+        if (t == S - 1) out_v[k] = tk;
+        if (t == S) out_u[k] = tk;
+        if (t < S) {
+          if (SAN) {
+            unsigned f;
+            G[t][2][k] = msan_flag(tk, f);
+            nf |= f << (2 * k);
+          } else {
+            G[t][2][k] = tk;
+          }
+        }
       }
+      if (t < S) newflags[t] = nf;
     }
 
-    // ---- stores: T_{k-1+S} row r-S, T_{k-2+S} row r-S+1, fbar row r-S ----
+    // stores: T_{k-1+S} row r-S, T_{k-2+S} row r-S+1, fbar row r-S
     {
       const int ju = r - S;
       if (keep && ju >= a && ju < b) {
-        int jj = ju;
-        if (P.wrap) { jj = ju % rows; if (jj < 0) jj += rows; }
-        const long long off = boff + (long long)jj * nx + col;
+        const long long off = boff + (long long)ju * nx + col;
         if (!last) {
-          mstore<T, VEC>(P.uo + off, newraw[S]);
+          mstore<T, VEC>(P.uo + off, out_u);
         } else if (P.area_weighted) {  // finalize(): / area (kernels.py:103-104)
           T ar[VEC];
-          mload<T, VEC>(ar, P.area + (long long)jj * nx + col);
+          mload<T, VEC>(ar, P.area + (long long)ju * nx + col);
 #pragma unroll
           for (int k = 0; k < VEC; ++k) Fq[S][k] = Fq[S][k] / (FB)ar[k];
         }
         mstore<FB, VEC>(P.fb_out + off, Fq[S]);
       }
       const int jv = r - S + 1;
-      if (!last && keep && jv >= a && jv < b) {
-        int jj = jv;
-        if (P.wrap) { jj = jv % rows; if (jj < 0) jj += rows; }
-        mstore<T, VEC>(P.vo + boff + (long long)jj * nx + col, newraw[S - 1]);
-      }
+      if (!last && keep && jv >= a && jv < b) mstore<T, VEC>(P.vo + boff + (long long)jv * nx + col, out_v);
     }
 
-    // ---- rotate the windows ----
+    // rotate the windows: old <- mid <- new, lags shift by one row
 #pragma unroll
     for (int t = 0; t < S; ++t) {
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         G[t][0][k] = G[t][1][k];
         G[t][1][k] = G[t][2][k];
-        R[t][0][k] = R[t][1][k];
-        R[t][1][k] = newraw[t][k];
       }
+      Rf[t] = ((Rf[t] >> (2 * VEC)) & OLD_MASK) | (newflags[t] << (2 * VEC));
     }
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) Vp[k] = first ? T(0) : cur.v[k];
-#pragma unroll
-    for (int l = S; l >= 1; --l) {
-      cEwq[l] = cEwq[l - 1];
+    for (int l = S; l >= 2; --l) {
       Bq[l] = Bq[l - 1];
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
@@ -305,15 +359,34 @@ __global__ __launch_bounds__(256, (S > 4 || (sizeof(T) == 8 && S > 3)) ? 1 : 2) 
       }
     }
 #pragma unroll
-    for (int l = S + 1; l >= 1; --l) {
+    for (int l = S + 1; l >= 2; --l) {
 #pragma unroll
       for (int k = 0; k < VEC; ++k) cNq[l][k] = cNq[l - 1][k];
     }
+  };
+
+  // ---- march north with D rows of operands in flight (explicit slots so that they stay in registers) ----
+  const int r_begin = a - S, r_end = b + S;  // rows loaded by this strip: [a-S, b+S)
+  Row q0, q1, q2;
+  load_row(q0, r_begin);
+  if (D >= 2) load_row(q1, min(r_begin + 1, r_end - 1));
+  if (D >= 3) load_row(q2, min(r_begin + 2, r_end - 1));
+#define GCMF_SLOT(Q, dd)                                          \
+  if (r + (dd) < r_end) {                                         \
+    consume(Q); /* waits for this slot only */                    \
+    load_row(Q, min(r + (dd) + D, r_end - 1)); /* tail: harmless re-load of the last row */ \
+    compute(r + (dd));                                            \
   }
+  for (int r = r_begin; r < r_end; r += D) {
+    GCMF_SLOT(q0, 0)
+    if (D >= 2) { GCMF_SLOT(q1, 1) }
+    if (D >= 3) { GCMF_SLOT(q2, 2) }
+  }
+#undef GCMF_SLOT
 }
 
 // ------------------------------------------------------------------------------------------------------
-template <typename T, typename FB, int KIND, int S>
+template <typename T, typename FB, int KIND, int S, int D>
 static int launch_multi_s(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int W = 64 * VEC;
@@ -339,15 +412,16 @@ static int launch_multi_s(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   const int nrows = a.row_hi - a.row_lo;
   if (nrows <= 0 || a.nbatch <= 0) return GCMF_OK;
   P.nwx = (g.nx + WI - 1) / WI;
-  // strip height: enough waves to fill 256 CUs x 4 SIMDs x (1|2) waves, but at least 4S rows so that the
-  // 2S rows of warm-up per strip stay a modest overhead
+  // strip height: one resident wave per register-file slot (2 waves/SIMD up to S=4, 1 above) and no second
+  // round -- all strips march in lock-step, so a partial second round would idle most of the chip.  Measured
+  // on MI355X (2400x3600 f64, S=4): 67 strips x 30 windows = 2010 waves (H=36) is the sweet spot.
   int H = pl->strip_rows;
   if (H <= 0) {
-    const long long target = 2048;
-    long long want = (target + (long long)P.nwx * a.nbatch - 1) / ((long long)P.nwx * a.nbatch);  // strips wanted
+    const long long cap = (S > 4) ? 1024 : 2048;
+    long long want = cap / ((long long)P.nwx * a.nbatch);
     if (want < 1) want = 1;
     H = (int)((nrows + want - 1) / want);
-    if (H < 4 * S) H = 4 * S;
+    if (H < 2 * S) H = 2 * S;  // keep the 2S warm-up rows per strip below half of the work
   }
   if (H > nrows) H = nrows;
   P.H = H;
@@ -362,18 +436,18 @@ static int launch_multi_s(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   P.p0 = a.p0;
   P.c = a.c;
   dim3 block(256), grid((P.nwaves + 3) / 4, (unsigned)a.nbatch);
-  hipLaunchKernelGGL((k_scalar_multi<T, FB, KIND, S>), grid, block, 0, s, P);
+  hipLaunchKernelGGL((k_scalar_multi<T, FB, KIND, S, D>), grid, block, 0, s, P);
   GCMF_HIP(hipGetLastError());
   return GCMF_OK;
 }
 
 template <typename T, typename FB, int KIND> static int launch_multi_k(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   switch (a.S) {
-    case 2: return launch_multi_s<T, FB, KIND, 2>(pl, a, s);
-    case 3: return launch_multi_s<T, FB, KIND, 3>(pl, a, s);
-    case 4: return launch_multi_s<T, FB, KIND, 4>(pl, a, s);
-    case 6: return launch_multi_s<T, FB, KIND, 6>(pl, a, s);
-    case 8: return launch_multi_s<T, FB, KIND, 8>(pl, a, s);
+    case 2: return launch_multi_s<T, FB, KIND, 2, 2>(pl, a, s);
+    case 3: return launch_multi_s<T, FB, KIND, 3, 2>(pl, a, s);
+    case 4: return pl->prefetch_rows == 1 ? launch_multi_s<T, FB, KIND, 4, 1>(pl, a, s) : launch_multi_s<T, FB, KIND, 4, 2>(pl, a, s);
+    case 6: return launch_multi_s<T, FB, KIND, 6, 2>(pl, a, s);
+    case 8: return pl->prefetch_rows == 3 ? launch_multi_s<T, FB, KIND, 8, 3>(pl, a, s) : launch_multi_s<T, FB, KIND, 8, 2>(pl, a, s);
   }
   set_error("launch_scalar_multi: unsupported S=%d", a.S);
   return GCMF_ERR_INVALID_ARG;
@@ -395,6 +469,7 @@ bool multi_supported(const gcmf_plan *pl, int S) {
   const int vec = pl->d.dtype == GCMF_F64 ? 2 : 4;
   if (pl->g.nx % vec) return false;
   if (pl->g.fold) return false;  // the tripole seam couples mirrored columns: handled by the single-step kernel
+  if (pl->g.rows < S + 2) return false;  // the march wraps row indices with one conditional add (needs |r| < rows)
   return true;
 }
 
