@@ -58,6 +58,78 @@ static int ensure_work(gcmf_plan *pl, size_t bytes) {
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// One temporally blocked advance of S steps on rows [row_lo, row_hi) of a scalar plan.
+//
+// Tripolar grids: the fold couples column i of the top row with column nx-1-i, i.e. with a DIFFERENT wave of the
+// streaming kernel, so the top S rows ("band") are advanced by S single-step launches instead.  Band step t
+// recomputes a ghost zone [rows-2S+t, rows-S) below the band that shrinks by one row per step (the same
+// trick the multi-GPU slabs use) and only rows >= rows-S update fbar / the output states.
+int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launches) {
+  const Geom &g = pl->g;
+  const int rows = g.rows, S = m.S;
+  const bool band = g.fold && m.row_hi == rows;
+  int rc;
+  if (!band) {
+    if ((rc = launch_scalar_multi(pl, m, s))) return rc;
+    if (launches) ++*launches;
+    return GCMF_OK;
+  }
+  const int blo = rows - S;  // first band row
+  if (m.row_lo > rows - 2 * S - 1) {
+    set_error("advance_multi: row range too short for the tripole band");
+    return GCMF_ERR_INVALID_ARG;
+  }
+  MultiArgs mm = m;
+  mm.row_hi = blo;
+  if ((rc = launch_scalar_multi(pl, mm, s))) return rc;
+  if (launches) ++*launches;
+
+  const size_t ts = dtype_size(pl->d.dtype);
+  const size_t plane = align_up((size_t)m.nbatch * rows * g.nx * ts, 256);
+  if (pl->band_bytes < 3 * plane) {
+    if (pl->band) GCMF_HIP(hipFree(pl->band));
+    pl->band = nullptr;
+    pl->band_bytes = 0;
+    GCMF_HIP(hipMalloc(&pl->band, 3 * plane));
+    pl->band_bytes = 3 * plane;
+  }
+  void *E[2] = {pl->band, (char *)pl->band + plane};
+  void *Pb = (char *)pl->band + 2 * plane;
+  const void *lvl0 = m.u0;
+  if (m.first && g.area_weighted) {
+    const void *pin[1] = {m.u0};
+    void *pout[1] = {Pb};
+    if ((rc = launch_prepare(pl, pin, pout, m.nbatch, rows - 2 * S, rows, s))) return rc;
+    if (launches) ++*launches;
+    lvl0 = Pb;
+  }
+  auto level_buf = [&](int t) -> void * {  // where level t (1..S) of the band lives
+    if (t == S) return m.uo;
+    if (t == S - 1 && !m.last) return m.vo;
+    return E[t & 1];
+  };
+  for (int t = 1; t <= S; ++t) {
+    StepArgs a{};
+    a.mode = ((m.first && t == 1) ? GCMF_STEP_FIRST : 0u) | ((m.last && t == S) ? GCMF_STEP_LAST : 0u);
+    a.coef0 = (m.first && t == 1) ? m.p0 : m.pk[t - 1];
+    a.coef1 = m.pk[0];
+    a.c = m.c;
+    a.fb_is_f32 = m.fb_is_f32;
+    a.nbatch = m.nbatch;
+    a.t1[0] = (t == 1) ? lvl0 : level_buf(t - 1);
+    a.t2[0] = (t == 1) ? m.v0 : (t == 2 ? lvl0 : level_buf(t - 2));
+    a.t0[0] = level_buf(t);
+    a.fb_in[0] = (m.first && t == 1) ? nullptr : ((t == 1) ? m.fb_in : (m.last ? m.fb_in : m.fb_out));
+    a.fb_out[0] = (m.last && t < S) ? const_cast<void *>(m.fb_in) : m.fb_out;
+    a.row_lo = (t >= S - 1 && !(t == S - 1 && m.last)) ? blo : rows - 2 * S + t;
+    a.row_hi = rows;
+    a.fb_lo = blo;
+    if ((rc = launch_scalar_step(pl, a, s))) return rc;
+    if (launches) ++*launches;
+  }
+  return GCMF_OK;
+}
+
 }  // namespace gcmf
 
 using namespace gcmf;
@@ -90,6 +162,7 @@ void gcmf_plan_destroy(gcmf_plan *pl) {
   if (pl->stream) (void)hipStreamSynchronize(pl->stream);
   for (void *p : pl->owned) (void)hipFree(p);
   if (pl->work) (void)hipFree(pl->work);
+  if (pl->band) (void)hipFree(pl->band);
   if (pl->ev0) (void)hipEventDestroy(pl->ev0);
   if (pl->ev1) (void)hipEventDestroy(pl->ev1);
   if (pl->stream) (void)hipStreamDestroy(pl->stream);
@@ -398,7 +471,8 @@ static int run_whole(gcmf_plan *pl, const double *p, int n_steps, double c, cons
           m.first = (k == 1); m.last = is_last; m.S = S; m.fb_is_f32 = fb32;
           for (int t = 0; t < S; ++t) m.pk[t] = p[k + t];
           m.p0 = p[0]; m.c = c; m.nbatch = nbatch; m.row_lo = 0; m.row_hi = rows;
-          if ((rc = launch_scalar_multi(pl, m, s))) return rc;
+          if ((rc = advance_multi(pl, m, s, &launches))) return rc;
+          --launches;  // counted once more below
           u = fr[0]; v = fr[1];
         } else {
           StepArgs a1{};

@@ -64,6 +64,7 @@ struct StepArgs {
   int fb_is_f32;  // f32 plans only: fbar arrays are f32 (GCMF_OUT_F32)
   int64_t nbatch;
   int row_lo, row_hi;
+  int fb_lo;  // scalar kinds: rows < fb_lo leave fbar untouched
 };
 
 // Arguments of one temporally blocked launch: S recurrence steps in one pass (scalar kinds, one component).
@@ -95,6 +96,8 @@ struct gcmf_plan {
   // work buffers of gcmf_apply (grow-only)
   void *work = nullptr;
   size_t work_bytes = 0;
+  void *band = nullptr;  // scratch of the tripole-band single steps that accompany a temporally blocked launch
+  size_t band_bytes = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timing = false;
@@ -115,6 +118,8 @@ int launch_scalar_step(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 int launch_vector_step(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 int launch_scalar_multi(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 bool multi_supported(const gcmf_plan *pl, int S);
+// S fused steps on rows [row_lo,row_hi) incl. the tripole band when the range ends at the fold row (gcmf_api.hip)
+int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launches);
 int launch_prepare(gcmf_plan *pl, const void *const *in, void *const *out, int64_t nbatch, int row_lo,
                    int row_hi, hipStream_t s);
 // plan-time precompute (gcmf_precompute.hip): fills pl->g from the raw global planes (device pointers)

@@ -69,6 +69,7 @@ template <typename T, typename FB> struct ScalarP {
   const uint8_t *mbits;
   const T *area;
   int nx, rows, row_lo, row_hi, rpw;
+  int fb_lo;  // rows below this index do not touch fbar (ghost rows of the tripole band, see gcmf_api.hip)
   int ntx, ntiles, per_xcd;  // tile grid: ntx x-chunks per row group, ntiles total, tiles per XCD (0 = no remap)
   long long bstride;
   int south_wrap, north_wrap, fold, area_weighted;
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256) void k_scalar_step(const ScalarP<T, FB> P) {
     }
     if (active) {
       if (!(last && !lapl)) store_vec<T, VEC>(P.t0 + off, t0v);
-      if (!lapl) store_vec<FB, VEC>(P.fb_out + off, fbo);
+      if (!lapl && j >= P.fb_lo) store_vec<FB, VEC>(P.fb_out + off, fbo);
     }
     // ---- march north ----
 #pragma unroll
@@ -248,6 +249,7 @@ static int launch_k(gcmf_plan *pl, const StepArgs &a, hipStream_t s) {
   P.rows = g.rows;
   P.row_lo = a.row_lo;
   P.row_hi = a.row_hi;
+  P.fb_lo = a.fb_lo;
   P.rpw = pl->rows_per_wave > 0 ? pl->rows_per_wave : 2;  // measured on MI355X: 1-4 rows per wave within noise, 8+ slower
   P.bstride = (long long)g.rows * g.nx;
   P.south_wrap = g.south_wrap;

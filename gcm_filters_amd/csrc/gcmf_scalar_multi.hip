@@ -468,7 +468,8 @@ bool multi_supported(const gcmf_plan *pl, int S) {
   if (!(S == 2 || S == 3 || S == 4 || S == 6 || S == 8)) return false;
   const int vec = pl->d.dtype == GCMF_F64 ? 2 : 4;
   if (pl->g.nx % vec) return false;
-  if (pl->g.fold) return false;  // the tripole seam couples mirrored columns: handled by the single-step kernel
+  // the tripole seam couples mirrored columns: its top S rows are advanced by single steps (advance_multi)
+  if (pl->g.fold && pl->g.rows < 3 * S + 2) return false;
   if (pl->g.rows < S + 2) return false;  // the march wraps row indices with one conditional add (needs |r| < rows)
   return true;
 }
