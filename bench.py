@@ -122,6 +122,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
+    # test hook: GCMF_BENCH_SHARE_GPU=1 runs all ranks on cuda:0 over gloo (a gpurun box has one GPU; RCCL refuses
+    # two ranks on one device).  The driver's real multi-GPU runs use one GPU per rank over RCCL.
+    share_gpu = os.environ.get("GCMF_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -131,7 +136,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     ny_global = args.ny * world if (world > 1 and args.scaling == "weak") else args.ny
     wl = build_workload(args.config, ny_global if world > 1 else args.ny, args.nx, args.nlev)
@@ -166,7 +174,10 @@ def main():
     else:
         from gcm_filters_amd.distributed import SlabFilter
         sf = SlabFilter(grid, wl["grid_vars"], fk, ny_global, args.nx, halo=args.halo or None,
-                        dtype=np.float64 if itemsize == 8 else np.float32)
+                        dtype=np.float64 if itemsize == 8 else np.float32, device=local_rank)
+        if args.multi:
+            sf.multi_depth = args.multi
+        sf.time_kernels = True
         n_steps = sf.n_steps
         local = sf.scatter_from_global(wl["fields"])
         for _ in range(args.warmup):
@@ -179,7 +190,7 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         elapsed = time.perf_counter() - t0
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device="cpu" if share_gpu else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         kernel_ms, launches = sf.kernel_ms, sf.kernel_launches
@@ -218,16 +229,20 @@ def main():
             avg_ms = kernel_ms / launches
             steps_per_launch = n_steps * args.steps / launches
             achieved = b_alg * cells_per_launch * steps_per_launch / (avg_ms * 1e-3) / 1e9
-            traffic = None
+            # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/),
+            # valid for the default tuning at N=1 only
+            traffic, kname = None, ("k_cgrid_step" if grid == "VECTOR_C_GRID" else "k_scalar_multi")
             tf = os.path.join(REPO, "profiles", "hbm_traffic.json")
-            if os.path.exists(tf):
+            default_tuning = not (args.multi or args.strip or args.prefetch or args.rows_per_wave or args.xcd_remap >= 0)
+            if os.path.exists(tf) and world == 1 and default_tuning:
                 try:
-                    traffic = json.load(open(tf)).get(f"config{args.config}", {}).get("bytes_per_launch")
+                    rec = json.load(open(tf)).get(f"config{args.config}", {})
+                    traffic, kname = rec.get("bytes_per_launch"), rec.get("kernel_short", kname)
                 except Exception:
                     traffic = None
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "kernel": "k_scalar_step" if grid != "VECTOR_C_GRID" else "k_cgrid_step",
+                               "kernel": kname,
                                "avg_launch_ms": avg_ms, "steps_per_launch": steps_per_launch,
                                "alg_bytes_per_launch": b_alg * cells_per_launch * steps_per_launch,
                                "alg_bytes_per_cell_step": b_alg}

@@ -28,6 +28,7 @@ EXPORTS = [
     "gcmf_plan_create", "gcmf_plan_destroy", "gcmf_grid_nplanes", "gcmf_grid_ncomp", "gcmf_grid_is_dimensional",
     "gcmf_grid_is_tripolar", "gcmf_plan_rows", "gcmf_apply", "gcmf_laplacian", "gcmf_cheb_step", "gcmf_prepare",
     "gcmf_last_timing", "gcmf_set_timing", "gcmf_set_tuning", "gcmf_last_error", "gcmf_version",
+    "gcmf_multi_supported", "gcmf_cheb_multi",
 ]
 
 
@@ -77,6 +78,11 @@ def load() -> C.CDLL:
         lib.gcmf_cheb_step.argtypes = [vp, vpp, vpp, vpp, vpp, vpp, C.c_double, C.c_double, C.c_double, C.c_uint32,
                                        C.c_uint32, C.c_int64, C.c_int64, C.c_int64, vp]
         lib.gcmf_cheb_step.restype = C.c_int
+        lib.gcmf_multi_supported.argtypes = [vp, C.c_int]
+        lib.gcmf_multi_supported.restype = C.c_int
+        lib.gcmf_cheb_multi.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_double), C.c_int, C.c_double, C.c_double,
+                                        C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, C.c_int64, vp]
+        lib.gcmf_cheb_multi.restype = C.c_int
         lib.gcmf_prepare.argtypes = [vp, vpp, vpp, C.c_int64, C.c_int64, C.c_int64, vp]
         lib.gcmf_prepare.restype = C.c_int
         lib.gcmf_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
@@ -186,6 +192,18 @@ class Plan:
                                     _ptr_array(t0 or z), _ptr_array(fb_out), float(coef0), float(coef1), float(c),
                                     int(mode), OUT_F32 if out_f32 else 0, int(nbatch), int(row_lo), int(row_hi),
                                     C.c_void_p(stream or None)))
+
+    def multi_supported(self, S: int) -> bool:
+        return bool(load().gcmf_multi_supported(self._h, int(S)))
+
+    def cheb_multi(self, u, v, uo, vo, fb_in, fb_out, pk, p0, c, mode, nbatch, row_lo, row_hi, *,
+                   out_f32: bool = False, stream: int = 0):
+        pk = np.ascontiguousarray(pk, dtype=np.float64)
+        check(load().gcmf_cheb_multi(self._h, C.c_void_p(u), C.c_void_p(v or None), C.c_void_p(uo or None),
+                                     C.c_void_p(vo or None), C.c_void_p(fb_in or None), C.c_void_p(fb_out),
+                                     pk.ctypes.data_as(C.POINTER(C.c_double)), len(pk), float(p0), float(c), int(mode),
+                                     OUT_F32 if out_f32 else 0, int(nbatch), int(row_lo), int(row_hi),
+                                     C.c_void_p(stream or None)))
 
     def prepare(self, ins, outs, nbatch, row_lo, row_hi, *, stream: int = 0):
         check(load().gcmf_prepare(self._h, _ptr_array(ins), _ptr_array(outs), int(nbatch), int(row_lo), int(row_hi),

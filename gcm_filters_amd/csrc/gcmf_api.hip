@@ -358,6 +358,40 @@ int gcmf_cheb_step(gcmf_plan *pl, const void *const *t1, const void *const *t2, 
   return step_dispatch(pl, a, (hipStream_t)stream);
 }
 
+int gcmf_multi_supported(const gcmf_plan *pl, int S) { return (pl && multi_supported(pl, S)) ? 1 : 0; }
+
+int gcmf_cheb_multi(gcmf_plan *pl, const void *u, const void *v, void *uo, void *vo, const void *fbar_in,
+                    void *fbar_out, const double *pk, int S, double p0, double c, uint32_t mode, uint32_t flags,
+                    int64_t nbatch, int64_t row_lo, int64_t row_hi, void *stream) {
+  if (!pl || !u || !fbar_out || !pk) {
+    set_error("gcmf_cheb_multi: null argument");
+    return GCMF_ERR_INVALID_ARG;
+  }
+  if (!multi_supported(pl, S)) {
+    set_error("gcmf_cheb_multi: S=%d is not available for this plan", S);
+    return GCMF_ERR_UNSUPPORTED;
+  }
+  if (row_lo < 0 || row_hi > pl->rows_alloc || row_lo > row_hi) {
+    set_error("gcmf_cheb_multi: rows [%lld, %lld) outside the slab allocation of %lld rows", (long long)row_lo,
+              (long long)row_hi, (long long)pl->rows_alloc);
+    return GCMF_ERR_INVALID_ARG;
+  }
+  const bool first = mode & GCMF_STEP_FIRST, last = mode & GCMF_STEP_LAST;
+  if ((!first && (!v || !fbar_in)) || (!last && (!uo || !vo)) || uo == u || uo == v || vo == u || (vo && vo == v)) {
+    set_error("gcmf_cheb_multi: missing or aliased state buffers");
+    return GCMF_ERR_INVALID_ARG;
+  }
+  std::lock_guard<std::mutex> lk(pl->mu);
+  GCMF_HIP(hipSetDevice(pl->d.device));
+  MultiArgs m{};
+  m.u0 = u; m.v0 = v; m.uo = uo; m.vo = vo; m.fb_in = fbar_in; m.fb_out = fbar_out;
+  for (int t = 0; t < S; ++t) m.pk[t] = pk[t];
+  m.p0 = p0; m.c = c; m.S = S; m.first = first; m.last = last;
+  m.fb_is_f32 = (pl->d.dtype == GCMF_F32) && (flags & GCMF_OUT_F32);
+  m.nbatch = nbatch; m.row_lo = (int)row_lo; m.row_hi = (int)row_hi;
+  return advance_multi(pl, m, (hipStream_t)stream, nullptr);
+}
+
 int gcmf_prepare(gcmf_plan *pl, const void *const *in, void *const *out, int64_t nbatch, int64_t row_lo,
                  int64_t row_hi, void *stream) {
   if (!pl || !in || !out) return GCMF_ERR_INVALID_ARG;

@@ -62,6 +62,15 @@ class HipSlabEngine:
         self.plan.cheb_step(self._ptrs(t1), self._ptrs(t2), self._ptrs(fb_in), self._ptrs(t0), self._ptrs(fb_out),
                             coef0, coef1, c, mode, nbatch, row_lo, row_hi, stream=self._stream())
 
+    def multi_supported(self, S):
+        return self.plan.multi_supported(S)
+
+    def multi(self, u, v, uo, vo, fb_in, fb_out, pk, p0, c, mode, nbatch, row_lo, row_hi):
+        """S = len(pk) recurrence steps in one HBM pass (gcmf_cheb_multi); scalar grids only (one component)."""
+        dp = lambda t: 0 if t is None else t.data_ptr()
+        self.plan.cheb_multi(dp(u), dp(v), dp(uo), dp(vo), dp(fb_in), dp(fb_out), pk, p0, c, mode, nbatch, row_lo,
+                             row_hi, stream=self._stream())
+
 
 class SlabFilter:
     """One rank's share of a filter over a (ny, nx) grid cut into `world` row slabs.
@@ -132,6 +141,7 @@ class SlabFilter:
         self.kernel_launches = 0
         self.exchanges = 0
         self.time_kernels = False  # bench.py: bracket every step launch with events on the launch stream
+        self.multi_depth = 8       # most recurrence steps fused per HBM pass (1 = single steps only)
 
     # -- data movement helpers -----------------------------------------------------------------
     def scatter_from_global(self, fields: Sequence[np.ndarray]):
@@ -168,8 +178,8 @@ class SlabFilter:
             t = self.torch
             shape = (self.ncomp, nbatch, self.rows_alloc, self.nx)
             mk = lambda dt: t.zeros(shape, dtype=dt, device=self.device)
-            self._bufs[key] = dict(X=mk(self.tdtype), A=mk(self.tdtype), B=mk(self.tdtype), F=mk(t.float64),
-                                   O=mk(t.float64))
+            self._bufs[key] = dict(X=mk(self.tdtype), A=mk(self.tdtype), B=mk(self.tdtype), C=mk(self.tdtype),
+                                   D=mk(self.tdtype), F=mk(t.float64), O=mk(t.float64))
         return self._bufs[key]
 
     # -- halo exchange -------------------------------------------------------------------------
@@ -221,54 +231,75 @@ class SlabFilter:
         self.exchanges += 1
 
     # -- the filter ----------------------------------------------------------------------------
+    MULTI_DEPTHS = (8, 6, 4, 3, 2)
+
     def apply_local(self, local: Sequence):
         """Filter this rank's rows.  `local`: ncomp tensors (nbatch, rows_owned, nx) on the device.  Returns
-        ncomp float64 tensors of the same shape (views into an internal buffer, valid until the next call)."""
+        ncomp float64 tensors of the same shape (views into an internal buffer, valid until the next call).
+
+        Between two halo exchanges the recurrence advances `halo` steps; scalar grids do that with the
+        temporally blocked kernel (up to 8 steps per HBM pass, consuming one ghost row per step), vector grids
+        with single steps on a row range that shrinks by one per step."""
         t = self.torch
         assert len(local) == self.ncomp
         nbatch = int(local[0].shape[0])
         st = self._state(nbatch)
-        X, A, B, F, O = st["X"], st["A"], st["B"], st["F"], st["O"]
+        X, F, O = st["X"], st["F"], st["O"]
+        pool = [st["A"], st["B"], st["C"], st["D"]]
         fo, ro, s = self.first_owned, self.rows_owned, self.halo
         for k in range(self.ncomp):
             X[k, :, fo: fo + ro, :].copy_(local[k].to(self.tdtype))
         comps = lambda buf: [buf[k] for k in range(self.ncomp)]
-        if self.area_weighted:  # T_0 = field * area on the owned rows; its ghosts arrive with the first exchange
-            self.engine.prepare(comps(X), comps(X), nbatch, fo, fo + ro)
         p = np.asarray(self.spec.p, dtype=np.float64)
         n = self.n_steps
-        valid = {id(X): 0, id(A): 0, id(B): 0}   # valid ghost rows per state buffer
-        t1, t2 = X, None
+        can_multi = self.ncomp == 1 and hasattr(self.engine, "multi") and self.multi_depth >= 2
+        prepared = False
+        u, v = X, None          # T_{k-1}, T_{k-2}
+        valid = 0               # ghost rows of u (and at least valid-1 of v) that are up to date
         events = []
-        for k in range(1, n + 1):
-            if k == 1:
-                t0 = A
-            elif k == 2:
-                t0 = B
-            else:
-                t0 = t2  # T_k overwrites T_{k-2} (centre-only read)
-            if self.world > 1 and valid[id(t1)] == 0:
-                self._exchange([t1] if t2 is None else [t1, t2])
-                valid[id(t1)] = s
-                if t2 is not None:
-                    valid[id(t2)] = s
-            v_out = (valid[id(t1)] - 1) if self.world > 1 else 0
+        k = 1
+        while k <= n:
+            left = n - k + 1
+            if self.world > 1 and valid == 0:
+                self._exchange([u] if v is None else [u, v])
+                valid = s
+            budget = min(left, valid if self.world > 1 else left)
+            S = 1
+            if can_multi:
+                for cand in self.MULTI_DEPTHS:
+                    if cand <= budget and cand <= self.multi_depth and self.engine.multi_supported(cand):
+                        S = cand
+                        break
+            free = [b for b in pool if b is not u and b is not v]
+            v_out = (valid - S) if self.world > 1 else 0
             lo = fo - (v_out if self.gs else 0)
             hi = fo + ro + (v_out if self.gn else 0)
-            mode = (_lib.STEP_FIRST if k == 1 else 0) | (_lib.STEP_LAST if k == n else 0)
+            is_last = (k + S - 1 == n)
+            mode = (_lib.STEP_FIRST if k == 1 else 0) | (_lib.STEP_LAST if is_last else 0)
             if self.time_kernels:
                 e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
                 e0.record()
-            self.engine.step(comps(t1), None if t2 is None else comps(t2), comps(F), comps(t0),
-                             comps(O) if k == n else comps(F), p[0] if k == 1 else p[k], p[1], self.c, mode,
-                             nbatch, lo, hi)
+            if S >= 2:
+                self.engine.multi(u[0], None if v is None else v[0], free[0][0], free[1][0], F[0],
+                                  O[0] if is_last else F[0], p[k: k + S], p[0], self.c, mode, nbatch, lo, hi)
+                u, v = free[0], free[1]
+            else:
+                if k == 1 and self.area_weighted and not prepared:
+                    # T_0 = field * area on every valid row (the blocked kernel fuses this, single steps do not)
+                    self.engine.prepare(comps(X), comps(X), nbatch, fo - (valid if self.gs else 0),
+                                        fo + ro + (valid if self.gn else 0))
+                    prepared = True
+                self.engine.step(comps(u), None if v is None else comps(v), comps(F), comps(free[0]),
+                                 comps(O) if is_last else comps(F), p[0] if k == 1 else p[k], p[1], self.c, mode,
+                                 nbatch, lo, hi)
+                u, v = free[0], u
             if self.time_kernels:
                 e1.record()
-                events.append((e0, e1))
-            valid[id(t0)] = v_out
-            t1, t2 = t0, t1
+                events.append((e0, e1, S))
+            valid = v_out
+            k += S
         if events:
             t.cuda.synchronize()
-            self.kernel_ms += sum(a.elapsed_time(b) for a, b in events)
+            self.kernel_ms += sum(a.elapsed_time(b) for a, b, _ in events)
             self.kernel_launches += len(events)
         return [O[k][:, fo: fo + ro, :] for k in range(self.ncomp)]

@@ -159,6 +159,21 @@ int gcmf_cheb_step(gcmf_plan *plan, const void *const *t1, const void *const *t2
                    double coef1, double c, uint32_t mode, uint32_t flags, int64_t nbatch,
                    int64_t row_lo, int64_t row_hi, void *stream);
 
+/*
+ * S recurrence steps in ONE pass over HBM (temporal blocking, scalar grid types; S in {2,3,4,6,8}):
+ *   u = T_{k-1}, v = T_{k-2} (ignored with GCMF_STEP_FIRST)  ->  uo = T_{k-1+S}, vo = T_{k-2+S}
+ *   fbar_out = fbar_in + sum_t pk[t] T_{k+t}  (t = 0..S-1; with FIRST: p0*T_0 + pk[0]*T_1 + ...)
+ * on rows [row_lo, row_hi) of the slab allocation; the inputs must be valid on [row_lo-S, row_hi+S) (clipped
+ * at a wrapped / closed / folded physical boundary, which the kernel handles).  uo / vo must not alias u / v;
+ * fbar_out may alias fbar_in.  prepare() is fused with FIRST, finalize() with LAST (uo/vo then unused).
+ * Results are bit-identical to S calls of gcmf_cheb_step.  gcmf_multi_supported tells whether a plan/S
+ * combination is available (vector grids, odd nx, very short grids are not).
+ */
+int gcmf_multi_supported(const gcmf_plan *plan, int S);
+int gcmf_cheb_multi(gcmf_plan *plan, const void *u, const void *v, void *uo, void *vo, const void *fbar_in,
+                    void *fbar_out, const double *pk, int S, double p0, double c, uint32_t mode, uint32_t flags,
+                    int64_t nbatch, int64_t row_lo, int64_t row_hi, void *stream);
+
 /* T_0 = prepare(field) = field * area for the AREA_WEIGHTED grid types (kernels.py:100-101),
  * a copy otherwise; rows [row_lo,row_hi) of the slab allocation. */
 int gcmf_prepare(gcmf_plan *plan, const void *const *in, void *const *out, int64_t nbatch,
