@@ -105,7 +105,7 @@ struct gcmf_plan {
   int last_launches = 0;
   int rows_per_wave = 0;
   int xcd_remap = 1;
-  int multi_s = 4;     // steps fused per pass by the temporally blocked kernel (1 = off)
+  int multi_s = 8;     // steps fused per pass by the temporally blocked kernel (1 = off); 8 measured best
   int strip_rows = 0;  // rows per wave strip of that kernel (0 = auto)
   int prefetch_rows = 0;  // rows of operands in flight per wave (0 = default per S)
   std::mutex mu;

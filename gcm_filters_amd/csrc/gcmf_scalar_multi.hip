@@ -92,6 +92,9 @@ template <> __device__ __forceinline__ float unsan<float>(float g, unsigned f) {
   return (f & 1u) ? __builtin_nanf("") : r;
 }
 
+__device__ __forceinline__ double mabs(double x) { return __builtin_fabs(x); }
+__device__ __forceinline__ float mabs(float x) { return __builtin_fabsf(x); }
+
 constexpr int MAX_S = 8;
 
 template <typename T, typename FB> struct MultiP {
@@ -221,18 +224,26 @@ __global__ __launch_bounds__(256, (S > 4) ? 1 : 2) void k_scalar_multi(const Mul
   T out_v[VEC], out_u[VEC];  // raw outputs of levels S-1 and S (the two states written back)
   auto consume = [&](const Row &cur) {
     newflags[0] = 0u;
+    T uu[VEC];
+    bool odd = false;  // any NaN / inf in this lane's cells?
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
-      T u = cur.u[k];
-      if (first && P.area_weighted) u = u * cur.ar[k];  // prepare(): field * area (kernels.py:100-101)
-      if (SAN) {
+      uu[k] = cur.u[k];
+      if (first && P.area_weighted) uu[k] = uu[k] * cur.ar[k];  // prepare(): field * area (kernels.py:100-101)
+      odd = odd || !(mabs(uu[k]) <= MLim<T>::big());
+    }
+    // nan_to_num is the identity on finite values: only waves that actually hold a NaN/inf (land cells of a
+    // NaN-masked field) pay for the selects and the flag bookkeeping
+    if (SAN && __any(odd)) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
         unsigned f;
-        G[0][2][k] = msan_flag(u, f);
+        G[0][2][k] = msan_flag(uu[k], f);
         newflags[0] |= f << (2 * k);
-      } else {
-        G[0][2][k] = u;
       }
-      if (S == 1) out_v[k] = u;
+    } else {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) G[0][2][k] = uu[k];
     }
     if (KIND == K_FLUX) {
 #pragma unroll
@@ -251,72 +262,104 @@ __global__ __launch_bounds__(256, (S > 4) ? 1 : 2) void k_scalar_multi(const Mul
   };
 
   // ---- part 2: levels 1..S (level t produces row r-t), stores, window rotation ----
-  auto compute = [&](int r) {
+  // one level.  FLAGGED=false is the common case "no NaN/inf anywhere in this wave's windows": raw == sanitised.
+  auto level = [&](auto tt, auto flagged_c) {
+    constexpr int t = decltype(tt)::value;
+    constexpr bool FLAGGED = decltype(flagged_c)::value;
+    const T(&gS)[VEC] = G[t - 1][0];
+    const T(&gC)[VEC] = G[t - 1][1];
+    const T(&gN)[VEC] = G[t - 1][2];
+    const T wv = from_lower_lane(gC[VEC - 1]);
+    const T ev = from_upper_lane(gC[0]);
+    T tkv[VEC];
 #pragma unroll
-    for (int t = 1; t <= S; ++t) {
-      const T(&gS)[VEC] = G[t - 1][0];
-      const T(&gC)[VEC] = G[t - 1][1];
-      const T(&gN)[VEC] = G[t - 1][2];
-      const T wv = from_lower_lane(gC[VEC - 1]);
-      const T ev = from_upper_lane(gC[0]);
-      unsigned nf = 0u;
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) {
-        const T xC = gC[k];
-        const T xW = (k == 0) ? wv : gC[k > 0 ? k - 1 : 0];
-        const T xE = (k == VEC - 1) ? ev : gC[k < VEC - 1 ? k + 1 : k];
-        T L;
-        if (KIND == K_REG) {
-          L = T(-4) * xC + xE;
-          L = L + xW;
-          L = L + gN[k];
-          L = L + gS[k];
-        } else if (KIND == K_MASK) {
-          const unsigned bb = (Bq[t] >> (8 * k)) & 0xFFu;
-          const T mC = (bb & 1u) ? xC : T(0);
-          const T wf = (T)__popc((bb >> 1) & 0xFu);
-          L = -wf * mC + ((bb & 2u) ? xE : T(0));
-          L = L + ((bb & 4u) ? xW : T(0));
-          L = L + ((bb & 8u) ? gN[k] : T(0));
-          L = L + ((bb & 16u) ? gS[k] : T(0));
-          L = (bb & 1u) ? L : T(0);
-        } else {
-          const T cw = (k == 0) ? from_lower_lane(cEq[t][VEC - 1]) : cEq[t][k > 0 ? k - 1 : 0];
-          const T fe = (xE - xC) * cEq[t][k];
-          const T fw = (xC - xW) * cw;
-          const T fn = (gN[k] - xC) * cNq[t][k];
-          const T fs = (xC - gS[k]) * cNq[t + 1][k];
-          L = (fe - fw + fn - fs) * raq[t][k];
-        }
-        // raw centre of level t-1 (NaN/inf survive in "-x", filter.py:171-173)
-        const T x = SAN ? unsan(xC, (Rf[t - 1] >> (2 * VEC + 2 * k)) & 3u) : xC;
-        const T av = -x - c * L;
-        T tk;
-        if (t == 1 && first) {
-          tk = av;
-          if (std::is_same<FB, T>::value) Fq[1][k] = (FB)((T)P.p0 * x + (T)P.pk[0] * av);
-          else Fq[1][k] = (FB)(P.p0 * (double)x + P.pk[0] * (double)av);
-        } else {
-          T x2;
-          if (t == 1) x2 = Vp[k];
-          else x2 = SAN ? unsan(G[t >= 2 ? t - 2 : 0][0][k], (Rf[t >= 2 ? t - 2 : 0] >> (2 * k)) & 3u) : G[t >= 2 ? t - 2 : 0][0][k];
-          tk = T(2) * av - x2;
-          if (std::is_same<FB, T>::value) Fq[t][k] = Fq[t][k] + (FB)((T)P.pk[t - 1] * tk);
-          else Fq[t][k] = Fq[t][k] + (FB)(P.pk[t - 1] * (double)tk);
-        }
-        if (t == S - 1) out_v[k] = tk;
-        if (t == S) out_u[k] = tk;
-        if (t < S) {
-          if (SAN) {
-            unsigned f;
-            G[t][2][k] = msan_flag(tk, f);
-            nf |= f << (2 * k);
-          } else {
-            G[t][2][k] = tk;
-          }
-        }
+    for (int k = 0; k < VEC; ++k) {
+      const T xC = gC[k];
+      const T xW = (k == 0) ? wv : gC[k > 0 ? k - 1 : 0];
+      const T xE = (k == VEC - 1) ? ev : gC[k < VEC - 1 ? k + 1 : k];
+      T L;
+      if (KIND == K_REG) {
+        L = T(-4) * xC + xE;
+        L = L + xW;
+        L = L + gN[k];
+        L = L + gS[k];
+      } else if (KIND == K_MASK) {
+        const unsigned bb = (Bq[t] >> (8 * k)) & 0xFFu;
+        const T mC = (bb & 1u) ? xC : T(0);
+        const T wf = (T)__popc((bb >> 1) & 0xFu);
+        L = -wf * mC + ((bb & 2u) ? xE : T(0));
+        L = L + ((bb & 4u) ? xW : T(0));
+        L = L + ((bb & 8u) ? gN[k] : T(0));
+        L = L + ((bb & 16u) ? gS[k] : T(0));
+        L = (bb & 1u) ? L : T(0);
+      } else {
+        const T cw = (k == 0) ? from_lower_lane(cEq[t][VEC - 1]) : cEq[t][k > 0 ? k - 1 : 0];
+        const T fe = (xE - xC) * cEq[t][k];
+        const T fw = (xC - xW) * cw;
+        const T fn = (gN[k] - xC) * cNq[t][k];
+        const T fs = (xC - gS[k]) * cNq[t + 1][k];
+        L = (fe - fw + fn - fs) * raq[t][k];
       }
-      if (t < S) newflags[t] = nf;
+      // raw centre of level t-1 (NaN/inf survive in "-x", filter.py:171-173)
+      const T x = FLAGGED ? unsan(xC, (Rf[t - 1] >> (2 * VEC + 2 * k)) & 3u) : xC;
+      const T av = -x - c * L;
+      T tk;
+      if (t == 1 && first) {
+        tk = av;
+        if (std::is_same<FB, T>::value) Fq[1][k] = (FB)((T)P.p0 * x + (T)P.pk[0] * av);
+        else Fq[1][k] = (FB)(P.p0 * (double)x + P.pk[0] * (double)av);
+      } else {
+        T x2;
+        if (t == 1) x2 = Vp[k];
+        else x2 = FLAGGED ? unsan(G[t >= 2 ? t - 2 : 0][0][k], (Rf[t >= 2 ? t - 2 : 0] >> (2 * k)) & 3u) : G[t >= 2 ? t - 2 : 0][0][k];
+        tk = T(2) * av - x2;
+        if (std::is_same<FB, T>::value) Fq[t][k] = Fq[t][k] + (FB)((T)P.pk[t - 1] * tk);
+        else Fq[t][k] = Fq[t][k] + (FB)(P.pk[t - 1] * (double)tk);
+      }
+      tkv[k] = tk;
+      if (t == S - 1) out_v[k] = tk;
+      if (t == S) out_u[k] = tk;
+    }
+    if (t < S) {  // becomes the `new` row of this level's window
+      unsigned nf = 0u;
+      bool odd = false;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) odd = odd || !(mabs(tkv[k]) <= MLim<T>::big());
+      if (SAN && __any(odd)) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          unsigned f;
+          G[t < S ? t : 0][2][k] = msan_flag(tkv[k], f);
+          nf |= f << (2 * k);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) G[t < S ? t : 0][2][k] = tkv[k];
+      }
+      newflags[t < S ? t : 0] = nf;
+    }
+  };
+
+  auto level_all = [&](auto flagged_c) {
+    level(std::integral_constant<int, 1>{}, flagged_c);
+    if constexpr (S >= 2) level(std::integral_constant<int, 2>{}, flagged_c);
+    if constexpr (S >= 3) level(std::integral_constant<int, 3>{}, flagged_c);
+    if constexpr (S >= 4) level(std::integral_constant<int, 4>{}, flagged_c);
+    if constexpr (S >= 5) level(std::integral_constant<int, 5>{}, flagged_c);
+    if constexpr (S >= 6) level(std::integral_constant<int, 6>{}, flagged_c);
+    if constexpr (S >= 7) level(std::integral_constant<int, 7>{}, flagged_c);
+    if constexpr (S >= 8) level(std::integral_constant<int, 8>{}, flagged_c);
+  };
+
+  // ---- part 2: levels 1..S (level t produces row r-t), stores, window rotation ----
+  auto compute = [&](int r) {
+    unsigned anyf = newflags[0];
+#pragma unroll
+    for (int t = 0; t < S; ++t) anyf |= Rf[t];
+    if (SAN && __any(anyf != 0u)) {
+      level_all(std::true_type{});
+    } else {
+      level_all(std::false_type{});
     }
 
     // stores: T_{k-1+S} row r-S, T_{k-2+S} row r-S+1, fbar row r-S

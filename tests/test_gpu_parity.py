@@ -360,7 +360,7 @@ def test_temporal_blocking_bit_identical(grid, shape, dt, S, strip):
             got = flt.apply(f)
             n_multi = plan.last_timing()[1]
         finally:
-            plan.set_tuning(multi_s=4, strip_rows=0)
+            plan.set_tuning(multi_s=8, strip_rows=0)
             plan.set_timing(False)
         if grid.startswith("TRIPOLAR"):  # + S single-step launches on the fold band per blocked launch
             assert n_multi != n_single, (n_multi, n_single)
