@@ -25,11 +25,12 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 # algorithmic HBM bytes per cell per Laplacian step (SURVEY 8d / DESIGN.md): 5 state words + folded coefficients
+# w = sizeof(state), f = sizeof(fbar) (f64 even for f32 state: NumPy >= 2 promotion), L = levels sharing the 2-D planes
 B_ALG = {
-    "REGULAR_WITH_LAND": lambda w: 5 * w + 1,
-    "IRREGULAR_WITH_LAND": lambda w: 8 * w,
-    "TRIPOLAR_POP_WITH_LAND": lambda w: 8 * w,
-    "VECTOR_C_GRID": lambda w: 24 * w,
+    "REGULAR_WITH_LAND": lambda w, f, L: 3 * w + 2 * f + 1.0 / L,
+    "IRREGULAR_WITH_LAND": lambda w, f, L: 3 * w + 2 * f + 3 * w / L,
+    "TRIPOLAR_POP_WITH_LAND": lambda w, f, L: 3 * w + 2 * f + 3 * w / L,
+    "VECTOR_C_GRID": lambda w, f, L: 2 * (3 * w + 2 * f) + 14 * w / L,
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
@@ -221,7 +222,7 @@ def main():
     }
     if rank == 0:
         w = itemsize
-        b_alg = B_ALG[grid](w)
+        b_alg = B_ALG[grid](w, 8, nbatch)
         cells_per_launch = (cells // world) if world > 1 else cells
         if launches and kernel_ms > 0:
             # a launch of the temporally blocked kernel advances several steps: price every launch with the

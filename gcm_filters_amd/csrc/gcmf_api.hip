@@ -491,8 +491,11 @@ static int run_whole(gcmf_plan *pl, const double *p, int n_steps, double c, cons
         const int left = n_steps - k + 1;
         int S = 1;
         const int cand[5] = {8, 6, 4, 3, 2};
-        for (int q = 0; q < 5; ++q)
-          if (cand[q] <= left && cand[q] <= pl->multi_s && multi_supported(pl, cand[q])) { S = cand[q]; break; }
+        for (int q = 0; q < 5; ++q)  // largest depth that does not strand a lone single step at the end
+          if (cand[q] <= left && left - cand[q] != 1 && cand[q] <= pl->multi_s && multi_supported(pl, cand[q])) {
+            S = cand[q];
+            break;
+          }
         void *fr[2] = {nullptr, nullptr};
         int nf = 0;
         for (int q = 0; q < 4 && nf < 2; ++q)

@@ -117,7 +117,11 @@ class SlabFilter:
         if self.world == 1:
             self.halo = 0
         else:
-            self.halo = int(halo) if halo else 8
+            # default: 8 ghost rows (one blocked launch) per ~400 owned rows, at most 32: an exchange costs a few
+            # hundred microseconds of host + RCCL latency, a blocked 8-step launch on a 2400-row slab ~230 us, and
+            # the redundant ghost-zone work of a 32-row halo is still < 2 % there
+            auto = 8 * max(1, min(4, min_rows // 400))
+            self.halo = int(halo) if halo else auto
             self.halo = max(1, min(self.halo, min_rows))
         planes = [np.ascontiguousarray(np.asarray(grid_vars[k]), dtype=self.np_dtype)
                   for k in self.lap_cls.required_grid_args()]
@@ -183,6 +187,15 @@ class SlabFilter:
         return self._bufs[key]
 
     # -- halo exchange -------------------------------------------------------------------------
+    def _xbuf(self, key, n, like):
+        """Persistent packed exchange buffer (one per peer / direction / size)."""
+        key = key + (like.dtype,)
+        b = self._bufs.get(key)
+        if b is None:
+            b = self.torch.empty(n, dtype=like.dtype, device=like.device)
+            self._bufs[key] = b
+        return b
+
     def _exchange(self, tensors: List):
         """Refresh all `halo` ghost rows of every tensor in `tensors` (each (ncomp, nbatch, rows_alloc, nx))."""
         if self.world == 1 or (self.south is None and self.north is None):
@@ -210,13 +223,19 @@ class SlabFilter:
         stage = self.device.type == "cuda" and dist.get_backend(self.group) == "gloo"
         ops, unpack = [], []
         for peer, parts in sends.items():
-            buf = t.cat([p.reshape(-1) for p in parts])
+            n = sum(p.numel() for p in parts)
+            buf = self._xbuf(("s", peer, n), n, parts[0])
+            off = 0
+            for p in parts:  # pack straight into the persistent send buffer
+                buf[off: off + p.numel()].view(p.shape).copy_(p)
+                off += p.numel()
             if stage:
                 buf = buf.cpu()
             ops.append(dist.P2POp(dist.isend, buf, self._global_rank(peer), group=self.group))
         for peer, parts in recvs.items():
             n = sum(p.numel() for p in parts)
-            buf = t.empty(n, dtype=parts[0].dtype, device="cpu" if stage else parts[0].device)
+            buf = (t.empty(n, dtype=parts[0].dtype, device="cpu") if stage
+                   else self._xbuf(("r", peer, n), n, parts[0]))
             ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(peer), group=self.group))
             unpack.append((buf, parts))
         for w in dist.batch_isend_irecv(ops):
@@ -267,6 +286,8 @@ class SlabFilter:
             S = 1
             if can_multi:
                 for cand in self.MULTI_DEPTHS:
+                    if budget - cand == 1 and left == budget:
+                        continue  # do not strand a lone single step at the very end
                     if cand <= budget and cand <= self.multi_depth and self.engine.multi_supported(cand):
                         S = cand
                         break
