@@ -106,7 +106,7 @@ def main():
                     help="N>1: weak = every GPU owns a full ny-row slab of a (N*ny, nx) grid; strong = one (ny, nx) grid")
     ap.add_argument("--halo", type=int, default=0, help="N>1: ghost rows per exchange (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-steps", type=int, default=12, help="Laplacian steps of the CPU sample")
+    ap.add_argument("--cpu-steps", type=int, default=64, help="Laplacian steps of the CPU sample")
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--xcd-remap", type=int, default=-1)
     ap.add_argument("--multi", type=int, default=0, help="recurrence steps fused per HBM pass (0 = library default, 1 = off)")
