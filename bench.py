@@ -27,6 +27,7 @@ sys.path.insert(0, REPO)
 # algorithmic HBM bytes per cell per Laplacian step (SURVEY 8d / DESIGN.md): 5 state words + folded coefficients
 # w = sizeof(state), f = sizeof(fbar) (f64 even for f32 state: NumPy >= 2 promotion), L = levels sharing the 2-D planes
 B_ALG = {
+    "REGULAR": lambda w, f, L: 3 * w + 2 * f,
     "REGULAR_WITH_LAND": lambda w, f, L: 3 * w + 2 * f + 1.0 / L,
     "IRREGULAR_WITH_LAND": lambda w, f, L: 3 * w + 2 * f + 3 * w / L,
     "TRIPOLAR_POP_WITH_LAND": lambda w, f, L: 3 * w + 2 * f + 3 * w / L,
@@ -40,7 +41,12 @@ def build_workload(cfg: int, ny: int, nx: int, nlev: int):
     from gcm_filters_amd import FilterShape, testing as T
 
     shape = (ny, nx)
-    if cfg == 2:
+    if cfg == 1:  # BASELINE config 1 scaled up is not asked for; REGULAR at the benchmark size for reference
+        grid = "REGULAR"
+        gv = {}
+        fields = [T.random_field(shape, 100)]
+        fk = dict(filter_scale=50.0, dx_min=1.0, filter_shape=FilterShape.GAUSSIAN)
+    elif cfg == 2:
         grid = "REGULAR_WITH_LAND"
         gv = {"wet_mask": T.land_mask(shape)}
         fields = [T.random_field(shape, 100)]
@@ -155,7 +161,7 @@ def main():
         from gcm_filters_amd import _lib
         plan = lap._plan(_lib.F64 if itemsize == 8 else _lib.F32, (args.ny, args.nx), local_rank)
         if args.rows_per_wave or args.xcd_remap >= 0 or args.multi or args.strip or args.prefetch:
-            plan.set_tuning(args.rows_per_wave, args.xcd_remap, args.multi or 4, args.strip, args.prefetch)
+            plan.set_tuning(args.rows_per_wave, args.xcd_remap, args.multi or 8, args.strip, args.prefetch)
         plan.set_timing(True)
         d_in = [torch.from_numpy(f).to(dev) for f in wl["fields"]]
         run = (lambda: flt.apply_to_vector(d_in[0], d_in[1])) if len(d_in) == 2 else (lambda: flt.apply(d_in[0]))

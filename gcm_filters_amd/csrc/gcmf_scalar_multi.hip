@@ -20,104 +20,18 @@
 //
 // Reference semantics per level: gcm_filters/filter.py:162-175,192-206 + the Laplacians of kernels.py (see
 // gcmf_scalar.hip for the per-kind citations).
-#include "gcmf_internal.hpp"
-
-#include <cfloat>
-#include <type_traits>
+#include "gcmf_multi_common.hpp"
 
 namespace gcmf {
 
-template <typename T> struct MLim;
-template <> struct MLim<float> { static __device__ __forceinline__ float big() { return FLT_MAX; } };
-template <> struct MLim<double> { static __device__ __forceinline__ double big() { return DBL_MAX; } };
-
-template <typename T> __device__ __forceinline__ T msan(T x) {  // numpy.nan_to_num
-  if (x != x) return T(0);
-  if (x > MLim<T>::big()) return MLim<T>::big();
-  if (x < -MLim<T>::big()) return -MLim<T>::big();
-  return x;
-}
-
-template <typename T, int VEC> struct alignas((sizeof(T) * VEC) > 16 ? 16 : (sizeof(T) * VEC)) MPack { T s[VEC]; };
-template <typename T, int VEC> __device__ __forceinline__ void mload(T (&d)[VEC], const T *p) {
-  const MPack<T, VEC> v = *reinterpret_cast<const MPack<T, VEC> *>(p);
-#pragma unroll
-  for (int k = 0; k < VEC; ++k) d[k] = v.s[k];
-}
-template <typename T, int VEC> __device__ __forceinline__ void mstore(T *p, const T (&d)[VEC]) {
-  MPack<T, VEC> v;
-#pragma unroll
-  for (int k = 0; k < VEC; ++k) v.s[k] = d[k];
-  *reinterpret_cast<MPack<T, VEC> *>(p) = v;
-}
-
-// lane i <- lane i-1 / lane i+1 of the same wave by DPP (one VALU move per dword; no LDS crossbar round trip).
-// The outermost lanes keep their own value -- they are margin lanes whose results are never stored.
-__device__ __forceinline__ int dpp_up_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }    // wave_shr:1
-__device__ __forceinline__ int dpp_down_i(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }  // wave_shl:1
-__device__ __forceinline__ double from_lower_lane(double v) {
-  return __hiloint2double(dpp_up_i(__double2hiint(v)), dpp_up_i(__double2loint(v)));
-}
-__device__ __forceinline__ double from_upper_lane(double v) {
-  return __hiloint2double(dpp_down_i(__double2hiint(v)), dpp_down_i(__double2loint(v)));
-}
-__device__ __forceinline__ float from_lower_lane(float v) { return __int_as_float(dpp_up_i(__float_as_int(v))); }
-__device__ __forceinline__ float from_upper_lane(float v) { return __int_as_float(dpp_down_i(__float_as_int(v))); }
-
-// nan_to_num that also reports what it removed (bit0: was NaN, bit1: was +-inf), so the raw value can be
-// rebuilt later from the sanitised one without keeping a second copy in registers.  Written as selects
-// (v_cmp + v_cndmask), not branches: this runs for every value of every level.
-template <typename T> __device__ __forceinline__ T msan_flag(T x, unsigned &f) {
-  const bool isn = (x != x);
-  const bool big = (__builtin_fabs(x) > MLim<T>::big());  // false for NaN
-  f = (isn ? 1u : 0u) | (big ? 2u : 0u);
-  const T clamped = big ? __builtin_copysign(MLim<T>::big(), x) : x;
-  return isn ? T(0) : clamped;
-}
-template <> __device__ __forceinline__ float msan_flag<float>(float x, unsigned &f) {
-  const bool isn = (x != x);
-  const bool big = (__builtin_fabsf(x) > FLT_MAX);
-  f = (isn ? 1u : 0u) | (big ? 2u : 0u);
-  const float clamped = big ? __builtin_copysignf(FLT_MAX, x) : x;
-  return isn ? 0.f : clamped;
-}
-template <typename T> __device__ __forceinline__ T unsan(T g, unsigned f) {
-  const T inf = __builtin_copysign((T)__builtin_inf(), g);
-  const T r = (f & 2u) ? inf : g;
-  return (f & 1u) ? (T)__builtin_nan("") : r;
-}
-template <> __device__ __forceinline__ float unsan<float>(float g, unsigned f) {
-  const float inf = __builtin_copysignf(__builtin_inff(), g);
-  const float r = (f & 2u) ? inf : g;
-  return (f & 1u) ? __builtin_nanf("") : r;
-}
-
-__device__ __forceinline__ double mabs(double x) { return __builtin_fabs(x); }
-__device__ __forceinline__ float mabs(float x) { return __builtin_fabsf(x); }
-
-constexpr int MAX_S = 8;
-
-template <typename T, typename FB> struct MultiP {
-  const T *u0;      // T_{k-1}
-  const T *v0;      // T_{k-2}            (unused when first)
-  T *uo;            // T_{k-1+S}          (unused when last)
-  T *vo;            // T_{k-2+S}          (unused when last)
-  const FB *fb_in;  // running sum in     (unused when first)
-  FB *fb_out;       // running sum out / finalised result when last
-  const T *cE, *cN, *ra;
-  const uint8_t *mbits;
-  const T *area;
-  int nx, rows, out_lo, out_hi;
-  int H, nwx, nstrips, nwaves;
-  int wrap, first, last, area_weighted;
-  long long bstride;
-  double pk[MAX_S];  // coefficient of level t (1-based) at pk[t-1]
-  double p0;         // first only
-  double c;
+// resident waves per SIMD the register budget allows: the flux form carries 3 coefficient lag windows and fits two
+// waves only up to S = 4; the coefficient-free kinds fit two waves at every depth
+template <typename T, int KIND, int S> struct WavesPerSimd {
+  static constexpr int value = (KIND == K_FLUX && S > 4) ? 1 : ((KIND == K_MASK && S > 6 && sizeof(T) == 4) ? 1 : 2);
 };
 
 template <typename T, typename FB, int KIND, int S, int D>
-__global__ __launch_bounds__(256, (S > 4) ? 1 : 2) void k_scalar_multi(const MultiP<T, FB> P) {
+__global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scalar_multi(const MultiP<T, FB> P) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int W = 64 * VEC;
   constexpr int M = (S + VEC - 1) / VEC * VEC;  // x margin, multiple of VEC so that windows stay 16-byte aligned
@@ -410,10 +324,11 @@ __global__ __launch_bounds__(256, (S > 4) ? 1 : 2) void k_scalar_multi(const Mul
 
   // ---- march north with D rows of operands in flight (explicit slots so that they stay in registers) ----
   const int r_begin = a - S, r_end = b + S;  // rows loaded by this strip: [a-S, b+S)
-  Row q0, q1, q2;
+  Row q0, q1, q2, q3;
   load_row(q0, r_begin);
   if (D >= 2) load_row(q1, min(r_begin + 1, r_end - 1));
   if (D >= 3) load_row(q2, min(r_begin + 2, r_end - 1));
+  if (D >= 4) load_row(q3, min(r_begin + 3, r_end - 1));
 #define GCMF_SLOT(Q, dd)                                          \
   if (r + (dd) < r_end) {                                         \
     consume(Q); /* waits for this slot only */                    \
@@ -424,6 +339,7 @@ __global__ __launch_bounds__(256, (S > 4) ? 1 : 2) void k_scalar_multi(const Mul
     GCMF_SLOT(q0, 0)
     if (D >= 2) { GCMF_SLOT(q1, 1) }
     if (D >= 3) { GCMF_SLOT(q2, 2) }
+    if (D >= 4) { GCMF_SLOT(q3, 3) }
   }
 #undef GCMF_SLOT
 }
@@ -460,7 +376,7 @@ static int launch_multi_s(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   // on MI355X (2400x3600 f64, S=4): 67 strips x 30 windows = 2010 waves (H=36) is the sweet spot.
   int H = pl->strip_rows;
   if (H <= 0) {
-    const long long cap = (S > 4) ? 1024 : 2048;
+    const long long cap = 1024 * WavesPerSimd<T, KIND, S>::value;
     long long want = cap / ((long long)P.nwx * a.nbatch);
     if (want < 1) want = 1;
     H = (int)((nrows + want - 1) / want);
@@ -490,7 +406,10 @@ template <typename T, typename FB, int KIND> static int launch_multi_k(gcmf_plan
     case 3: return launch_multi_s<T, FB, KIND, 3, 2>(pl, a, s);
     case 4: return pl->prefetch_rows == 1 ? launch_multi_s<T, FB, KIND, 4, 1>(pl, a, s) : launch_multi_s<T, FB, KIND, 4, 2>(pl, a, s);
     case 6: return launch_multi_s<T, FB, KIND, 6, 2>(pl, a, s);
-    case 8: return pl->prefetch_rows == 3 ? launch_multi_s<T, FB, KIND, 8, 3>(pl, a, s) : launch_multi_s<T, FB, KIND, 8, 2>(pl, a, s);
+    case 8:
+      if (pl->prefetch_rows == 3) return launch_multi_s<T, FB, KIND, 8, 3>(pl, a, s);
+      if (pl->prefetch_rows == 4) return launch_multi_s<T, FB, KIND, 8, 4>(pl, a, s);
+      return launch_multi_s<T, FB, KIND, 8, 2>(pl, a, s);
   }
   set_error("launch_scalar_multi: unsupported S=%d", a.S);
   return GCMF_ERR_INVALID_ARG;
