@@ -62,6 +62,29 @@ __device__ __forceinline__ void cheb_update(const VecP<T, FB> &P, int comp, long
   P.fb_out[comp][off] = fb;
 }
 
+// same update with the centre-only operands (T_{k-2}, fbar) already in registers
+template <typename T, typename FB>
+__device__ __forceinline__ void cheb_update_pre(const VecP<T, FB> &P, int comp, long long off, T x, T L, T x2, FB fbin) {
+  if (P.mode & STEP_LAPL) {
+    P.t0[comp][off] = L;
+    return;
+  }
+  const T a = -x - (T)P.c * L;
+  FB fb;
+  T tk;
+  if (P.mode & GCMF_STEP_FIRST) {
+    tk = a;
+    if (std::is_same<FB, T>::value) fb = (FB)((T)P.coef0 * x + (T)P.coef1 * a);
+    else fb = (FB)(P.coef0 * (double)x + P.coef1 * (double)a);
+  } else {
+    tk = T(2) * a - x2;
+    if (std::is_same<FB, T>::value) fb = fbin + (FB)((T)P.coef0 * tk);
+    else fb = fbin + (FB)(P.coef0 * (double)tk);
+  }
+  if (!(P.mode & GCMF_STEP_LAST)) P.t0[comp][off] = tk;
+  P.fb_out[comp][off] = fb;
+}
+
 __device__ __forceinline__ int wrapx(int i, int nx) { return i < 0 ? i + nx : (i >= nx ? i - nx : i); }
 
 // row index inside the slab allocation: periodic wrap for a single slab, clamp otherwise (clamped rows are
@@ -86,6 +109,28 @@ template <typename T, typename FB> __global__ __launch_bounds__(256) void k_cgri
   const T *r_dyCu = P.coef[0], *r_dxCu = P.coef[1], *r_dxCv = P.coef[2], *r_dyCv = P.coef[3];
   const T *a1 = P.coef[4], *a2 = P.coef[5], *rh = P.coef[6], *b1 = P.coef[7], *b2 = P.coef[8], *rq = P.coef[9];
   const int tid = threadIdx.y * 64 + threadIdx.x;
+
+  // operands of phase 2 (this thread's 4 output cells): issued now so that they are in flight during phase 1
+  const int bcol = threadIdx.x;
+  const bool col_ok = (I0 + bcol) < nx;
+  long long cc2[CT_J / 4];
+  bool ok2[CT_J / 4];
+  T k10[CT_J / 4], k11[CT_J / 4], k12[CT_J / 4], k13[CT_J / 4], xu[CT_J / 4], xv[CT_J / 4], x2u[CT_J / 4], x2v[CT_J / 4];
+  FB fbu[CT_J / 4], fbv[CT_J / 4];
+  const bool need_prev = !(P.mode & (GCMF_STEP_FIRST | STEP_LAPL));
+#pragma unroll
+  for (int q = 0; q < CT_J / 4; ++q) {
+    const int j = J0 + threadIdx.y + 4 * q;
+    ok2[q] = col_ok && j < P.row_hi;
+    cc2[q] = ok2[q] ? (long long)j * nx + (I0 + bcol) : 0;
+    k10[q] = P.coef[10][cc2[q]]; k11[q] = P.coef[11][cc2[q]]; k12[q] = P.coef[12][cc2[q]]; k13[q] = P.coef[13][cc2[q]];
+    xu[q] = u[cc2[q]]; xv[q] = v[cc2[q]];
+    x2u[q] = T(0); x2v[q] = T(0); fbu[q] = FB(0); fbv[q] = FB(0);
+    if (need_prev) {
+      x2u[q] = P.t2[0][boff + cc2[q]]; x2v[q] = P.t2[1][boff + cc2[q]];
+      fbu[q] = P.fb_in[0][boff + cc2[q]]; fbv[q] = P.fb_in[1][boff + cc2[q]];
+    }
+  }
 
   // phase 1: stresses.  sP[a][b] = dy2h*str_xx at (J0+a, I0+b);  sR[a][b] = dx2q*str_xy at (J0-1+a, I0-1+b)
   for (int idx = tid; idx < CT_PTS; idx += 256) {
@@ -115,18 +160,17 @@ template <typename T, typename FB> __global__ __launch_bounds__(256) void k_cgri
   }
   __syncthreads();
 
-  // phase 2: divergence of the stresses + recurrence update
-  const int b = threadIdx.x, i = I0 + b;
-  if (i >= nx) return;
-  for (int a = threadIdx.y; a < CT_J; a += 4) {
-    const int j = J0 + a;
-    if (j >= P.row_hi) break;
-    const long long cc = (long long)j * nx + i;
-    const int l00 = a * CT_LD + b;  // [a][b]
-    const T lu = P.coef[10][cc] * (sP[l00] - sP[l00 + 1]) + P.coef[11][cc] * (sR[l00 + 1] - sR[l00 + CT_LD + 1]);
-    const T lv = P.coef[12][cc] * (sS[l00 + CT_LD] - sS[l00 + CT_LD + 1]) - P.coef[13][cc] * (sQ[l00] - sQ[l00 + CT_LD]);
-    cheb_update<T, FB>(P, 0, boff + cc, u[cc], lu);
-    cheb_update<T, FB>(P, 1, boff + cc, v[cc], lv);
+  // phase 2: divergence of the stresses + recurrence update (operands were fetched before phase 1)
+  if (!col_ok) return;
+#pragma unroll
+  for (int q = 0; q < CT_J / 4; ++q) {
+    if (!ok2[q]) continue;
+    const int a = threadIdx.y + 4 * q;
+    const int l00 = a * CT_LD + bcol;  // [a][b]
+    const T lu = k10[q] * (sP[l00] - sP[l00 + 1]) + k11[q] * (sR[l00 + 1] - sR[l00 + CT_LD + 1]);
+    const T lv = k12[q] * (sS[l00 + CT_LD] - sS[l00 + CT_LD + 1]) - k13[q] * (sQ[l00] - sQ[l00 + CT_LD]);
+    cheb_update_pre<T, FB>(P, 0, boff + cc2[q], xu[q], lu, x2u[q], fbu[q]);
+    cheb_update_pre<T, FB>(P, 1, boff + cc2[q], xv[q], lv, x2v[q], fbv[q]);
   }
 }
 

@@ -117,10 +117,10 @@ class SlabFilter:
         if self.world == 1:
             self.halo = 0
         else:
-            # default: 8 ghost rows (one blocked launch) per ~400 owned rows, at most 32: an exchange costs a few
-            # hundred microseconds of host + RCCL latency, a blocked 8-step launch on a 2400-row slab ~230 us, and
-            # the redundant ghost-zone work of a 32-row halo is still < 2 % there
-            auto = 8 * max(1, min(4, min_rows // 400))
+            # default: 8 ghost rows (one blocked launch) per ~300 owned rows, at most 64: an exchange costs a few
+            # hundred microseconds of host + RCCL latency, a blocked 8-step launch on a 2400-row slab ~200 us, and
+            # the redundant ghost-zone work of a 64-row halo is still ~2 % there
+            auto = 8 * max(1, min(8, min_rows // 300))
             self.halo = int(halo) if halo else auto
             self.halo = max(1, min(self.halo, min_rows))
         planes = [np.ascontiguousarray(np.asarray(grid_vars[k]), dtype=self.np_dtype)
