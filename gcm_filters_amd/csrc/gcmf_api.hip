@@ -3,6 +3,7 @@
 #include "gcmf_internal.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace gcmf {
@@ -252,6 +253,7 @@ int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int 
       return fail(GCMF_ERR_HIP);                                                       \
     }                                                                                  \
   } while (0)
+  if (const char *e = getenv("GCMF_CGRID_TILE")) pl->cgrid_tile = atoi(e);
   PLAN_HIP(hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking));
   PLAN_HIP(hipEventCreate(&pl->ev0));
   PLAN_HIP(hipEventCreate(&pl->ev1));

@@ -108,6 +108,7 @@ struct gcmf_plan {
   int multi_s = 8;     // steps fused per pass by the temporally blocked kernel (1 = off); 8 measured best
   int strip_rows = 0;  // rows per wave strip of that kernel (0 = auto)
   int prefetch_rows = 0;  // rows of operands in flight per wave (0 = default per S)
+  int cgrid_tile = 0;     // 1: force the LDS-tile C-grid kernel instead of the streaming one (A/B testing)
   std::mutex mu;
 };
 
@@ -117,6 +118,8 @@ size_t dtype_size(int dtype);
 int launch_scalar_step(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 int launch_vector_step(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 int launch_scalar_multi(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
+int launch_cgrid_stream(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
+bool cgrid_stream_supported(const gcmf_plan *pl, const StepArgs &a);
 bool multi_supported(const gcmf_plan *pl, int S);
 // S fused steps on rows [row_lo,row_hi) incl. the tripole band when the range ends at the fold row (gcmf_api.hip)
 int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launches);
