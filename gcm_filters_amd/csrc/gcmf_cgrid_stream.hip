@@ -244,7 +244,9 @@ template <typename T, typename FB> static int launch_cs(gcmf_plan *pl, const Ste
   if (nrows <= 0 || a.nbatch <= 0) return GCMF_OK;
   P.nwx = (g.nx + WI - 1) / WI;
   P.nlev = (int)a.nbatch;
-  P.nlev4 = P.nlev >= 4 ? (P.nlev + 3) / 4 * 4 : P.nlev;
+  P.nlev4 = (P.nlev + 3) / 4 * 4;
+  P.lockstep = (P.nlev4 * 10 <= P.nlev * 11) ? 1 : 0;
+  if (!P.lockstep) P.nlev4 = P.nlev;
   int H = pl->strip_rows;
   if (H <= 0) {
     // enough waves for one resident round (2 per SIMD) AND enough (window, strip) groups that the 8 XCDs, which
@@ -254,14 +256,14 @@ template <typename T, typename FB> static int launch_cs(gcmf_plan *pl, const Ste
     if (want < want_groups) want = want_groups;
     if (want < 1) want = 1;
     H = (int)((nrows + want - 1) / want);
-    if (H < 32) H = 32;
+    if (H < 16) H = 16;
   }
   if (H > nrows) H = nrows;
   P.H = H;
   const int nstrips = (nrows + H - 1) / H;
   P.ngroups = P.nwx * nstrips;
   P.wrap = g.south_wrap && g.north_wrap;
-  P.lockstep = P.nlev >= 4 ? 1 : 0;  // fewer than 4 levels: independent waves, no padding
+  // lock-step needs whole workgroups per group: pad the levels to a multiple of 4 unless that wastes > 10 %
   P.mode = a.mode;
   P.bstride = (long long)g.rows * g.nx;
   P.coef0 = a.coef0;
