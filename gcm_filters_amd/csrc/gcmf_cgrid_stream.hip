@@ -45,8 +45,12 @@ template <typename T> __device__ __forceinline__ T csan(T x) {  // numpy.nan_to_
   return isn ? T(0) : clamped;
 }
 
-template <typename T, typename FB, int D>
+// SHARED: the 4 waves of a workgroup are 4 levels of one (window, strip) group marching in lock-step; each wave
+// fetches a quarter of the 14 coefficient rows and they are exchanged through LDS (double-buffered, one barrier
+// per row), so a coefficient row crosses the memory system once per workgroup instead of once per level.
+template <typename T, typename FB, int D, bool SHARED>
 __global__ __launch_bounds__(256, 2) void k_cgrid_stream(const CStreamP<T, FB> P) {
+  __shared__ MPack<T, 16 / sizeof(T)> s_coef[SHARED ? 2 : 1][SHARED ? 14 : 1][SHARED ? 64 : 1];
   constexpr int VEC = 16 / sizeof(T);
   constexpr int W = 64 * VEC;
   constexpr int M = VEC;
@@ -85,7 +89,9 @@ __global__ __launch_bounds__(256, 2) void k_cgrid_stream(const CStreamP<T, FB> P
     T b1[VEC], b2[VEC], rq[VEC], cu1[VEC], cu2[VEC], cv1[VEC], cv2[VEC];         // row r-1
     T u2[VEC], v2[VEC];                                           // row r-1
     FB fu[VEC], fv[VEC];                                          // row r-1
+    T share[4][VEC];                                              // SHARED: planes wv, wv+4, wv+8, wv+12 of this row
   };
+  const int wv = threadIdx.x >> 6;
   auto row_index = [&](int r) {
     if (P.wrap) return r < 0 ? r + rows : (r >= rows ? r - rows : r);
     return r < 0 ? 0 : (r >= rows ? rows - 1 : r);
@@ -95,6 +101,20 @@ __global__ __launch_bounds__(256, 2) void k_cgrid_stream(const CStreamP<T, FB> P
     const long long rc = (long long)row_index(r - 1) * nx + col;
     mload<T, VEC>(x.u, P.u0 + boff + ro);
     mload<T, VEC>(x.v, P.v0 + boff + ro);
+    if (need_prev) {
+      mload<T, VEC>(x.u2, P.u2 + boff + rc);
+      mload<T, VEC>(x.v2, P.v2 + boff + rc);
+      mload<FB, VEC>(x.fu, P.fu_in + boff + rc);
+      mload<FB, VEC>(x.fv, P.fv_in + boff + rc);
+    }
+    if (SHARED) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int pidx = wv + 4 * q;  // planes 0..6 belong to row r, 7..13 to row r-1
+        if (pidx < 14) mload<T, VEC>(x.share[q], P.coef[pidx] + (pidx < 7 ? ro : rc));
+      }
+      return;
+    }
     mload<T, VEC>(x.rdyCu, P.coef[0] + ro);
     mload<T, VEC>(x.rdxCu, P.coef[1] + ro);
     mload<T, VEC>(x.rdxCv, P.coef[2] + ro);
@@ -109,12 +129,6 @@ __global__ __launch_bounds__(256, 2) void k_cgrid_stream(const CStreamP<T, FB> P
     mload<T, VEC>(x.cu2, P.coef[11] + rc);
     mload<T, VEC>(x.cv1, P.coef[12] + rc);
     mload<T, VEC>(x.cv2, P.coef[13] + rc);
-    if (need_prev) {
-      mload<T, VEC>(x.u2, P.u2 + boff + rc);
-      mload<T, VEC>(x.v2, P.v2 + boff + rc);
-      mload<FB, VEC>(x.fu, P.fu_in + boff + rc);
-      mload<FB, VEC>(x.fv, P.fv_in + boff + rc);
-    }
   };
 
   // state carried from row r-1 / r-2
@@ -135,7 +149,28 @@ __global__ __launch_bounds__(256, 2) void k_cgrid_stream(const CStreamP<T, FB> P
     }
   };
 
-  auto step = [&](const Row &x, int r) {
+  auto step = [&](Row &x, int r) {
+    if (SHARED) {
+      const int buf = (r - (a - 1)) & 1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int pidx = wv + 4 * q;
+        if (pidx < 14) {
+          MPack<T, VEC> pk;
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) pk.s[k] = x.share[q][k];
+          s_coef[buf][pidx][lane] = pk;
+        }
+      }
+      __syncthreads();
+      auto get = [&](T (&dst)[VEC], int pidx) {
+        const MPack<T, VEC> pk = s_coef[buf][pidx][lane];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) dst[k] = pk.s[k];
+      };
+      get(x.rdyCu, 0); get(x.rdxCu, 1); get(x.rdxCv, 2); get(x.rdyCv, 3); get(x.a1, 4); get(x.a2, 5); get(x.rh, 6);
+      get(x.b1, 7); get(x.b2, 8); get(x.rq, 9); get(x.cu1, 10); get(x.cu2, 11); get(x.cv1, 12); get(x.cv2, 13);
+    }
     T ut[VEC], uh[VEC], vt[VEC], vh[VEC], Pr[VEC], Qr[VEC], Rm[VEC], Sm[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
@@ -211,7 +246,6 @@ __global__ __launch_bounds__(256, 2) void k_cgrid_stream(const CStreamP<T, FB> P
     load_row(Q, min(r + (dd) + D, r_end - 1));               \
   }
   for (int r = r_begin; r < r_end; r += D) {
-    if (P.lockstep) __syncthreads();  // the waves of a workgroup are levels of one group: keep their coefficient reads together
     GCMF_CSLOT(q0, 0)
     if (D >= 2) { GCMF_CSLOT(q1, 1) }
   }
@@ -249,13 +283,12 @@ template <typename T, typename FB> static int launch_cs(gcmf_plan *pl, const Ste
   if (!P.lockstep) P.nlev4 = P.nlev;
   int H = pl->strip_rows;
   if (H <= 0) {
-    // enough waves for one resident round (2 per SIMD) AND enough (window, strip) groups that the 8 XCDs, which
-    // each take whole groups with all their levels, are evenly loaded (>= 16 groups per XCD); strips >= 32 rows
+    // enough waves for a resident round (2 per SIMD), but strips of at most 48 rows: many (window, strip) groups
+    // keep the 8 XCDs (which each take whole groups with all their levels) evenly loaded -- measured best 32..64
     long long want = 2048 / ((long long)P.nwx * a.nbatch);
-    const long long want_groups = (128 + P.nwx - 1) / P.nwx;
-    if (want < want_groups) want = want_groups;
     if (want < 1) want = 1;
     H = (int)((nrows + want - 1) / want);
+    if (H > 48) H = 48;
     if (H < 16) H = 16;
   }
   if (H > nrows) H = nrows;
@@ -274,7 +307,8 @@ template <typename T, typename FB> static int launch_cs(gcmf_plan *pl, const Ste
   const long long waves_per_xcd = groups_per_xcd * P.nlev4;
   const long long blocks_per_xcd = (waves_per_xcd + 3) / 4;
   dim3 block(256), grid((unsigned)(blocks_per_xcd * 8));
-  hipLaunchKernelGGL((k_cgrid_stream<T, FB, 2>), grid, block, 0, s, P);
+  if (P.lockstep) hipLaunchKernelGGL((k_cgrid_stream<T, FB, 2, true>), grid, block, 0, s, P);
+  else hipLaunchKernelGGL((k_cgrid_stream<T, FB, 2, false>), grid, block, 0, s, P);
   GCMF_HIP(hipGetLastError());
   return GCMF_OK;
 }
