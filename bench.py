@@ -32,6 +32,7 @@ B_ALG = {
     "IRREGULAR_WITH_LAND": lambda w, f, L: 3 * w + 2 * f + 3 * w / L,
     "TRIPOLAR_POP_WITH_LAND": lambda w, f, L: 3 * w + 2 * f + 3 * w / L,
     "VECTOR_C_GRID": lambda w, f, L: 2 * (3 * w + 2 * f) + 14 * w / L,
+    "VECTOR_B_GRID": lambda w, f, L: 2 * (3 * w + 2 * f) + 8 * w / L,
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
@@ -69,6 +70,12 @@ def build_workload(cfg: int, ny: int, nx: int, nlev: int):
         gv["kappa_aniso"] = np.zeros(shape, dtype=np.float32)
         fields = [np.stack([T.random_field(shape, 42 + c + 2 * l).astype(np.float32) for l in range(nlev)])
                   for c in range(2)]
+        dx = T.grid_dx_min(grid, gv)
+        fk = dict(filter_scale=40 * dx, dx_min=dx, filter_shape=FilterShape.GAUSSIAN)
+    elif cfg == 6:  # not a BASELINE config: the POP B-grid vector Laplacian at the benchmark size, fp64
+        grid = "VECTOR_B_GRID"
+        gv = T.vector_grid_vars(grid, shape)
+        fields = [T.random_field(shape, 42), T.random_field(shape, 43)]
         dx = T.grid_dx_min(grid, gv)
         fk = dict(filter_scale=40 * dx, dx_min=dx, filter_shape=FilterShape.GAUSSIAN)
     else:
@@ -218,7 +225,7 @@ def main():
         "dtype": "f64" if itemsize == 8 else "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"BASELINE config {args.config}: {grid} {args.ny}x{args.nx}"
+            "workload": f"{'BASELINE config' if args.config <= 5 else 'extra config'} {args.config}: {grid} {args.ny}x{args.nx}"
                         + (f" x{nbatch} levels" if nbatch > 1 else "") + (f" per GPU, {world} row slabs" if world > 1 and args.scaling == "weak" else ""),
             "filter": f"{fk['filter_shape'].name} filter_scale={fk['filter_scale']:.6g} dx_min={fk['dx_min']:.6g}",
             "n_steps": n_steps,
@@ -238,7 +245,7 @@ def main():
             achieved = b_alg * cells_per_launch * steps_per_launch / (avg_ms * 1e-3) / 1e9
             # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/),
             # valid for the default tuning at N=1 only
-            traffic, kname = None, ("k_cgrid_stream" if grid == "VECTOR_C_GRID" else "k_scalar_multi")
+            traffic, kname = None, {"VECTOR_C_GRID": "k_cgrid_stream", "VECTOR_B_GRID": "k_bgrid_step"}.get(grid, "k_scalar_multi")
             tf = os.path.join(REPO, "profiles", "hbm_traffic.json")
             default_tuning = not (args.multi or args.strip or args.prefetch or args.rows_per_wave or args.xcd_remap >= 0)
             if os.path.exists(tf) and world == 1 and default_tuning:

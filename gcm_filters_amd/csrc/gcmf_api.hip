@@ -82,9 +82,6 @@ int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launche
   }
   MultiArgs mm = m;
   mm.row_hi = blo;
-  if ((rc = launch_scalar_multi(pl, mm, s))) return rc;
-  if (launches) ++*launches;
-
   const size_t ts = dtype_size(pl->d.dtype);
   const size_t plane = align_up((size_t)m.nbatch * rows * g.nx * ts, 256);
   if (pl->band_bytes < 3 * plane) {
@@ -97,11 +94,9 @@ int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launche
   void *E[2] = {pl->band, (char *)pl->band + plane};
   void *Pb = (char *)pl->band + 2 * plane;
   const void *lvl0 = m.u0;
+  bool prep_band = false;
   if (m.first && g.area_weighted) {
-    const void *pin[1] = {m.u0};
-    void *pout[1] = {Pb};
-    if ((rc = launch_prepare(pl, pin, pout, m.nbatch, rows - 2 * S, rows, s))) return rc;
-    if (launches) ++*launches;
+    prep_band = true;
     lvl0 = Pb;
   }
   auto level_buf = [&](int t) -> void * {  // where level t (1..S) of the band lives
@@ -109,7 +104,33 @@ int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launche
     if (t == S - 1 && !m.last) return m.vo;
     return E[t & 1];
   };
+  // Band steps 1..S-1 do not depend on the blocked launch (only step S reads the row just below the band from its
+  // output), so they run on a side stream concurrently with it: they are tiny, latency-bound launches (~6 us
+  // each) that fit beside the one-wave-per-SIMD blocked kernel.  All writes of the two streams are row-disjoint.
+  if (!pl->side) {
+    GCMF_HIP(hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking));
+    GCMF_HIP(hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
+    GCMF_HIP(hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
+  }
+  const int n_early = S - 1;  // steps 1..n_early are independent of the blocked launch
+  GCMF_HIP(hipEventRecord(pl->ev_fork, s));
+  GCMF_HIP(hipStreamWaitEvent(pl->side, pl->ev_fork, 0));
+  if (prep_band) {  // T_0 = field * area for the band rows (the blocked kernel fuses this, single steps do not)
+    const void *pin[1] = {m.u0};
+    void *pout[1] = {Pb};
+    if ((rc = launch_prepare(pl, pin, pout, m.nbatch, rows - 2 * S, rows, n_early >= 1 ? pl->side : s))) return rc;
+    if (launches) ++*launches;
+  }
+  bool main_launched = false;
   for (int t = 1; t <= S; ++t) {
+    hipStream_t ts_ = (t <= n_early) ? pl->side : s;
+    if (t > n_early && !main_launched) {
+      if ((rc = launch_scalar_multi(pl, mm, s))) return rc;
+      if (launches) ++*launches;
+      GCMF_HIP(hipEventRecord(pl->ev_join, pl->side));
+      GCMF_HIP(hipStreamWaitEvent(s, pl->ev_join, 0));
+      main_launched = true;
+    }
     StepArgs a{};
     a.mode = ((m.first && t == 1) ? GCMF_STEP_FIRST : 0u) | ((m.last && t == S) ? GCMF_STEP_LAST : 0u);
     a.coef0 = (m.first && t == 1) ? m.p0 : m.pk[t - 1];
@@ -125,7 +146,7 @@ int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launche
     a.row_lo = (t >= S - 1 && !(t == S - 1 && m.last)) ? blo : rows - 2 * S + t;
     a.row_hi = rows;
     a.fb_lo = blo;
-    if ((rc = launch_scalar_step(pl, a, s))) return rc;
+    if ((rc = launch_scalar_step(pl, a, ts_))) return rc;
     if (launches) ++*launches;
   }
   return GCMF_OK;
@@ -164,6 +185,9 @@ void gcmf_plan_destroy(gcmf_plan *pl) {
   for (void *p : pl->owned) (void)hipFree(p);
   if (pl->work) (void)hipFree(pl->work);
   if (pl->band) (void)hipFree(pl->band);
+  if (pl->side) { (void)hipStreamSynchronize(pl->side); (void)hipStreamDestroy(pl->side); }
+  if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
+  if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
   if (pl->ev0) (void)hipEventDestroy(pl->ev0);
   if (pl->ev1) (void)hipEventDestroy(pl->ev1);
   if (pl->stream) (void)hipStreamDestroy(pl->stream);

@@ -98,6 +98,8 @@ struct gcmf_plan {
   size_t work_bytes = 0;
   void *band = nullptr;  // scratch of the tripole-band single steps that accompany a temporally blocked launch
   size_t band_bytes = 0;
+  hipStream_t side = nullptr;           // the band's early steps run here, concurrently with the blocked launch
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timing = false;
