@@ -190,6 +190,7 @@ void gcmf_plan_destroy(gcmf_plan *pl) {
   if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
   if (pl->ev0) (void)hipEventDestroy(pl->ev0);
   if (pl->ev1) (void)hipEventDestroy(pl->ev1);
+  if (pl->ev_busy) (void)hipEventDestroy(pl->ev_busy);
   if (pl->stream) (void)hipStreamDestroy(pl->stream);
   delete pl;
 }
@@ -281,6 +282,7 @@ int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int 
   PLAN_HIP(hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking));
   PLAN_HIP(hipEventCreate(&pl->ev0));
   PLAN_HIP(hipEventCreate(&pl->ev1));
+  PLAN_HIP(hipEventCreateWithFlags(&pl->ev_busy, hipEventDisableTiming));
 
   // stage the raw grid planes on the device (temporaries), fold them, free the temporaries
   const size_t plane_bytes = (size_t)desc->ny * desc->nx * dtype_size(desc->dtype);
@@ -472,6 +474,9 @@ static int run_whole(gcmf_plan *pl, const double *p, int n_steps, double c, cons
   const size_t oOut = per; if (!on_dev) per += szF;
   int rc = ensure_work(pl, per * nc);
   if (rc) return rc;
+  // the plan's work buffers are shared by all calls: a call enqueued on another stream (dask worker threads with
+  // their own streams) must not start before the previous one has finished with them
+  if (pl->busy_valid) GCMF_HIP(hipStreamWaitEvent(s, pl->ev_busy, 0));
   char *w = (char *)pl->work;
   const void *din[2];
   void *dout[2], *A[2], *B[2], *Cb[2], *Db[2], *F[2], *Pp[2];
@@ -587,6 +592,8 @@ static int run_whole(gcmf_plan *pl, const double *p, int n_steps, double c, cons
     }
   }
   if (pl->timing) GCMF_HIP(hipEventRecord(pl->ev1, s));
+  GCMF_HIP(hipEventRecord(pl->ev_busy, s));
+  pl->busy_valid = true;
   pl->last_launches = launches;
   if (!on_dev) {
     for (int k = 0; k < nc; ++k)

@@ -102,6 +102,8 @@ struct gcmf_plan {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev_busy = nullptr;  // end of the last gcmf_apply that used the plan's work buffers
+  bool busy_valid = false;
   bool timing = false;
   float last_ms = 0.f;
   int last_launches = 0;

@@ -372,3 +372,41 @@ def test_temporal_blocking_bit_identical(grid, shape, dt, S, strip):
     with np.errstate(all="ignore"):
         want = O.filter_func(spec, grid, f, gv)
     assert rel_err(outs[16], want) <= (1e-4 if dt == "f4" else 1e-11)
+
+
+def test_concurrent_calls_from_threads_and_streams():
+    """dask="parallelized" calls filter_func from worker threads: the plan (shared through the cache) must serialise
+    them, also when device-resident inputs arrive on different HIP streams."""
+    import threading
+    import torch
+    f, gv = T.scalar_case("IRREGULAR_WITH_LAND", (96, 160))
+    dx = T.grid_dx_min("IRREGULAR_WITH_LAND", gv)
+    flt = Filter(filter_scale=8 * dx, dx_min=dx, grid_type=GridType.IRREGULAR_WITH_LAND, grid_vars=gv)
+    fields = [T.random_field((3, 96, 160), 50 + k) for k in range(8)]
+    want = [flt.apply(x) for x in fields]
+    got = [None] * len(fields)
+
+    def host_worker(k):
+        got[k] = flt.apply(fields[k])
+
+    th = [threading.Thread(target=host_worker, args=(k,)) for k in range(len(fields))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+
+    dev = [torch.from_numpy(x).cuda() for x in fields]
+    outs = [None] * len(fields)
+
+    def stream_worker(k):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            outs[k] = flt.apply(dev[k])
+        st.synchronize()
+
+    th = [threading.Thread(target=stream_worker, args=(k,)) for k in range(len(fields))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    torch.cuda.synchronize()
+    for g, w in zip(outs, want):
+        assert np.array_equal(g.cpu().numpy(), w)
