@@ -183,8 +183,21 @@ __global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scal
     const T(&gS)[VEC] = G[t - 1][0];
     const T(&gC)[VEC] = G[t - 1][1];
     const T(&gN)[VEC] = G[t - 1][2];
-    const T wv = from_lower_lane(gC[VEC - 1]);
     const T ev = from_upper_lane(gC[0]);
+    // flux form: the west-face flux of a cell IS the east-face flux of its western neighbour (same operands, same
+    // rounding), so every east flux is computed once and the lane's first cell takes its west flux from the
+    // lower lane -- one DPP hop of the flux instead of hops of the value and of the coefficient
+    T fev[VEC], few = T(0), wv = T(0);
+    if (KIND == K_FLUX) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const T xE = (k == VEC - 1) ? ev : gC[k < VEC - 1 ? k + 1 : k];
+        fev[k] = (xE - gC[k]) * cEq[t][k];
+      }
+      few = from_lower_lane(fev[VEC - 1]);
+    } else {
+      wv = from_lower_lane(gC[VEC - 1]);
+    }
     T tkv[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
@@ -207,9 +220,8 @@ __global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scal
         L = L + ((bb & 16u) ? gS[k] : T(0));
         L = (bb & 1u) ? L : T(0);
       } else {
-        const T cw = (k == 0) ? from_lower_lane(cEq[t][VEC - 1]) : cEq[t][k > 0 ? k - 1 : 0];
-        const T fe = (xE - xC) * cEq[t][k];
-        const T fw = (xC - xW) * cw;
+        const T fe = fev[k];
+        const T fw = (k == 0) ? few : fev[k > 0 ? k - 1 : 0];
         const T fn = (gN[k] - xC) * cNq[t][k];
         const T fs = (xC - gS[k]) * cNq[t + 1][k];
         L = (fe - fw + fn - fs) * raq[t][k];

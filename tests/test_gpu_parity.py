@@ -410,3 +410,26 @@ def test_concurrent_calls_from_threads_and_streams():
     torch.cuda.synchronize()
     for g, w in zip(outs, want):
         assert np.array_equal(g.cpu().numpy(), w)
+
+
+@pytest.mark.parametrize("grid", ["IRREGULAR_WITH_LAND", "REGULAR_WITH_LAND", "VECTOR_C_GRID", "VECTOR_B_GRID"])
+def test_out_f32_option(grid):
+    """GCMF_OUT_F32: f32 plans may keep fbar / the output in f32 (opt-in; the default follows NumPy >= 2 and returns
+    f64).  Must agree with the f64-accumulated result to f32 accuracy."""
+    shape = (64, 256)
+    vec = grid in T.VECTOR_GRIDS
+    if vec:
+        fields, gv = T.vector_case(grid, shape)
+    else:
+        f, gv = T.scalar_case(grid, shape)
+        fields = (f,)
+    fields = [x.astype("f4") for x in fields]
+    gv = {k: v.astype("f4") for k, v in gv.items()}
+    dx = T.grid_dx_min(grid, gv) if O.DIMENSIONAL[grid] else 1.0
+    flt = Filter(filter_scale=6.0 * dx, dx_min=dx, grid_type=GridType[grid], grid_vars=gv)
+    lap = ALL_KERNELS[GridType[grid]](*[gv[k] for k in ALL_KERNELS[GridType[grid]].required_grid_args()])
+    ref = lap._run(fields, spec=flt.filter_spec)
+    got = lap._run(fields, spec=flt.filter_spec, out_f32=True)
+    for r, g in zip(ref, got):
+        assert r.dtype == np.float64 and g.dtype == np.float32
+        assert np.abs(g - r).max() <= 2e-5 * np.abs(r).max()
