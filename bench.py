@@ -102,8 +102,9 @@ def cpu_baseline(wl, budget_steps: int):
     dt = time.perf_counter() - t0
     ny, nx = fields[0].shape
     return {"value": ny * nx * n / dt, "unit": "cell-steps/s", "cores": 1, "kind": "port",
-            "sample": f"same {ny}x{nx} grid and field, 1 level, polynomial truncated to n_steps={n} "
-                      f"({dt:.1f} s, numpy {np.__version__}, host has {os.cpu_count()} cores)"}
+            "sample": f"same {ny}x{nx} grid and field, 1 level, "
+                      + ("whole polynomial" if n == full.n_steps else f"polynomial truncated to n_steps={n}")
+                      + f" (n_steps={n}, {dt:.1f} s, numpy {np.__version__}, host has {os.cpu_count()} cores)"}
 
 
 def main():
