@@ -146,6 +146,7 @@ class SlabFilter:
         self.exchanges = 0
         self.time_kernels = False  # bench.py: bracket every step launch with events on the launch stream
         self.multi_depth = 8       # most recurrence steps fused per HBM pass (1 = single steps only)
+        self.overlap = True        # overlap the halo exchange with the interior rows of the last launch of a cycle
 
     # -- data movement helpers -----------------------------------------------------------------
     def scatter_from_global(self, fields: Sequence[np.ndarray]):
@@ -198,8 +199,13 @@ class SlabFilter:
 
     def _exchange(self, tensors: List):
         """Refresh all `halo` ghost rows of every tensor in `tensors` (each (ncomp, nbatch, rows_alloc, nx))."""
+        self._exchange_finish(self._exchange_start(tensors))
+
+    def _exchange_start(self, tensors: List):
+        """Pack the boundary rows and post the sends / receives; returns a ticket for ``_exchange_finish``.  Work
+        enqueued on the compute stream AFTER this call (the interior of the slab) overlaps with the transfer."""
         if self.world == 1 or (self.south is None and self.north is None):
-            return
+            return None
         t, dist = self.torch, self.dist
         s, fo, ro = self.halo, self.first_owned, self.rows_owned
         top = [x[:, :, fo + ro - s: fo + ro, :] for x in tensors]      # -> northern neighbour's south ghosts
@@ -238,7 +244,14 @@ class SlabFilter:
                    else self._xbuf(("r", peer, n), n, parts[0]))
             ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(peer), group=self.group))
             unpack.append((buf, parts))
-        for w in dist.batch_isend_irecv(ops):
+        works = dist.batch_isend_irecv(ops)
+        return works, unpack, stage
+
+    def _exchange_finish(self, ticket):
+        if ticket is None:
+            return
+        works, unpack, stage = ticket
+        for w in works:
             w.wait()
         for buf, parts in unpack:
             off = 0
@@ -301,8 +314,23 @@ class SlabFilter:
                 e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
                 e0.record()
             if S >= 2:
-                self.engine.multi(u[0], None if v is None else v[0], free[0][0], free[1][0], F[0],
-                                  O[0] if is_last else F[0], p[k: k + S], p[0], self.c, mode, nbatch, lo, hi)
+                args = (u[0], None if v is None else v[0], free[0][0], free[1][0], F[0], O[0] if is_last else F[0],
+                        p[k: k + S], p[0], self.c, mode, nbatch)
+                overlap = (self.overlap and self.world > 1 and v_out == 0 and not is_last and ro >= 4 * s
+                           and self.engine.multi_supported(S))
+                if overlap:
+                    # this launch uses up the ghost zone: advance the rows the neighbours need first, post the halo
+                    # exchange of the NEW states, and let the interior rows run while the messages are in flight
+                    if self.gs:
+                        self.engine.multi(*args, lo, lo + s)
+                    if self.gn:
+                        self.engine.multi(*args, hi - s, hi)
+                    pending = self._exchange_start([free[0], free[1]])
+                    self.engine.multi(*args, lo + (s if self.gs else 0), hi - (s if self.gn else 0))
+                    self._exchange_finish(pending)
+                    v_out = s
+                else:
+                    self.engine.multi(*args, lo, hi)
                 u, v = free[0], free[1]
             else:
                 if k == 1 and self.area_weighted and not prepared:

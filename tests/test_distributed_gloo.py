@@ -32,6 +32,11 @@ CASES = [
     ("MOM5U", (24, 16), 2, 1),
     ("VECTOR_C_GRID", (24, 16), 3, 1),
     ("VECTOR_B_GRID", (23, 16), 2, 2),
+    # slabs tall enough (rows_owned >= 4 halo) for the overlapped exchange: edge rows first, interior during the transfer
+    ("IRREGULAR_WITH_LAND", (66, 16), 2, 1),
+    ("REGULAR_WITH_LAND_AREA_WEIGHTED", (72, 16), 4, 2),
+    ("TRIPOLAR_POP_WITH_LAND", (96, 16), 4, 1),
+    ("TRIPOLAR_REGULAR_WITH_LAND_AREA_WEIGHTED", (100, 16), 3, 1),
 ]
 
 
