@@ -85,14 +85,19 @@ __device__ __forceinline__ void cheb_update_pre(const VecP<T, FB> &P, int comp, 
   P.fb_out[comp][off] = fb;
 }
 
-__device__ __forceinline__ int wrapx(int i, int nx) { return i < 0 ? i + nx : (i >= nx ? i - nx : i); }
+// periodic column index.  Tile points far outside a narrow grid (nx smaller than the tile) are never used, but
+// their loads must still stay inside the plane: clamp after the single wrap.
+__device__ __forceinline__ int wrapx(int i, int nx) {
+  i = i < 0 ? i + nx : (i >= nx ? i - nx : i);
+  return i < 0 ? 0 : (i >= nx ? nx - 1 : i);
+}
 
 // row index inside the slab allocation: periodic wrap for a single slab, clamp otherwise (clamped rows are
 // only ever read for tile points whose results are not used)
 __device__ __forceinline__ int slab_row(int j, int rows, int south_wrap, int north_wrap) {
-  if (j < 0) return south_wrap ? j + rows : 0;
-  if (j >= rows) return north_wrap ? j - rows : rows - 1;
-  return j;
+  if (j < 0) j = south_wrap ? j + rows : 0;
+  else if (j >= rows) j = north_wrap ? j - rows : rows - 1;
+  return j < 0 ? 0 : (j >= rows ? rows - 1 : j);  // grids shorter than a tile: keep unused tile points in bounds
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -13,10 +13,15 @@ t0 = time.time()
 for it in range(ncase):
     grid = T.ALL_GRIDS[rng.integers(len(T.ALL_GRIDS))]
     vec = grid in T.VECTOR_GRIDS
-    ny = int(rng.integers(3, 200)); nx = int(rng.integers(2, 700))
+    if "--tiny" in sys.argv:
+        ny = int(rng.integers(1, 14)); nx = int(rng.integers(1, 14))
+    else:
+        ny = int(rng.integers(3, 200)); nx = int(rng.integers(2, 700))
     if grid.startswith("TRIPOLAR"):
         nx += nx % 2; ny = max(ny, 4)
     if rng.random() < 0.5: nx = (nx // 4 + 1) * 4      # vector-width friendly half of the time
+    if grid.startswith("TRIPOLAR"):
+        nx += nx % 2; ny = max(ny, 2)
     shape = (ny, nx)
     dt = "f8" if rng.random() < 0.7 else "f4"
     nb = () if rng.random() < 0.6 else (int(rng.integers(1, 4)),) if rng.random() < 0.7 else (2, int(rng.integers(1, 3)))
@@ -34,6 +39,8 @@ for it in range(ncase):
     shp = "GAUSSIAN" if rng.random() < 0.5 else "TAPER"
     n_steps = int(rng.integers(3, 40))
     scale = float(rng.uniform(1.5, 6.0)) * dx
+    if "-v" in sys.argv:
+        print("CASE", it, grid, shape, dt, nb, shp, n_steps, round(scale / dx, 3), flush=True)
     try:
         import warnings
         with warnings.catch_warnings():
