@@ -246,7 +246,7 @@ def main():
             achieved = b_alg * cells_per_launch * steps_per_launch / (avg_ms * 1e-3) / 1e9
             # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/),
             # valid for the default tuning at N=1 only
-            traffic, kname = None, {"VECTOR_C_GRID": "k_cgrid_stream", "VECTOR_B_GRID": "k_bgrid_step"}.get(grid, "k_scalar_multi")
+            traffic, kname = None, {"VECTOR_C_GRID": "k_cgrid_stream", "VECTOR_B_GRID": "k_bgrid_stream"}.get(grid, "k_scalar_multi")
             tf = os.path.join(REPO, "profiles", "hbm_traffic.json")
             default_tuning = not (args.multi or args.strip or args.prefetch or args.rows_per_wave or args.xcd_remap >= 0)
             if os.path.exists(tf) and world == 1 and default_tuning:

@@ -124,6 +124,8 @@ int launch_vector_step(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 int launch_scalar_multi(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_cgrid_stream(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 bool cgrid_stream_supported(const gcmf_plan *pl, const StepArgs &a);
+int launch_bgrid_stream(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
+bool bgrid_stream_supported(const gcmf_plan *pl, const StepArgs &a);
 bool multi_supported(const gcmf_plan *pl, int S);
 // S fused steps on rows [row_lo,row_hi) incl. the tripole band when the range ends at the fold row (gcmf_api.hip)
 int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launches);

@@ -250,6 +250,7 @@ template <typename T, typename FB> static int launch_vec(gcmf_plan *pl, const St
   if (nrows <= 0 || a.nbatch <= 0) return GCMF_OK;
   dim3 block(64, 4, 1);
   if (pl->kind == K_CGRID && !pl->cgrid_tile && cgrid_stream_supported(pl, a)) return launch_cgrid_stream(pl, a, s);
+  if (pl->kind == K_BGRID && !pl->cgrid_tile && bgrid_stream_supported(pl, a)) return launch_bgrid_stream(pl, a, s);
   if (pl->kind == K_CGRID) {
     const int ntx = (g.nx + CT_I - 1) / CT_I, nty = (nrows + CT_J - 1) / CT_J;
     const int ntiles = ntx * nty;
