@@ -22,6 +22,10 @@
 // gcmf_scalar.hip for the per-kind citations).
 #include "gcmf_multi_common.hpp"
 
+#ifndef GCMF_NO_SKIP
+#define GCMF_NO_SKIP 0
+#endif
+
 namespace gcmf {
 
 // resident waves per SIMD the register budget allows: the flux form carries 3 coefficient lag windows and fits two
@@ -175,7 +179,6 @@ __global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scal
     }
   };
 
-  // ---- part 2: levels 1..S (level t produces row r-t), stores, window rotation ----
   // one level.  FLAGGED=false is the common case "no NaN/inf anywhere in this wave's windows": raw == sanitised.
   auto level = [&](auto tt, auto flagged_c) {
     constexpr int t = decltype(tt)::value;
@@ -266,15 +269,19 @@ __global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scal
     }
   };
 
-  auto level_all = [&](auto flagged_c) {
-    level(std::integral_constant<int, 1>{}, flagged_c);
-    if constexpr (S >= 2) level(std::integral_constant<int, 2>{}, flagged_c);
-    if constexpr (S >= 3) level(std::integral_constant<int, 3>{}, flagged_c);
-    if constexpr (S >= 4) level(std::integral_constant<int, 4>{}, flagged_c);
-    if constexpr (S >= 5) level(std::integral_constant<int, 5>{}, flagged_c);
-    if constexpr (S >= 6) level(std::integral_constant<int, 6>{}, flagged_c);
-    if constexpr (S >= 7) level(std::integral_constant<int, 7>{}, flagged_c);
-    if constexpr (S >= 8) level(std::integral_constant<int, 8>{}, flagged_c);
+  // Only the trapezoid of (level, row) pairs that can reach an output row of this strip is evaluated: level t
+  // matters on rows [a-S+t, b+S-t).  The skipped corners (warm-up / drain iterations) are ~10 % of the
+  // level-iterations at S=8.  The test is wave-uniform (scalar branch) -- but the branches also fence the
+  // compiler's cross-level scheduling, which the one-wave-per-SIMD flux kernel needs more than it needs the saved
+  // work (measured 330 -> 304 G with skipping), so it is enabled only where two waves share a SIMD.
+  constexpr bool SKIP = (WavesPerSimd<T, KIND, S>::value == 2) && !GCMF_NO_SKIP;
+  auto level_all = [&](auto flagged_c, int r) {
+#define GCMF_LEVEL(t_)                                                                           \
+  if constexpr (S >= (t_)) {                                                                     \
+    if (!SKIP || (r - (t_) >= a - S + (t_) && r - (t_) < b + S - (t_))) level(std::integral_constant<int, (t_)>{}, flagged_c); \
+  }
+    GCMF_LEVEL(1) GCMF_LEVEL(2) GCMF_LEVEL(3) GCMF_LEVEL(4) GCMF_LEVEL(5) GCMF_LEVEL(6) GCMF_LEVEL(7) GCMF_LEVEL(8)
+#undef GCMF_LEVEL
   };
 
   // ---- part 2: levels 1..S (level t produces row r-t), stores, window rotation ----
@@ -283,9 +290,9 @@ __global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scal
 #pragma unroll
     for (int t = 0; t < S; ++t) anyf |= Rf[t];
     if (SAN && __any(anyf != 0u)) {
-      level_all(std::true_type{});
+      level_all(std::true_type{}, r);
     } else {
-      level_all(std::false_type{});
+      level_all(std::false_type{}, r);
     }
 
     // stores: T_{k-1+S} row r-S, T_{k-2+S} row r-S+1, fbar row r-S
