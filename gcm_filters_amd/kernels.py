@@ -50,6 +50,10 @@ def _unwrap(x):
     """xarray.DataArray / Variable -> its array; everything else unchanged."""
     if _is_torch(x) or isinstance(x, np.ndarray):
         return x
+    if hasattr(x, "__cuda_array_interface__") or (hasattr(x, "__dlpack__") and not hasattr(x, "dims")):
+        # other device-array libraries (the reference's cupy path, gpu_compat.py:5-10): zero-copy via DLPack
+        import torch
+        return torch.from_dlpack(x)
     data = getattr(x, "data", None)
     if data is not None and hasattr(x, "dims"):
         return data if (_is_torch(data) or isinstance(data, np.ndarray)) else np.asarray(data)
