@@ -199,7 +199,7 @@ def _xarray():
 
 
 def _is_bare_array(x) -> bool:
-    return isinstance(x, np.ndarray) or _is_torch(x)
+    return isinstance(x, np.ndarray) or _is_torch(x) or hasattr(x, "__cuda_array_interface__")
 
 
 @dataclass
