@@ -463,11 +463,12 @@ static int run_whole(gcmf_plan *pl, const double *p, int n_steps, double c, cons
   // work layout per component: [A][B][fbar] (+ [prepared T0]) (+ host staging: [in][out])
   const size_t szT = align_up(ncell * ts, 256), szF = align_up(ncell * fbs, 256);
   const bool use_multi = !lapl_only && pl->multi_s >= 2 && n_steps >= 2 && multi_supported(pl, 2);
+  const bool use_pair = !lapl_only && pl->multi_s >= 2 && n_steps >= 2 && cgrid_multi_supported(pl, nbatch, 2);
   size_t per = 0;
   const size_t oA = per; per += szT;
   const size_t oB = per; per += szT;
-  const size_t oC = per; if (use_multi) per += szT;
-  const size_t oD = per; if (use_multi) per += szT;
+  const size_t oC = per; if (use_multi || use_pair) per += szT;
+  const size_t oD = per; if (use_multi || use_pair) per += szT;
   const size_t oF = per; per += szF;
   const size_t oP = per; if (prep) per += szT;
   const size_t oIn = per; if (!on_dev) per += szT;
@@ -559,6 +560,53 @@ static int run_whole(gcmf_plan *pl, const double *p, int n_steps, double c, cons
         }
         ++launches;
         k += S;
+      }
+    } else if (use_pair) {
+      // C-grid: S = 2..4 steps per pass, (T_{k-1}, T_{k-2}) -> (T_{k+S-2}, T_{k+S-1}).  Neither output may overwrite
+      // T_{k-2}: the halo rows / columns a strip recomputes need its neighbours' T_{k-2}.  The state rotates through
+      // four buffers.  A lone last step runs the single-step kernel.
+      const void *u[2] = {x0[0], x0[1]}, *v[2] = {nullptr, nullptr};
+      int k = 1;
+      while (k <= n_steps) {
+        const int left = n_steps - k + 1;
+        void *pool[4][2] = {{A[0], A[1]}, {B[0], B[1]}, {Cb[0], Cb[1]}, {Db[0], Db[1]}};
+        void *fr[2][2];
+        int nf = 0;
+        for (int q = 0; q < 4 && nf < 2; ++q)
+          if (pool[q][0] != u[0] && pool[q][0] != v[0]) { fr[nf][0] = pool[q][0]; fr[nf][1] = pool[q][1]; ++nf; }
+        int S = 1;
+        const int cand[3] = {4, 3, 2};
+        for (int q = 0; q < 3; ++q)  // largest depth that does not strand a lone single step at the end
+          if (cand[q] <= left && left - cand[q] != 1 && cand[q] <= pl->multi_s && cgrid_multi_supported(pl, nbatch, cand[q])) {
+            S = cand[q];
+            break;
+          }
+        if (S == 1 && left >= 2) S = 2;
+        if (S >= 2) {
+          const bool is_last = (k + S - 1 == n_steps);
+          VecMultiArgs m{};
+          for (int q = 0; q < 2; ++q) {
+            m.u0[q] = u[q]; m.uprev[q] = v[q]; m.u1o[q] = fr[0][q]; m.u2o[q] = fr[1][q];
+            m.fb_in[q] = F[q]; m.fb_out[q] = is_last ? dout[q] : F[q];
+          }
+          for (int t = 0; t < S; ++t) m.pk[t] = p[k + t];
+          m.p0 = p[0]; m.c = c; m.S = S;
+          m.first = (k == 1); m.last = is_last; m.fb_is_f32 = fb32; m.nbatch = nbatch; m.row_lo = 0; m.row_hi = rows;
+          if ((rc = launch_cgrid_multi(pl, m, s))) return rc;
+          for (int q = 0; q < 2; ++q) { u[q] = fr[1][q]; v[q] = fr[0][q]; }
+          k += S;
+        } else {
+          StepArgs a1{};
+          a1.mode = (k == 1 ? GCMF_STEP_FIRST : 0u) | GCMF_STEP_LAST;
+          a1.coef0 = (k == 1) ? p[0] : p[k]; a1.coef1 = p[1]; a1.c = c; a1.fb_is_f32 = fb32; a1.nbatch = nbatch;
+          a1.row_lo = 0; a1.row_hi = rows;
+          for (int q = 0; q < 2; ++q) {
+            a1.t1[q] = u[q]; a1.t2[q] = v[q]; a1.t0[q] = fr[0][q]; a1.fb_in[q] = F[q]; a1.fb_out[q] = dout[q];
+          }
+          if ((rc = step_dispatch(pl, a1, s))) return rc;
+          k += 1;
+        }
+        ++launches;
       }
     } else {
     if (prep) {  // T_0 = field * area

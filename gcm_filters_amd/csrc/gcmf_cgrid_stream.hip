@@ -91,7 +91,12 @@ __global__ __launch_bounds__(256, 2) void k_cgrid_stream(const CStreamP<T, FB> P
     FB fu[VEC], fv[VEC];                                          // row r-1
     T share[4][VEC];                                              // SHARED: planes wv, wv+4, wv+8, wv+12 of this row
   };
-  const int wv = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // this wave's coefficient planes, resolved once: indexing the kernel argument inside the row loop costs a
+  // dependent memory load plus a full vmcnt(0) drain per plane and row
+  const T *cp[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) cp[q] = P.coef[wv + 4 * q < 14 ? wv + 4 * q : 0];
   auto row_index = [&](int r) {
     if (P.wrap) return r < 0 ? r + rows : (r >= rows ? r - rows : r);
     return r < 0 ? 0 : (r >= rows ? rows - 1 : r);
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void k_cgrid_stream(const CStreamP<T, FB> P
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int pidx = wv + 4 * q;  // planes 0..6 belong to row r, 7..13 to row r-1
-        if (pidx < 14) mload<T, VEC>(x.share[q], P.coef[pidx] + (pidx < 7 ? ro : rc));
+        if (pidx < 14) mload<T, VEC>(x.share[q], cp[q] + (pidx < 7 ? ro : rc));
       }
       return;
     }

@@ -1,0 +1,366 @@
+// Streaming C-grid kernel, S Chebyshev steps per pass over HBM (temporal blocking for the vector path).
+//
+// Same wave-march / lock-step / LDS-shared-coefficient structure as k_cgrid_stream (gcmf_cgrid_stream.hip), with S
+// levels riding one row behind each other, all in registers:
+//   iteration r (row r of T_{k-1} delivered, coefficient rows A_r = planes 0..6 at row r, B_{r-1} = planes 7..13 at
+//   row r-1 exchanged through LDS):
+//     level j = 1..S:  T_{k-1+j} row r-j  from T_{k-2+j} rows r-j-1..r-j+1, with the coefficient rows A_{r-j+1},
+//                      B_{r-j}, i.e. the LDS slot filled j-1 iterations ago
+// so the LDS coefficient ring has S+1 slots (S readable, one being refilled) and one barrier per row.  A pass reads
+// T_{k-1}, T_{k-2}, fbar and (once per four levels) the 14 coefficient planes and writes T_{k+S-1}, T_{k+S-2}, fbar:
+// 4w + 2f + 14w/4 + 4w + 2f bytes per cell.level whatever S is (78 B with f32 state and f64 fbar; 65 B for S = 1).
+// Arithmetic per level is the single-step kernel's: bit-identical results.
+#include "gcmf_multi_common.hpp"
+
+namespace gcmf {
+
+template <typename T, typename FB> struct CStream2P {
+  const T *u0, *v0;          // T_{k-1}
+  const T *up, *vp;          // T_{k-2}      (unused when first)
+  const FB *fu_in, *fv_in;   //              (unused when first)
+  T *u1o, *v1o;              // T_{k+S-2} out (unused when last)
+  T *u2o, *v2o;              // T_{k+S-1} out (unused when last)
+  FB *fu_out, *fv_out;
+  const T *coef[MAX_COEF];
+  int nx, rows, out_lo, out_hi;
+  int H, nwx, ngroups, nlev, nlev4, wrap, first, last;
+  long long bstride;
+  double p0, pk[4], c;
+};
+
+template <typename T> __device__ __forceinline__ T c2san(T x) {
+  const bool isn = (x != x);
+  const bool big = (mabs(x) > MLim<T>::big());
+  const T clamped = big ? (x > T(0) ? MLim<T>::big() : -MLim<T>::big()) : x;
+  return isn ? T(0) : clamped;
+}
+
+// state machine of one level of the C-grid operator: feed it row r, get L_u, L_v of row r-1
+template <typename T, int VEC> struct CgLevel {
+  T vt_p[VEC], vh_p[VEC], uh_p[VEC], P_p[VEC], Q_p[VEC], R_pp[VEC];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) vt_p[k] = vh_p[k] = uh_p[k] = P_p[k] = Q_p[k] = R_pp[k] = T(0);
+  }
+  // cA: rdyCu, rdxCu, rdxCv, rdyCv, a1, a2, rh of the fed row;  cB: b1, b2, rq, cu1, cu2, cv1, cv2 of the row before
+  __device__ __forceinline__ void feed(const T (&su)[VEC], const T (&sv)[VEC], const T (&cA)[7][VEC], const T (&cB)[7][VEC],
+                                       T (&lu)[VEC], T (&lv)[VEC]) {
+    T ut[VEC], uh[VEC], vt[VEC], vh[VEC], Pr[VEC], Qr[VEC], Rm[VEC], Sm[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      ut[k] = su[k] * cA[0][k];
+      uh[k] = su[k] * cA[1][k];
+      vt[k] = sv[k] * cA[2][k];
+      vh[k] = sv[k] * cA[3][k];
+    }
+    const T ut_w = from_lower_lane(ut[VEC - 1]);
+    const T vh_e = from_upper_lane(vh_p[0]);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const T utw = (k == 0) ? ut_w : ut[k > 0 ? k - 1 : 0];
+      Pr[k] = cA[4][k] * (ut[k] - utw) - cA[5][k] * (vt[k] - vt_p[k]);
+      Qr[k] = cA[6][k] * Pr[k];
+      const T vhe = (k == VEC - 1) ? vh_e : vh_p[k < VEC - 1 ? k + 1 : k];
+      Rm[k] = cB[0][k] * (vhe - vh_p[k]) + cB[1][k] * (uh[k] - uh_p[k]);
+      Sm[k] = cB[2][k] * Rm[k];
+    }
+    const T P_e = from_upper_lane(P_p[0]);
+    const T S_w = from_lower_lane(Sm[VEC - 1]);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const T pe = (k == VEC - 1) ? P_e : P_p[k < VEC - 1 ? k + 1 : k];
+      const T sw = (k == 0) ? S_w : Sm[k > 0 ? k - 1 : 0];
+      lu[k] = cB[3][k] * (P_p[k] - pe) + cB[4][k] * (R_pp[k] - Rm[k]);
+      lv[k] = cB[5][k] * (sw - Sm[k]) - cB[6][k] * (Q_p[k] - Qr[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      vt_p[k] = vt[k];
+      vh_p[k] = vh[k];
+      uh_p[k] = uh[k];
+      P_p[k] = Pr[k];
+      Q_p[k] = Qr[k];
+      R_pp[k] = Rm[k];
+    }
+  }
+};
+
+template <typename T, typename FB, int VEC, int S, int D>
+__global__ __launch_bounds__(256, 2) void k_cgrid_stream2(const CStream2P<T, FB> P) {
+  constexpr int M = (S + VEC - 1) / VEC * VEC;  // level j is stale j cells per side; windows start on a VEC boundary
+  constexpr int W = 64 * VEC, WI = W - 2 * M;
+  constexpr int NS = S + 1;
+  __shared__ MPack<T, VEC> s_coef[NS][14][64];
+
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int blk = blockIdx.x;
+  const int xcd = blk & 7, slot = (blk >> 3) * 4 + wv;
+  const int group = (slot / P.nlev4) * 8 + xcd;
+  int lev = slot % P.nlev4;
+  if (group >= P.ngroups) return;  // whole workgroups exit together
+  const bool shadow = lev >= P.nlev;
+  if (shadow) lev = P.nlev - 1;
+  const int wx = group % P.nwx, st = group / P.nwx;
+  const int nx = P.nx, rows = P.rows;
+  const int a = P.out_lo + st * P.H;
+  const int b = min(a + P.H, P.out_hi);
+  const long long boff = (long long)lev * P.bstride;
+  const int pos = wx * WI - M + lane * VEC;
+  int col = pos % nx;
+  if (col < 0) col += nx;
+  const bool keep = (lane * VEC >= M) && (lane * VEC < W - M) && (pos < nx) && !shadow;
+  const T c = (T)P.c;
+  const bool first = P.first, last = P.last;
+
+  struct Row {
+    T u[VEC], v[VEC];      // T_{k-1} row r
+    T up[VEC], vp[VEC];    // T_{k-2} row r-1
+    FB fu[VEC], fv[VEC];   // fbar    row r-1
+    T share[4][VEC];       // this wave's quarter of the coefficient rows (planes wv, wv+4, wv+8, wv+12)
+  };
+  // this wave's coefficient planes, resolved once: indexing the kernel argument inside the row loop costs a
+  // dependent memory load plus a full vmcnt(0) drain per plane and row
+  const T *cp[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) cp[q] = P.coef[wv + 4 * q < 14 ? wv + 4 * q : 0];
+  auto row_index = [&](int r) {
+    if (P.wrap) {
+      r = r < 0 ? r + rows : (r >= rows ? r - rows : r);
+      return r < 0 ? r + rows : (r >= rows ? r - rows : r);  // |overshoot| <= S + 1 may exceed one period on tiny grids
+    }
+    return r < 0 ? 0 : (r >= rows ? rows - 1 : r);
+  };
+  auto load_row = [&](Row &x, int r) {
+    const long long ro = (long long)row_index(r) * nx + col;
+    const long long rc = (long long)row_index(r - 1) * nx + col;
+    mload<T, VEC>(x.u, P.u0 + boff + ro);
+    mload<T, VEC>(x.v, P.v0 + boff + ro);
+    if (!first) {
+      mload<T, VEC>(x.up, P.up + boff + rc);
+      mload<T, VEC>(x.vp, P.vp + boff + rc);
+      mload<FB, VEC>(x.fu, P.fu_in + boff + rc);
+      mload<FB, VEC>(x.fv, P.fv_in + boff + rc);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int pidx = wv + 4 * q;
+      if (pidx < 14) mload<T, VEC>(x.share[q], cp[q] + (pidx < 7 ? ro : rc));
+    }
+  };
+
+  // Level j (1..S) consumes the output of level j-1 (level 0 = the delivered T_{k-1}):
+  //   fed with its newest row, "-x" is its row of one iteration ago (o1), "-T_{k-2}" is level j-2's row of two
+  //   iterations ago (o2; for level 1 the lagged T_{k-2} load).  fbar after level j waits one iteration for level j+1.
+  CgLevel<T, VEC> L[S];
+  T o1u[S][VEC], o1v[S][VEC], o2u[S][VEC], o2v[S][VEC];
+  FB accu[S][VEC], accv[S][VEC];
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    L[j].init();
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      o1u[j][k] = o1v[j][k] = o2u[j][k] = o2v[j][k] = T(0);
+      accu[j][k] = accv[j][k] = FB(0);
+    }
+  }
+  int cur = 0;  // LDS ring slot of this iteration
+
+  auto step = [&](Row &x, int r) {
+    // ---- exchange the coefficient rows of this iteration through LDS ----
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int pidx = wv + 4 * q;
+      if (pidx < 14) {
+        MPack<T, VEC> pk;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) pk.s[k] = x.share[q][k];
+        s_coef[cur][pidx][lane] = pk;
+      }
+    }
+    __syncthreads();
+
+    T cu[S + 1][VEC], cv[S + 1][VEC];  // newest row of every level this iteration
+    FB nau[S + 1][VEC], nav[S + 1][VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { cu[0][k] = x.u[k]; cv[0][k] = x.v[k]; }
+
+#pragma unroll
+    for (int j = 1; j <= S; ++j) {
+      int sl = cur - (j - 1);
+      if (sl < 0) sl += NS;
+      T cA[7][VEC], cB[7][VEC];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        const MPack<T, VEC> pa = s_coef[sl][q][lane];
+        const MPack<T, VEC> pb = s_coef[sl][7 + q][lane];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) { cA[q][k] = pa.s[k]; cB[q][k] = pb.s[k]; }
+      }
+      T su[VEC], sv[VEC], lu[VEC], lv[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) { su[k] = c2san(cu[j - 1][k]); sv[k] = c2san(cv[j - 1][k]); }
+      L[j - 1].feed(su, sv, cA, cB, lu, lv);
+      const double pkj = P.pk[j - 1];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const T xu = o1u[j - 1][k], xv = o1v[j - 1][k];
+        const T avu = -xu - c * lu[k], avv = -xv - c * lv[k];
+        if (j == 1 && first) {
+          cu[j][k] = avu;
+          cv[j][k] = avv;
+          if (std::is_same<FB, T>::value) {
+            nau[j][k] = (FB)((T)P.p0 * xu + (T)pkj * avu);
+            nav[j][k] = (FB)((T)P.p0 * xv + (T)pkj * avv);
+          } else {
+            nau[j][k] = (FB)(P.p0 * (double)xu + pkj * (double)avu);
+            nav[j][k] = (FB)(P.p0 * (double)xv + pkj * (double)avv);
+          }
+        } else {
+          const T x2u = (j == 1) ? x.up[k] : o2u[j >= 2 ? j - 2 : 0][k];
+          const T x2v = (j == 1) ? x.vp[k] : o2v[j >= 2 ? j - 2 : 0][k];
+          const FB fiu = (j == 1) ? x.fu[k] : accu[j - 1][k];
+          const FB fiv = (j == 1) ? x.fv[k] : accv[j - 1][k];
+          cu[j][k] = T(2) * avu - x2u;
+          cv[j][k] = T(2) * avv - x2v;
+          if (std::is_same<FB, T>::value) {
+            nau[j][k] = fiu + (FB)((T)pkj * cu[j][k]);
+            nav[j][k] = fiv + (FB)((T)pkj * cv[j][k]);
+          } else {
+            nau[j][k] = fiu + (FB)(pkj * (double)cu[j][k]);
+            nav[j][k] = fiv + (FB)(pkj * (double)cv[j][k]);
+          }
+        }
+      }
+      if (j >= S - 1 && keep && r - j >= a && r - j < b) {
+        const long long off = boff + (long long)(r - j) * nx + col;
+        if (!last) {
+          mstore<T, VEC>((j == S ? P.u2o : P.u1o) + off, cu[j]);
+          mstore<T, VEC>((j == S ? P.v2o : P.v1o) + off, cv[j]);
+        }
+        if (j == S) {
+          mstore<FB, VEC>(P.fu_out + off, nau[j]);
+          mstore<FB, VEC>(P.fv_out + off, nav[j]);
+        }
+      }
+    }
+
+    // ---- rotate ----
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        o2u[j][k] = o1u[j][k];
+        o2v[j][k] = o1v[j][k];
+        o1u[j][k] = cu[j][k];
+        o1v[j][k] = cv[j][k];
+        if (j >= 1) { accu[j][k] = nau[j][k]; accv[j][k] = nav[j][k]; }
+      }
+    }
+    cur = (cur + 1 == NS) ? 0 : cur + 1;
+  };
+
+  const int r_begin = a - S, r_end = b + S;  // rows delivered: [a-S, b+S-1]
+  if (D == 1) {  // one row of operands in flight per wave; the other waves of the SIMD hide the rest of the latency
+    Row nxt;
+    load_row(nxt, r_begin);
+    for (int r = r_begin; r < r_end; ++r) {
+      Row now = nxt;
+      load_row(nxt, min(r + 1, r_end - 1));
+      step(now, r);
+    }
+  } else {  // two rows in flight
+    Row q0, q1;
+    load_row(q0, r_begin);
+    load_row(q1, min(r_begin + 1, r_end - 1));
+    for (int r = r_begin; r < r_end; r += 2) {
+      {
+        Row now = q0;
+        load_row(q0, min(r + 2, r_end - 1));
+        step(now, r);
+      }
+      if (r + 1 < r_end) {
+        Row now = q1;
+        load_row(q1, min(r + 3, r_end - 1));
+        step(now, r + 1);
+      }
+    }
+  }
+}
+
+static bool c2al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+bool cgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
+  if (pl->kind != K_CGRID || pl->cgrid_tile) return false;
+  if (S < 2 || S > (pl->d.dtype == GCMF_F64 ? 2 : 4)) return false;  // f64: more levels would spill registers
+  const int vec = pl->d.dtype == GCMF_F64 ? 2 : 4;
+  if (pl->g.nx % vec || pl->g.nx < vec || pl->g.rows < S + 2) return false;
+  const int64_t nlev4 = (nbatch + 3) / 4 * 4;
+  if (nlev4 * 10 > nbatch * 11) return false;  // needs lock-step workgroups of 4 levels (see k_cgrid_stream)
+  for (int k = 0; k < MAX_COEF; ++k)
+    if (!c2al16(pl->g.coef[k])) return false;
+  return true;
+}
+
+template <typename T, typename FB, int VEC, int S, int D> static int launch_c2(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
+  constexpr int M = (S + VEC - 1) / VEC * VEC, W = 64 * VEC, WI = W - 2 * M;
+  const Geom &g = pl->g;
+  CStream2P<T, FB> P;
+  P.u0 = (const T *)a.u0[0];  P.v0 = (const T *)a.u0[1];
+  P.up = (const T *)a.uprev[0];  P.vp = (const T *)a.uprev[1];
+  P.fu_in = (const FB *)a.fb_in[0];  P.fv_in = (const FB *)a.fb_in[1];
+  P.u1o = (T *)a.u1o[0];  P.v1o = (T *)a.u1o[1];
+  P.u2o = (T *)a.u2o[0];  P.v2o = (T *)a.u2o[1];
+  P.fu_out = (FB *)a.fb_out[0];  P.fv_out = (FB *)a.fb_out[1];
+  for (int k = 0; k < MAX_COEF; ++k) P.coef[k] = (const T *)g.coef[k];
+  P.nx = g.nx;
+  P.rows = g.rows;
+  P.out_lo = a.row_lo;
+  P.out_hi = a.row_hi;
+  const int nrows = a.row_hi - a.row_lo;
+  if (nrows <= 0 || a.nbatch <= 0) return GCMF_OK;
+  P.nwx = (g.nx + WI - 1) / WI;
+  P.nlev = (int)a.nbatch;
+  P.nlev4 = (P.nlev + 3) / 4 * 4;
+  int H = pl->strip_rows;
+  if (H <= 0) {
+    long long want = 2048 / ((long long)P.nwx * a.nbatch);
+    if (want < 1) want = 1;
+    H = (int)((nrows + want - 1) / want);
+    if (H > 96) H = 96;  // (H + 4) / H rows are marched per strip: 4 % redundancy, measured best on config 5
+    if (H < 16) H = 16;
+  }
+  if (H > nrows) H = nrows;
+  P.H = H;
+  P.ngroups = P.nwx * ((nrows + H - 1) / H);
+  P.wrap = g.south_wrap && g.north_wrap;
+  P.first = a.first;
+  P.last = a.last;
+  P.bstride = (long long)g.rows * g.nx;
+  P.p0 = a.p0;
+  for (int t = 0; t < 4; ++t) P.pk[t] = a.pk[t];
+  P.c = a.c;
+  const long long groups_per_xcd = (P.ngroups + 7) / 8;
+  const long long blocks_per_xcd = (groups_per_xcd * P.nlev4 + 3) / 4;
+  dim3 block(256), grid((unsigned)(blocks_per_xcd * 8));
+  hipLaunchKernelGGL((k_cgrid_stream2<T, FB, VEC, S, D>), grid, block, 0, s, P);
+  GCMF_HIP(hipGetLastError());
+  return GCMF_OK;
+}
+
+int launch_cgrid_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
+  if (pl->d.dtype == GCMF_F64) return a.S == 2 ? launch_c2<double, double, 2, 2, 1>(pl, a, s) : GCMF_ERR_INVALID_ARG;
+  const int d2 = pl->prefetch_rows == 2;
+  // f32: two cells per lane (8-byte accesses).  Four would need > 256 registers per lane already for two levels;
+  // with two cells S = 2 runs three waves per SIMD and measured 115 G cell.steps/s against 87 G (config 5).
+  switch (a.S * 2 + (a.fb_is_f32 ? 1 : 0)) {
+    case 4: return d2 ? launch_c2<float, double, 2, 2, 2>(pl, a, s) : launch_c2<float, double, 2, 2, 1>(pl, a, s);
+    case 5: return d2 ? launch_c2<float, float, 2, 2, 2>(pl, a, s) : launch_c2<float, float, 2, 2, 1>(pl, a, s);
+    case 6: return d2 ? launch_c2<float, double, 2, 3, 2>(pl, a, s) : launch_c2<float, double, 2, 3, 1>(pl, a, s);
+    case 7: return d2 ? launch_c2<float, float, 2, 3, 2>(pl, a, s) : launch_c2<float, float, 2, 3, 1>(pl, a, s);
+    case 8: return d2 ? launch_c2<float, double, 2, 4, 2>(pl, a, s) : launch_c2<float, double, 2, 4, 1>(pl, a, s);
+    case 9: return d2 ? launch_c2<float, float, 2, 4, 2>(pl, a, s) : launch_c2<float, float, 2, 4, 1>(pl, a, s);
+  }
+  return GCMF_ERR_INVALID_ARG;
+}
+
+}  // namespace gcmf

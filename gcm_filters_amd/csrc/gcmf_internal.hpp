@@ -80,6 +80,21 @@ struct MultiArgs {
   int row_lo, row_hi;
 };
 
+// Arguments of one S-step C-grid launch (gcmf_cgrid_stream2.hip): T_{k-1}, T_{k-2} -> T_{k+S-2}, T_{k+S-1}.
+struct VecMultiArgs {
+  const void *u0[2];     // T_{k-1} (u, v)
+  const void *uprev[2];  // T_{k-2}             (ignored with `first`)
+  void *u1o[2];          // T_{k+S-2} out (must not alias u0 / uprev)
+  void *u2o[2];          // T_{k+S-1} out (must not alias u0 / uprev / u1o)
+  const void *fb_in[2];
+  void *fb_out[2];
+  double pk[4];          // p[k] .. p[k+S-1]; with `first`: p[1] .. p[S]
+  double p0, c;
+  int S, first, last, fb_is_f32;
+  int64_t nbatch;
+  int row_lo, row_hi;
+};
+
 }  // namespace gcmf
 
 struct gcmf_plan {
@@ -127,6 +142,8 @@ bool cgrid_stream_supported(const gcmf_plan *pl, const StepArgs &a);
 int launch_bgrid_stream(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 bool bgrid_stream_supported(const gcmf_plan *pl, const StepArgs &a);
 bool multi_supported(const gcmf_plan *pl, int S);
+bool cgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S);
+int launch_cgrid_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s);
 // S fused steps on rows [row_lo,row_hi) incl. the tripole band when the range ends at the fold row (gcmf_api.hip)
 int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launches);
 int launch_prepare(gcmf_plan *pl, const void *const *in, void *const *out, int64_t nbatch, int row_lo,

@@ -433,3 +433,53 @@ def test_out_f32_option(grid):
     for r, g in zip(ref, got):
         assert r.dtype == np.float64 and g.dtype == np.float32
         assert np.abs(g - r).max() <= 2e-5 * np.abs(r).max()
+
+
+@pytest.mark.parametrize("shape,nlev,dt", [((40, 64), 4, "f8"), ((33, 130), 8, "f8"), ((64, 256), 12, "f4"), ((25, 520), 4, "f4"),
+                                           ((96, 160), 50, "f4"), ((6, 8), 4, "f8"), ((6, 8), 4, "f4"), ((48, 64), 7, "f8"),
+                                           ((120, 124), 4, "f4")])
+def test_cgrid_temporal_blocking_bit_identical(shape, nlev, dt):
+    """VECTOR_C_GRID with a batch of levels advances S = 2..4 recurrence steps per HBM pass (k_cgrid_stream2); results
+    must be bit-identical to single steps, for every split of the step count, with NaN / inf in the input, and match
+    the oracle."""
+    from gcm_filters_amd import _lib
+    grid = "VECTOR_C_GRID"
+    (u0, v0), gv = T.vector_case(grid, shape)
+    rng = np.random.default_rng(5)
+    u = np.stack([u0 * (1 + 0.1 * k) + rng.standard_normal(shape) for k in range(nlev)]).astype(dt)
+    v = np.stack([v0 * (1 - 0.05 * k) + rng.standard_normal(shape) for k in range(nlev)]).astype(dt)
+    u[0, 3, 5] = np.nan
+    v[nlev - 1, 1, 2] = np.inf
+    gv = {k: x.astype(dt) for k, x in gv.items()}
+    dx = T.grid_dx_min(grid, gv)
+    lap = ALL_KERNELS[GridType[grid]](**gv)
+    plan = lap._plan(_lib.dtype_code(dt), shape)
+    blocked = (nlev + 3) // 4 * 4 * 10 <= nlev * 11   # lock-step workgroups of 4 levels, <= 10 % padding
+    for n_steps in (3, 4, 8, 9, 13):
+        flt = Filter(filter_scale=2.0 * dx, dx_min=dx, n_steps=n_steps, filter_shape=FilterShape.TAPER,
+                     grid_type=GridType[grid], grid_vars=gv)
+        try:
+            plan.set_tuning(multi_s=1)
+            plan.set_timing(True)
+            ref = flt.apply_to_vector(u, v)
+            assert plan.last_timing()[1] == n_steps
+            for S in (2, 3, 4):
+                plan.set_tuning(multi_s=S)
+                got = flt.apply_to_vector(u, v)
+                n_launch = plan.last_timing()[1]
+                if blocked:
+                    assert n_launch < n_steps, (n_launch, n_steps, S)
+                    if S == 4 and dt == "f4" and n_steps == 8:
+                        assert n_launch == 2
+                else:
+                    assert n_launch == n_steps
+                for r, g in zip(ref, got):
+                    assert np.array_equal(r, g, equal_nan=True), (shape, nlev, dt, n_steps, S, rel_err(g, r))
+        finally:
+            plan.set_tuning(multi_s=8)
+            plan.set_timing(False)
+    spec = O.make_spec(2.0 * dx, dx, "TAPER", n_steps=13)
+    with np.errstate(all="ignore"):
+        want = O.filter_func_vec(spec, grid, u, v, gv)
+    for g, w in zip(got, want):
+        assert rel_err(g, w) <= (1e-4 if dt == "f4" else 1e-11)
