@@ -463,12 +463,12 @@ static int run_whole(gcmf_plan *pl, const double *p, int n_steps, double c, cons
   // work layout per component: [A][B][fbar] (+ [prepared T0]) (+ host staging: [in][out])
   const size_t szT = align_up(ncell * ts, 256), szF = align_up(ncell * fbs, 256);
   const bool use_multi = !lapl_only && pl->multi_s >= 2 && n_steps >= 2 && multi_supported(pl, 2);
-  const bool use_pair = !lapl_only && pl->multi_s >= 2 && n_steps >= 2 && cgrid_multi_supported(pl, nbatch, 2);
+  const bool use_vmulti = !lapl_only && pl->multi_s >= 2 && n_steps >= 2 && cgrid_multi_supported(pl, nbatch, 2);
   size_t per = 0;
   const size_t oA = per; per += szT;
   const size_t oB = per; per += szT;
-  const size_t oC = per; if (use_multi || use_pair) per += szT;
-  const size_t oD = per; if (use_multi || use_pair) per += szT;
+  const size_t oC = per; if (use_multi || use_vmulti) per += szT;
+  const size_t oD = per; if (use_multi || use_vmulti) per += szT;
   const size_t oF = per; per += szF;
   const size_t oP = per; if (prep) per += szT;
   const size_t oIn = per; if (!on_dev) per += szT;
@@ -561,7 +561,7 @@ static int run_whole(gcmf_plan *pl, const double *p, int n_steps, double c, cons
         ++launches;
         k += S;
       }
-    } else if (use_pair) {
+    } else if (use_vmulti) {
       // C-grid: S = 2..4 steps per pass, (T_{k-1}, T_{k-2}) -> (T_{k+S-2}, T_{k+S-1}).  Neither output may overwrite
       // T_{k-2}: the halo rows / columns a strip recomputes need its neighbours' T_{k-2}.  The state rotates through
       // four buffers.  A lone last step runs the single-step kernel.

@@ -291,7 +291,9 @@ static bool c2al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u
 
 bool cgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
   if (pl->kind != K_CGRID || pl->cgrid_tile) return false;
-  if (S < 2 || S > (pl->d.dtype == GCMF_F64 ? 2 : 4)) return false;  // f64: more levels would spill registers
+  // f64: more than two levels spill registers.  f32: S = 6 / 8 fit only one wave per SIMD and measured slower than
+  // S = 4 at two (234-252 G against 268-274 G cell.steps/s on config 5)
+  if (S < 2 || S > (pl->d.dtype == GCMF_F64 ? 2 : 4)) return false;
   const int vec = pl->d.dtype == GCMF_F64 ? 2 : 4;
   if (pl->g.nx % vec || pl->g.nx < vec || pl->g.rows < S + 2) return false;
   const int64_t nlev4 = (nbatch + 3) / 4 * 4;
@@ -349,7 +351,7 @@ template <typename T, typename FB, int VEC, int S, int D> static int launch_c2(g
 
 int launch_cgrid_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
   if (pl->d.dtype == GCMF_F64) return a.S == 2 ? launch_c2<double, double, 2, 2, 1>(pl, a, s) : GCMF_ERR_INVALID_ARG;
-  const int d2 = pl->prefetch_rows == 2;
+  const int d2 = pl->prefetch_rows != 1;  // two operand rows in flight per wave unless tuned down
   // f32: two cells per lane (8-byte accesses).  Four would need > 256 registers per lane already for two levels;
   // with two cells S = 2 runs three waves per SIMD and measured 115 G cell.steps/s against 87 G (config 5).
   switch (a.S * 2 + (a.fb_is_f32 ? 1 : 0)) {
