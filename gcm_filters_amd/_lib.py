@@ -28,7 +28,7 @@ EXPORTS = [
     "gcmf_plan_create", "gcmf_plan_destroy", "gcmf_grid_nplanes", "gcmf_grid_ncomp", "gcmf_grid_is_dimensional",
     "gcmf_grid_is_tripolar", "gcmf_plan_rows", "gcmf_apply", "gcmf_laplacian", "gcmf_cheb_step", "gcmf_prepare",
     "gcmf_last_timing", "gcmf_set_timing", "gcmf_set_tuning", "gcmf_last_error", "gcmf_version",
-    "gcmf_multi_supported", "gcmf_cheb_multi",
+    "gcmf_multi_supported", "gcmf_cheb_multi", "gcmf_multi_supported_vec", "gcmf_cheb_multi_vec",
 ]
 
 
@@ -83,6 +83,11 @@ def load() -> C.CDLL:
         lib.gcmf_cheb_multi.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_double), C.c_int, C.c_double, C.c_double,
                                         C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, C.c_int64, vp]
         lib.gcmf_cheb_multi.restype = C.c_int
+        lib.gcmf_multi_supported_vec.argtypes = [vp, C.c_int, C.c_int64]
+        lib.gcmf_multi_supported_vec.restype = C.c_int
+        lib.gcmf_cheb_multi_vec.argtypes = [vp, vpp, vpp, vpp, vpp, vpp, vpp, C.POINTER(C.c_double), C.c_int, C.c_double,
+                                            C.c_double, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, C.c_int64, vp]
+        lib.gcmf_cheb_multi_vec.restype = C.c_int
         lib.gcmf_prepare.argtypes = [vp, vpp, vpp, C.c_int64, C.c_int64, C.c_int64, vp]
         lib.gcmf_prepare.restype = C.c_int
         lib.gcmf_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
@@ -204,6 +209,20 @@ class Plan:
                                      pk.ctypes.data_as(C.POINTER(C.c_double)), len(pk), float(p0), float(c), int(mode),
                                      OUT_F32 if out_f32 else 0, int(nbatch), int(row_lo), int(row_hi),
                                      C.c_void_p(stream or None)))
+
+    def multi_supported_vec(self, S: int, nbatch: int) -> bool:
+        return bool(load().gcmf_multi_supported_vec(self._h, int(S), int(nbatch)))
+
+    def cheb_multi_vec(self, u, v, uo, vo, fb_in, fb_out, pk, p0, c, mode, nbatch, row_lo, row_hi, *,
+                       out_f32: bool = False, stream: int = 0):
+        """Per-component pointer lists (ncomp entries; None for the ones FIRST / LAST do not need)."""
+        pk = np.ascontiguousarray(pk, dtype=np.float64)
+        z = [None] * self.ncomp
+        check(load().gcmf_cheb_multi_vec(self._h, _ptr_array(u), _ptr_array(v or z), _ptr_array(uo or z),
+                                         _ptr_array(vo or z), _ptr_array(fb_in or z), _ptr_array(fb_out),
+                                         pk.ctypes.data_as(C.POINTER(C.c_double)), len(pk), float(p0), float(c),
+                                         int(mode), OUT_F32 if out_f32 else 0, int(nbatch), int(row_lo), int(row_hi),
+                                         C.c_void_p(stream or None)))
 
     def prepare(self, ins, outs, nbatch, row_lo, row_hi, *, stream: int = 0):
         check(load().gcmf_prepare(self._h, _ptr_array(ins), _ptr_array(outs), int(nbatch), int(row_lo), int(row_hi),

@@ -420,6 +420,53 @@ int gcmf_cheb_multi(gcmf_plan *pl, const void *u, const void *v, void *uo, void 
   return advance_multi(pl, m, (hipStream_t)stream, nullptr);
 }
 
+int gcmf_multi_supported_vec(const gcmf_plan *pl, int S, int64_t nbatch) {
+  if (!pl || nbatch < 1) return 0;
+  if (pl->ncomp == 1) return multi_supported(pl, S) ? 1 : 0;
+  return cgrid_multi_supported(pl, nbatch, S) ? 1 : 0;
+}
+
+int gcmf_cheb_multi_vec(gcmf_plan *pl, const void *const *u, const void *const *v, void *const *uo, void *const *vo,
+                        const void *const *fbar_in, void *const *fbar_out, const double *pk, int S, double p0, double c,
+                        uint32_t mode, uint32_t flags, int64_t nbatch, int64_t row_lo, int64_t row_hi, void *stream) {
+  if (!pl || !u || !fbar_out || !pk) {
+    set_error("gcmf_cheb_multi_vec: null argument");
+    return GCMF_ERR_INVALID_ARG;
+  }
+  if (pl->ncomp == 1)
+    return gcmf_cheb_multi(pl, u[0], v ? v[0] : nullptr, uo ? uo[0] : nullptr, vo ? vo[0] : nullptr,
+                           fbar_in ? fbar_in[0] : nullptr, fbar_out[0], pk, S, p0, c, mode, flags, nbatch, row_lo,
+                           row_hi, stream);
+  if (!cgrid_multi_supported(pl, nbatch, S)) {
+    set_error("gcmf_cheb_multi_vec: S=%d with %lld levels is not available for this plan", S, (long long)nbatch);
+    return GCMF_ERR_UNSUPPORTED;
+  }
+  if (row_lo < 0 || row_hi > pl->rows_alloc || row_lo > row_hi) {
+    set_error("gcmf_cheb_multi_vec: rows [%lld, %lld) outside the slab allocation of %lld rows", (long long)row_lo,
+              (long long)row_hi, (long long)pl->rows_alloc);
+    return GCMF_ERR_INVALID_ARG;
+  }
+  const bool first = mode & GCMF_STEP_FIRST, last = mode & GCMF_STEP_LAST;
+  VecMultiArgs m{};
+  for (int q = 0; q < 2; ++q) {
+    const void *uq = u[q], *vq = v ? v[q] : nullptr, *fi = fbar_in ? fbar_in[q] : nullptr;
+    void *uoq = uo ? uo[q] : nullptr, *voq = vo ? vo[q] : nullptr;
+    if (!uq || !fbar_out[q] || (!first && (!vq || !fi)) || (!last && (!uoq || !voq)) || uoq == uq || (uoq && uoq == vq) ||
+        voq == uq || (voq && voq == vq) || (uoq && uoq == voq)) {
+      set_error("gcmf_cheb_multi_vec: missing or aliased state buffers");
+      return GCMF_ERR_INVALID_ARG;
+    }
+    m.u0[q] = uq; m.uprev[q] = vq; m.u2o[q] = uoq; m.u1o[q] = voq; m.fb_in[q] = fi; m.fb_out[q] = fbar_out[q];
+  }
+  for (int t = 0; t < S; ++t) m.pk[t] = pk[t];
+  m.p0 = p0; m.c = c; m.S = S; m.first = first; m.last = last;
+  m.fb_is_f32 = (pl->d.dtype == GCMF_F32) && (flags & GCMF_OUT_F32);
+  m.nbatch = nbatch; m.row_lo = (int)row_lo; m.row_hi = (int)row_hi;
+  std::lock_guard<std::mutex> lk(pl->mu);
+  GCMF_HIP(hipSetDevice(pl->d.device));
+  return launch_cgrid_multi(pl, m, (hipStream_t)stream);
+}
+
 int gcmf_prepare(gcmf_plan *pl, const void *const *in, void *const *out, int64_t nbatch, int64_t row_lo,
                  int64_t row_hi, void *stream) {
   if (!pl || !in || !out) return GCMF_ERR_INVALID_ARG;

@@ -62,14 +62,13 @@ class HipSlabEngine:
         self.plan.cheb_step(self._ptrs(t1), self._ptrs(t2), self._ptrs(fb_in), self._ptrs(t0), self._ptrs(fb_out),
                             coef0, coef1, c, mode, nbatch, row_lo, row_hi, stream=self._stream())
 
-    def multi_supported(self, S):
-        return self.plan.multi_supported(S)
+    def multi_supported(self, S, nbatch=1):
+        return self.plan.multi_supported_vec(S, nbatch)
 
     def multi(self, u, v, uo, vo, fb_in, fb_out, pk, p0, c, mode, nbatch, row_lo, row_hi):
-        """S = len(pk) recurrence steps in one HBM pass (gcmf_cheb_multi); scalar grids only (one component)."""
-        dp = lambda t: 0 if t is None else t.data_ptr()
-        self.plan.cheb_multi(dp(u), dp(v), dp(uo), dp(vo), dp(fb_in), dp(fb_out), pk, p0, c, mode, nbatch, row_lo,
-                             row_hi, stream=self._stream())
+        """S = len(pk) recurrence steps in one HBM pass (gcmf_cheb_multi_vec); per-component tensor lists."""
+        self.plan.cheb_multi_vec(self._ptrs(u), self._ptrs(v), self._ptrs(uo), self._ptrs(vo), self._ptrs(fb_in),
+                                 self._ptrs(fb_out), pk, p0, c, mode, nbatch, row_lo, row_hi, stream=self._stream())
 
 
 class SlabFilter:
@@ -263,15 +262,15 @@ class SlabFilter:
         self.exchanges += 1
 
     # -- the filter ----------------------------------------------------------------------------
-    MULTI_DEPTHS = (8, 6, 4, 3, 2)
+    MULTI_DEPTHS = (8, 6, 4, 3, 2)  # scalar kinds support all of them, the C-grid 4 / 3 / 2 (f64: 2)
 
     def apply_local(self, local: Sequence):
         """Filter this rank's rows.  `local`: ncomp tensors (nbatch, rows_owned, nx) on the device.  Returns
         ncomp float64 tensors of the same shape (views into an internal buffer, valid until the next call).
 
-        Between two halo exchanges the recurrence advances `halo` steps; scalar grids do that with the
-        temporally blocked kernel (up to 8 steps per HBM pass, consuming one ghost row per step), vector grids
-        with single steps on a row range that shrinks by one per step."""
+        Between two halo exchanges the recurrence advances `halo` steps; scalar grids and batched C-grid fields do
+        that with the temporally blocked kernels (up to 8 / 4 steps per HBM pass, consuming one ghost row per
+        step), the rest with single steps on a row range that shrinks by one per step."""
         t = self.torch
         assert len(local) == self.ncomp
         nbatch = int(local[0].shape[0])
@@ -284,7 +283,7 @@ class SlabFilter:
         comps = lambda buf: [buf[k] for k in range(self.ncomp)]
         p = np.asarray(self.spec.p, dtype=np.float64)
         n = self.n_steps
-        can_multi = self.ncomp == 1 and hasattr(self.engine, "multi") and self.multi_depth >= 2
+        can_multi = hasattr(self.engine, "multi") and self.multi_depth >= 2
         prepared = False
         u, v = X, None          # T_{k-1}, T_{k-2}
         valid = 0               # ghost rows of u (and at least valid-1 of v) that are up to date
@@ -301,7 +300,7 @@ class SlabFilter:
                 for cand in self.MULTI_DEPTHS:
                     if budget - cand == 1 and left == budget:
                         continue  # do not strand a lone single step at the very end
-                    if cand <= budget and cand <= self.multi_depth and self.engine.multi_supported(cand):
+                    if cand <= budget and cand <= self.multi_depth and self.engine.multi_supported(cand, nbatch):
                         S = cand
                         break
             free = [b for b in pool if b is not u and b is not v]
@@ -314,10 +313,10 @@ class SlabFilter:
                 e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
                 e0.record()
             if S >= 2:
-                args = (u[0], None if v is None else v[0], free[0][0], free[1][0], F[0], O[0] if is_last else F[0],
-                        p[k: k + S], p[0], self.c, mode, nbatch)
+                args = (comps(u), None if v is None else comps(v), comps(free[0]), comps(free[1]), comps(F),
+                        comps(O) if is_last else comps(F), p[k: k + S], p[0], self.c, mode, nbatch)
                 overlap = (self.overlap and self.world > 1 and v_out == 0 and not is_last and ro >= 4 * s
-                           and self.engine.multi_supported(S))
+                           and self.engine.multi_supported(S, nbatch))
                 if overlap:
                     # this launch uses up the ghost zone: advance the rows the neighbours need first, post the halo
                     # exchange of the NEW states, and let the interior rows run while the messages are in flight

@@ -174,6 +174,19 @@ int gcmf_cheb_multi(gcmf_plan *plan, const void *u, const void *v, void *uo, voi
                     void *fbar_out, const double *pk, int S, double p0, double c, uint32_t mode, uint32_t flags,
                     int64_t nbatch, int64_t row_lo, int64_t row_hi, void *stream);
 
+/*
+ * The same for every grid type, with per-component pointer arrays like gcmf_cheb_step (ncomp entries each).
+ * Scalar plans forward to gcmf_cheb_multi.  VECTOR_C_GRID (reference kernels.py:591-699 inside the recurrence of
+ * filter.py:225-283) advances S in {2,3,4} steps per pass (f64 plans: S = 2) when the batch fills lock-step
+ * workgroups of 4 levels (nbatch a multiple of 4, or >= 40); nbatch is part of the question, hence the extra
+ * argument of gcmf_multi_supported_vec.  VECTOR_B_GRID has no blocked kernel yet (returns 0 / GCMF_ERR_UNSUPPORTED).
+ */
+int gcmf_multi_supported_vec(const gcmf_plan *plan, int S, int64_t nbatch);
+int gcmf_cheb_multi_vec(gcmf_plan *plan, const void *const *u, const void *const *v, void *const *uo,
+                        void *const *vo, const void *const *fbar_in, void *const *fbar_out, const double *pk,
+                        int S, double p0, double c, uint32_t mode, uint32_t flags, int64_t nbatch,
+                        int64_t row_lo, int64_t row_hi, void *stream);
+
 /* T_0 = prepare(field) = field * area for the AREA_WEIGHTED grid types (kernels.py:100-101),
  * a copy otherwise; rows [row_lo,row_hi) of the slab allocation. */
 int gcmf_prepare(gcmf_plan *plan, const void *const *in, void *const *out, int64_t nbatch,

@@ -60,33 +60,38 @@ class OracleSlabEngine:
             fb_out[k].numpy()[:, rows, :] = fb
 
     # --- temporally blocked advance, emulated with S single oracle steps on a shrinking row range ---
-    def multi_supported(self, S):
-        return self.name not in O.VECTOR and S in (2, 3, 4, 6, 8) and self.rows_alloc >= 3 * S + 2
+    def multi_supported(self, S, nbatch=1):
+        if self.name in O.VECTOR:  # mirrors cgrid_multi_supported: lock-step groups of 4 levels, S <= 4
+            return (self.name == "VECTOR_C_GRID" and S in (2, 3, 4) and self.rows_alloc >= S + 2
+                    and (nbatch + 3) // 4 * 4 * 10 <= nbatch * 11)
+        return S in (2, 3, 4, 6, 8) and self.rows_alloc >= 3 * S + 2
 
     def multi(self, u, v, uo, vo, fb_in, fb_out, pk, p0, c, mode, nbatch, row_lo, row_hi):
         import torch
         S = len(pk)
+        nc = len(u)
         first, last = bool(mode & STEP_FIRST), bool(mode & STEP_LAST)
-        lvl = {0: u.clone(), -1: None if v is None else v.clone()}
+        lvl = {0: [x.clone() for x in u], -1: None if v is None else [x.clone() for x in v]}
         if first and self.area is not None:
-            lvl[0] = lvl[0] * torch.from_numpy(self.area[self.gidx])
-        fb = None if first else fb_in.clone()
+            lvl[0] = [x * torch.from_numpy(self.area[self.gidx]) for x in lvl[0]]
+        fb = None if first else [x.clone() for x in fb_in]
         for t in range(1, S + 1):
             lo, hi = max(row_lo - (S - t), 0), min(row_hi + (S - t), self.rows_alloc)
-            t0 = torch.full_like(u, POISON)
-            fbo = torch.full_like(fb_out, POISON) if fb is None else fb.clone()
+            t0 = [torch.full_like(x, POISON) for x in u]
+            fbo = [torch.full_like(x, POISON) for x in fb_out] if fb is None else [x.clone() for x in fb]
             m = (STEP_FIRST if (first and t == 1) else 0)
-            self.step([lvl[t - 1]], None if lvl[t - 2] is None else [lvl[t - 2]], None if fb is None else [fb], [t0], [fbo],
+            self.step(lvl[t - 1], lvl[t - 2], fb, t0, fbo,
                       p0 if (first and t == 1) else pk[t - 1], pk[0], c, m, nbatch, lo, hi)
             lvl[t] = t0
             fb = fbo
         rows = slice(row_lo, row_hi)
-        if last:
-            res = fb[:, rows, :]
-            if self.area is not None:
-                res = res / torch.from_numpy(self.area[self.gidx[rows]])
-            fb_out[:, rows, :] = res
-        else:
-            uo[:, rows, :] = lvl[S][:, rows, :]
-            vo[:, rows, :] = lvl[S - 1][:, rows, :]
-            fb_out[:, rows, :] = fb[:, rows, :]
+        for q in range(nc):
+            if last:
+                res = fb[q][:, rows, :]
+                if self.area is not None:
+                    res = res / torch.from_numpy(self.area[self.gidx[rows]])
+                fb_out[q][:, rows, :] = res
+            else:
+                uo[q][:, rows, :] = lvl[S][q][:, rows, :]
+                vo[q][:, rows, :] = lvl[S - 1][q][:, rows, :]
+                fb_out[q][:, rows, :] = fb[q][:, rows, :]

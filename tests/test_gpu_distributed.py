@@ -20,6 +20,9 @@ CASES = [
     ("VECTOR_C_GRID", (48, 64), 3, 2, "f8"),
     ("VECTOR_B_GRID", (47, 64), 2, 1, "f8"),
     ("VECTOR_C_GRID", (48, 64), 4, 3, "f4"),
+    ("VECTOR_C_GRID", (48, 64), 4, 4, "f4"),    # 4 levels: blocked C-grid kernel (S = 4) on the slabs
+    ("VECTOR_C_GRID", (120, 64), 3, 8, "f4"),   # ... with the overlapped exchange
+    ("VECTOR_C_GRID", (60, 64), 4, 4, "f8"),    # f64: S = 2
 ]
 
 
@@ -55,7 +58,10 @@ def _worker(rank, world, port, q):
             dx = T.grid_dx_min(grid, gv) if O.DIMENSIONAL[grid] else 1.0
             fk = dict(filter_scale=5.0 * dx, dx_min=dx, filter_shape="GAUSSIAN")
             sf = SlabFilter(grid, gv, fk, shape[0], shape[1], halo=halo, dtype=np.dtype(dt), device=0)
+            sf.time_kernels = True
             got = sf.gather_to_global(sf.apply_local(sf.scatter_from_global(fields)))
+            if grid == "VECTOR_C_GRID" and nbatch % 4 == 0:   # the blocked vector kernel really ran on the slabs
+                assert sf.kernel_launches < sf.n_steps, (sf.kernel_launches, sf.n_steps)
             if rank == 0:
                 flt = Filter(filter_scale=fk["filter_scale"], dx_min=dx, grid_type=GridType[grid], grid_vars=gv)
                 one = flt.apply_to_vector(*fields) if vec else (flt.apply(fields[0]),)
@@ -64,7 +70,7 @@ def _worker(rank, world, port, q):
                     want = O.filter_func_vec(spec, grid, *fields, gv) if vec else (O.filter_func(spec, grid, fields[0], gv),)
                 e_one = max(float(np.abs(g - w).max() / np.abs(w).max()) for g, w in zip(got, one))
                 e_ref = max(float(np.abs(g - w).max() / np.abs(w).max()) for g, w in zip(got, want))
-                res[f"{grid}-{dt}"] = (e_one, e_ref)
+                res[f"{grid}-{shape}-h{halo}-b{nbatch}-{dt}"] = (e_one, e_ref)
         if rank == 0:
             q.put(res)
     finally:
