@@ -296,8 +296,10 @@ bool cgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
   if (S < 2 || S > (pl->d.dtype == GCMF_F64 ? 2 : 4)) return false;
   const int vec = pl->d.dtype == GCMF_F64 ? 2 : 4;
   if (pl->g.nx % vec || pl->g.nx < vec || pl->g.rows < S + 2) return false;
-  const int64_t nlev4 = (nbatch + 3) / 4 * 4;
-  if (nlev4 * 10 > nbatch * 11) return false;  // needs lock-step workgroups of 4 levels (see k_cgrid_stream)
+  // any batch size: the lock-step workgroups of 4 levels are padded with shadow waves that repeat the last level
+  // without storing.  Even 1 level + 3 shadows beats the single-step kernel (83 G against 40 G cell.steps/s on
+  // 2400x3600 f32; 2 levels 163 against 54; 5 levels 198 against 62): the shadows' loads hit in L2.
+  if (nbatch < 1) return false;
   for (int k = 0; k < MAX_COEF; ++k)
     if (!c2al16(pl->g.coef[k])) return false;
   return true;
@@ -325,10 +327,16 @@ template <typename T, typename FB, int VEC, int S, int D> static int launch_c2(g
   P.nlev4 = (P.nlev + 3) / 4 * 4;
   int H = pl->strip_rows;
   if (H <= 0) {
-    long long want = 2048 / ((long long)P.nwx * a.nbatch);
-    if (want < 1) want = 1;
-    H = (int)((nrows + want - 1) / want);
-    if (H > 96) H = 96;  // (H + 4) / H rows are marched per strip: 4 % redundancy, measured best on config 5
+    // strips as tall as possible (a strip marches H + 2S rows) while the launch still fills whole rounds of the
+    // 2048 resident waves (2 per SIMD): the fewest strips of <= 96 rows (64-96 measured best on config 5: 273 G
+    // against 262 G at 160) fix the number of rounds, then the strip
+    // count grows to fill the last round
+    const long long per_strip = (long long)P.nwx * P.nlev4, cap = 2048, hmax = 96;
+    const long long ns_min = (nrows + hmax - 1) / hmax;
+    const long long rounds = (ns_min * per_strip + cap - 1) / cap;
+    long long ns = rounds * cap / per_strip;
+    if (ns < ns_min) ns = ns_min;
+    H = (int)((nrows + ns - 1) / ns);
     if (H < 16) H = 16;
   }
   if (H > nrows) H = nrows;

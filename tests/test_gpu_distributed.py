@@ -60,7 +60,7 @@ def _worker(rank, world, port, q):
             sf = SlabFilter(grid, gv, fk, shape[0], shape[1], halo=halo, dtype=np.dtype(dt), device=0)
             sf.time_kernels = True
             got = sf.gather_to_global(sf.apply_local(sf.scatter_from_global(fields)))
-            if grid == "VECTOR_C_GRID" and nbatch % 4 == 0:   # the blocked vector kernel really ran on the slabs
+            if grid == "VECTOR_C_GRID":   # the blocked vector kernel really ran on the slabs
                 assert sf.kernel_launches < sf.n_steps, (sf.kernel_launches, sf.n_steps)
             if rank == 0:
                 flt = Filter(filter_scale=fk["filter_scale"], dx_min=dx, grid_type=GridType[grid], grid_vars=gv)
