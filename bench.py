@@ -37,7 +37,7 @@ B_ALG = {
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
-def build_workload(cfg: int, ny: int, nx: int, nlev: int):
+def build_workload(cfg: int, ny: int, nx: int, nlev: int, f32: bool = False):
     """Synthetic inputs of BASELINE.json configs: returns dict(grid, fields, grid_vars, filter kwargs)."""
     from gcm_filters_amd import FilterShape, testing as T
 
@@ -75,7 +75,13 @@ def build_workload(cfg: int, ny: int, nx: int, nlev: int):
     elif cfg == 6:  # not a BASELINE config: the POP B-grid vector Laplacian at the benchmark size, fp64
         grid = "VECTOR_B_GRID"
         gv = T.vector_grid_vars(grid, shape)
-        fields = [T.random_field(shape, 42), T.random_field(shape, 43)]
+        if nlev <= 1:
+            fields = [T.random_field(shape, 42), T.random_field(shape, 43)]
+        else:
+            fields = [np.stack([T.random_field(shape, 42 + c + 2 * l) for l in range(nlev)]) for c in range(2)]
+        if f32:
+            gv = {k: v.astype(np.float32) for k, v in gv.items()}
+            fields = [f.astype(np.float32) for f in fields]
         dx = T.grid_dx_min(grid, gv)
         fk = dict(filter_scale=40 * dx, dx_min=dx, filter_shape=FilterShape.GAUSSIAN)
     else:
@@ -115,7 +121,8 @@ def main():
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config number (2..5), default 3")
     ap.add_argument("--ny", type=int, default=2400)
     ap.add_argument("--nx", type=int, default=3600)
-    ap.add_argument("--nlev", type=int, default=50, help="vertical levels of config 5")
+    ap.add_argument("--nlev", type=int, default=0, help="vertical levels of config 5 (default 50) / config 6 (default 1)")
+    ap.add_argument("--f32", action="store_true", help="config 6 only: f32 state instead of f64")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N>1: weak = every GPU owns a full ny-row slab of a (N*ny, nx) grid; strong = one (ny, nx) grid")
     ap.add_argument("--halo", type=int, default=0, help="N>1: ghost rows per exchange (0 = auto)")
@@ -157,7 +164,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     ny_global = args.ny * world if (world > 1 and args.scaling == "weak") else args.ny
-    wl = build_workload(args.config, ny_global if world > 1 else args.ny, args.nx, args.nlev)
+    if args.nlev <= 0:
+        args.nlev = 50 if args.config == 5 else 1
+    wl = build_workload(args.config, ny_global if world > 1 else args.ny, args.nx, args.nlev, args.f32)
     grid, fk = wl["grid"], wl["fk"]
     itemsize = wl["fields"][0].dtype.itemsize
     nbatch = 1 if wl["fields"][0].ndim == 2 else wl["fields"][0].shape[0]

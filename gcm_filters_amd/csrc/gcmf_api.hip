@@ -423,7 +423,7 @@ int gcmf_cheb_multi(gcmf_plan *pl, const void *u, const void *v, void *uo, void 
 int gcmf_multi_supported_vec(const gcmf_plan *pl, int S, int64_t nbatch) {
   if (!pl || nbatch < 1) return 0;
   if (pl->ncomp == 1) return multi_supported(pl, S) ? 1 : 0;
-  return cgrid_multi_supported(pl, nbatch, S) ? 1 : 0;
+  return vec_multi_supported(pl, nbatch, S) ? 1 : 0;
 }
 
 int gcmf_cheb_multi_vec(gcmf_plan *pl, const void *const *u, const void *const *v, void *const *uo, void *const *vo,
@@ -437,7 +437,7 @@ int gcmf_cheb_multi_vec(gcmf_plan *pl, const void *const *u, const void *const *
     return gcmf_cheb_multi(pl, u[0], v ? v[0] : nullptr, uo ? uo[0] : nullptr, vo ? vo[0] : nullptr,
                            fbar_in ? fbar_in[0] : nullptr, fbar_out[0], pk, S, p0, c, mode, flags, nbatch, row_lo,
                            row_hi, stream);
-  if (!cgrid_multi_supported(pl, nbatch, S)) {
+  if (!vec_multi_supported(pl, nbatch, S)) {
     set_error("gcmf_cheb_multi_vec: S=%d with %lld levels is not available for this plan", S, (long long)nbatch);
     return GCMF_ERR_UNSUPPORTED;
   }
@@ -464,7 +464,7 @@ int gcmf_cheb_multi_vec(gcmf_plan *pl, const void *const *u, const void *const *
   m.nbatch = nbatch; m.row_lo = (int)row_lo; m.row_hi = (int)row_hi;
   std::lock_guard<std::mutex> lk(pl->mu);
   GCMF_HIP(hipSetDevice(pl->d.device));
-  return launch_cgrid_multi(pl, m, (hipStream_t)stream);
+  return launch_vec_multi(pl, m, (hipStream_t)stream);
 }
 
 int gcmf_prepare(gcmf_plan *pl, const void *const *in, void *const *out, int64_t nbatch, int64_t row_lo,
@@ -510,7 +510,7 @@ static int run_whole(gcmf_plan *pl, const double *p, int n_steps, double c, cons
   // work layout per component: [A][B][fbar] (+ [prepared T0]) (+ host staging: [in][out])
   const size_t szT = align_up(ncell * ts, 256), szF = align_up(ncell * fbs, 256);
   const bool use_multi = !lapl_only && pl->multi_s >= 2 && n_steps >= 2 && multi_supported(pl, 2);
-  const bool use_vmulti = !lapl_only && pl->multi_s >= 2 && n_steps >= 2 && cgrid_multi_supported(pl, nbatch, 2);
+  const bool use_vmulti = !lapl_only && pl->multi_s >= 2 && n_steps >= 2 && vec_multi_supported(pl, nbatch, 2);
   size_t per = 0;
   const size_t oA = per; per += szT;
   const size_t oB = per; per += szT;
@@ -609,7 +609,7 @@ static int run_whole(gcmf_plan *pl, const double *p, int n_steps, double c, cons
         k += S;
       }
     } else if (use_vmulti) {
-      // C-grid: S = 2..4 steps per pass, (T_{k-1}, T_{k-2}) -> (T_{k+S-2}, T_{k+S-1}).  Neither output may overwrite
+      // vector kinds: S = 2..4 steps per pass, (T_{k-1}, T_{k-2}) -> (T_{k+S-2}, T_{k+S-1}).  Neither output may overwrite
       // T_{k-2}: the halo rows / columns a strip recomputes need its neighbours' T_{k-2}.  The state rotates through
       // four buffers.  A lone last step runs the single-step kernel.
       const void *u[2] = {x0[0], x0[1]}, *v[2] = {nullptr, nullptr};
@@ -624,7 +624,7 @@ static int run_whole(gcmf_plan *pl, const double *p, int n_steps, double c, cons
         int S = 1;
         const int cand[3] = {4, 3, 2};
         for (int q = 0; q < 3; ++q)  // largest depth that does not strand a lone single step at the end
-          if (cand[q] <= left && left - cand[q] != 1 && cand[q] <= pl->multi_s && cgrid_multi_supported(pl, nbatch, cand[q])) {
+          if (cand[q] <= left && left - cand[q] != 1 && cand[q] <= pl->multi_s && vec_multi_supported(pl, nbatch, cand[q])) {
             S = cand[q];
             break;
           }
@@ -639,7 +639,7 @@ static int run_whole(gcmf_plan *pl, const double *p, int n_steps, double c, cons
           for (int t = 0; t < S; ++t) m.pk[t] = p[k + t];
           m.p0 = p[0]; m.c = c; m.S = S;
           m.first = (k == 1); m.last = is_last; m.fb_is_f32 = fb32; m.nbatch = nbatch; m.row_lo = 0; m.row_hi = rows;
-          if ((rc = launch_cgrid_multi(pl, m, s))) return rc;
+          if ((rc = launch_vec_multi(pl, m, s))) return rc;
           for (int q = 0; q < 2; ++q) { u[q] = fr[1][q]; v[q] = fr[0][q]; }
           k += S;
         } else {

@@ -80,7 +80,7 @@ struct MultiArgs {
   int row_lo, row_hi;
 };
 
-// Arguments of one S-step C-grid launch (gcmf_cgrid_stream2.hip): T_{k-1}, T_{k-2} -> T_{k+S-2}, T_{k+S-1}.
+// Arguments of one S-step vector launch (gcmf_cgrid_stream2.hip / gcmf_bgrid_stream2.hip): T_{k-1}, T_{k-2} -> T_{k+S-2}, T_{k+S-1}.
 struct VecMultiArgs {
   const void *u0[2];     // T_{k-1} (u, v)
   const void *uprev[2];  // T_{k-2}             (ignored with `first`)
@@ -144,6 +144,14 @@ bool bgrid_stream_supported(const gcmf_plan *pl, const StepArgs &a);
 bool multi_supported(const gcmf_plan *pl, int S);
 bool cgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S);
 int launch_cgrid_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s);
+bool bgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S);
+int launch_bgrid_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s);
+inline bool vec_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
+  return pl->kind == K_CGRID ? cgrid_multi_supported(pl, nbatch, S) : bgrid_multi_supported(pl, nbatch, S);
+}
+inline int launch_vec_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
+  return pl->kind == K_CGRID ? launch_cgrid_multi(pl, a, s) : launch_bgrid_multi(pl, a, s);
+}
 // S fused steps on rows [row_lo,row_hi) incl. the tripole band when the range ends at the fold row (gcmf_api.hip)
 int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launches);
 int launch_prepare(gcmf_plan *pl, const void *const *in, void *const *out, int64_t nbatch, int row_lo,

@@ -34,6 +34,7 @@ CASES = [
     ("VECTOR_B_GRID", (23, 16), 2, 2),
     ("VECTOR_C_GRID", (24, 16), 4, 4),   # 4 levels: the blocked C-grid path (S = 4) between exchanges
     ("VECTOR_C_GRID", (72, 16), 3, 4),   # ... with the overlapped exchange (S = 3 uses up the ghost zone)
+    ("VECTOR_B_GRID", (72, 16), 4, 3),   # blocked B-grid path, padded batch
     # slabs tall enough (rows_owned >= 4 halo) for the overlapped exchange: edge rows first, interior during the transfer
     ("IRREGULAR_WITH_LAND", (66, 16), 2, 1),
     ("REGULAR_WITH_LAND_AREA_WEIGHTED", (72, 16), 4, 2),

@@ -23,6 +23,8 @@ CASES = [
     ("VECTOR_C_GRID", (48, 64), 4, 4, "f4"),    # 4 levels: blocked C-grid kernel (S = 4) on the slabs
     ("VECTOR_C_GRID", (120, 64), 3, 8, "f4"),   # ... with the overlapped exchange
     ("VECTOR_C_GRID", (60, 64), 4, 4, "f8"),    # f64: S = 2
+    ("VECTOR_B_GRID", (120, 64), 3, 5, "f8"),   # blocked B-grid kernel (f64: S <= 3), padded batch, overlapped exchange
+    ("VECTOR_B_GRID", (49, 64), 4, 2, "f4"),
 ]
 
 
@@ -60,7 +62,7 @@ def _worker(rank, world, port, q):
             sf = SlabFilter(grid, gv, fk, shape[0], shape[1], halo=halo, dtype=np.dtype(dt), device=0)
             sf.time_kernels = True
             got = sf.gather_to_global(sf.apply_local(sf.scatter_from_global(fields)))
-            if grid == "VECTOR_C_GRID":   # the blocked vector kernel really ran on the slabs
+            if vec:   # the blocked vector kernels really ran on the slabs
                 assert sf.kernel_launches < sf.n_steps, (sf.kernel_launches, sf.n_steps)
             if rank == 0:
                 flt = Filter(filter_scale=fk["filter_scale"], dx_min=dx, grid_type=GridType[grid], grid_vars=gv)

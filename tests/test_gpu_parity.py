@@ -438,12 +438,12 @@ def test_out_f32_option(grid):
 @pytest.mark.parametrize("shape,nlev,dt", [((40, 64), 4, "f8"), ((33, 130), 8, "f8"), ((64, 256), 12, "f4"), ((25, 520), 4, "f4"),
                                            ((96, 160), 50, "f4"), ((6, 8), 4, "f8"), ((6, 8), 4, "f4"), ((48, 64), 7, "f8"),
                                            ((120, 124), 4, "f4")])
-def test_cgrid_temporal_blocking_bit_identical(shape, nlev, dt):
-    """VECTOR_C_GRID with a batch of levels advances S = 2..4 recurrence steps per HBM pass (k_cgrid_stream2); results
-    must be bit-identical to single steps, for every split of the step count, with NaN / inf in the input, and match
-    the oracle."""
+@pytest.mark.parametrize("grid", ["VECTOR_C_GRID", "VECTOR_B_GRID"])
+def test_vector_temporal_blocking_bit_identical(grid, shape, nlev, dt):
+    """The vector Laplacians advance S = 2..4 recurrence steps per HBM pass (k_cgrid_stream2 / k_bgrid_stream2);
+    results must be bit-identical to single steps, for every split of the step count and every batch size (lock-step
+    workgroups of 4 levels, padded), with NaN / inf in the input, and match the oracle."""
     from gcm_filters_amd import _lib
-    grid = "VECTOR_C_GRID"
     (u0, v0), gv = T.vector_case(grid, shape)
     rng = np.random.default_rng(5)
     u = np.stack([u0 * (1 + 0.1 * k) + rng.standard_normal(shape) for k in range(nlev)]).astype(dt)
@@ -471,6 +471,8 @@ def test_cgrid_temporal_blocking_bit_identical(shape, nlev, dt):
                     assert n_launch < n_steps, (n_launch, n_steps, S)
                     if S == 4 and dt == "f4" and n_steps == 8:
                         assert n_launch == 2
+                    if S == 2 and n_steps == 8:
+                        assert n_launch == 4
                 else:
                     assert n_launch == n_steps
                 for r, g in zip(ref, got):

@@ -12,8 +12,10 @@ worst = {}
 t0 = time.time()
 for it in range(ncase):
     grid = T.ALL_GRIDS[rng.integers(len(T.ALL_GRIDS))]
-    if "--cgrid" in sys.argv:  # batched C-grid: exercises the two-steps-per-pass kernel
+    if "--cgrid" in sys.argv:  # batched vector fields: exercise the temporally blocked vector kernels
         grid = "VECTOR_C_GRID"
+    if "--bgrid" in sys.argv:
+        grid = "VECTOR_B_GRID"
     vec = grid in T.VECTOR_GRIDS
     if "--tiny" in sys.argv:
         ny = int(rng.integers(1, 14)); nx = int(rng.integers(1, 14))
@@ -27,8 +29,8 @@ for it in range(ncase):
     shape = (ny, nx)
     dt = "f8" if rng.random() < 0.7 else "f4"
     nb = () if rng.random() < 0.6 else (int(rng.integers(1, 4)),) if rng.random() < 0.7 else (2, int(rng.integers(1, 3)))
-    if "--cgrid" in sys.argv:
-        nb = (int(rng.choice([4, 4, 8, 12, 41])),)
+    if "--cgrid" in sys.argv or "--bgrid" in sys.argv:
+        nb = (int(rng.choice([1, 3, 4, 8, 12, 41])),)
     gv = T.vector_grid_vars(grid, shape) if vec else T.scalar_grid_vars(grid, shape)
     ncomp = 2 if vec else 1
     fields = [rng.random(nb + shape) for _ in range(ncomp)]
