@@ -37,7 +37,7 @@ B_ALG = {
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
-def build_workload(cfg: int, ny: int, nx: int, nlev: int, f32: bool = False):
+def build_workload(cfg: int, ny: int, nx: int, nlev: int, f32: bool = False, f64: bool = False):
     """Synthetic inputs of BASELINE.json configs: returns dict(grid, fields, grid_vars, filter kwargs)."""
     from gcm_filters_amd import FilterShape, testing as T
 
@@ -66,9 +66,10 @@ def build_workload(cfg: int, ny: int, nx: int, nlev: int, f32: bool = False):
         fk = dict(filter_scale=50 * dx, dx_min=dx, filter_shape=FilterShape.GAUSSIAN)
     elif cfg == 5:
         grid = "VECTOR_C_GRID"
-        gv = {k: v.astype(np.float32) for k, v in T.vector_grid_vars(grid, shape).items()}
-        gv["kappa_aniso"] = np.zeros(shape, dtype=np.float32)
-        fields = [np.stack([T.random_field(shape, 42 + c + 2 * l).astype(np.float32) for l in range(nlev)])
+        cdt = np.float64 if f64 else np.float32   # BASELINE config 5 is f32; --f64 is an extra measurement
+        gv = {k: v.astype(cdt) for k, v in T.vector_grid_vars(grid, shape).items()}
+        gv["kappa_aniso"] = np.zeros(shape, dtype=cdt)
+        fields = [np.stack([T.random_field(shape, 42 + c + 2 * l).astype(cdt) for l in range(nlev)])
                   for c in range(2)]
         dx = T.grid_dx_min(grid, gv)
         fk = dict(filter_scale=40 * dx, dx_min=dx, filter_shape=FilterShape.GAUSSIAN)
@@ -123,6 +124,7 @@ def main():
     ap.add_argument("--nx", type=int, default=3600)
     ap.add_argument("--nlev", type=int, default=0, help="vertical levels of config 5 (default 50) / config 6 (default 1)")
     ap.add_argument("--f32", action="store_true", help="config 6 only: f32 state instead of f64")
+    ap.add_argument("--f64", action="store_true", help="config 5 only: f64 state instead of the BASELINE's f32")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N>1: weak = every GPU owns a full ny-row slab of a (N*ny, nx) grid; strong = one (ny, nx) grid")
     ap.add_argument("--halo", type=int, default=0, help="N>1: ghost rows per exchange (0 = auto)")
@@ -166,7 +168,7 @@ def main():
     ny_global = args.ny * world if (world > 1 and args.scaling == "weak") else args.ny
     if args.nlev <= 0:
         args.nlev = 50 if args.config == 5 else 1
-    wl = build_workload(args.config, ny_global if world > 1 else args.ny, args.nx, args.nlev, args.f32)
+    wl = build_workload(args.config, ny_global if world > 1 else args.ny, args.nx, args.nlev, args.f32, args.f64)
     grid, fk = wl["grid"], wl["fk"]
     itemsize = wl["fields"][0].dtype.itemsize
     nbatch = 1 if wl["fields"][0].ndim == 2 else wl["fields"][0].shape[0]
@@ -235,7 +237,7 @@ def main():
         "dtype": "f64" if itemsize == 8 else "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"{'BASELINE config' if args.config <= 5 else 'extra config'} {args.config}: {grid} {args.ny}x{args.nx}"
+            "workload": f"{'BASELINE config' if (args.config <= 5 and not args.f64) else 'extra config'} {args.config}{' (f64 variant)' if args.f64 else ''}: {grid} {args.ny}x{args.nx}"
                         + (f" x{nbatch} levels" if nbatch > 1 else "") + (f" per GPU, {world} row slabs" if world > 1 and args.scaling == "weak" else ""),
             "filter": f"{fk['filter_shape'].name} filter_scale={fk['filter_scale']:.6g} dx_min={fk['dx_min']:.6g}",
             "n_steps": n_steps,

@@ -10,6 +10,7 @@
 // 8w + 4f + 8w/4 bytes per cell.level whatever S is.  Batches that do not fill the 4 levels are padded with shadow waves.
 // Per level the summation order is the reference's, term by term: bit-identical to S single steps and to numpy.
 #include "gcmf_multi_common.hpp"
+#include <cstdlib>
 
 namespace gcmf {
 
@@ -71,19 +72,27 @@ template <typename T, int VEC> struct BgLevel {
   }
 };
 
-template <typename T, typename FB, int VEC, int S, int D>
-__global__ __launch_bounds__(256, 2) void k_bgrid_stream2(const BStream2P<T, FB> P) {
+// PRIV (single-level fields): one-wave workgroups, each an independent (window, strip) group; the wave fetches all 8
+// coefficient rows itself, level 1 uses them straight from registers and levels 2..S read them back from the wave's own
+// LDS ring of S-1 slots, refilled at the end of the iteration (no barrier, no shadow waves).
+template <typename T, typename FB, int VEC, int S, int D, bool PRIV>
+__global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) == 8 && (S > 3 || (PRIV && S > 2)) ? 1 : 2)) void k_bgrid_stream2(const BStream2P<T, FB> P) {
   constexpr int M = (S + VEC - 1) / VEC * VEC;
   constexpr int W = 64 * VEC, WI = W - 2 * M;
-  constexpr int NS = S + 1;
-  __shared__ MPack<T, VEC> s_coef[NS][8][64];
+  constexpr int NS = PRIV ? S - 1 : S + 1;
+  constexpr int NSHARE = PRIV ? 8 : 2;
+  constexpr int WPB = PRIV ? 1 : 4;  // waves per workgroup
+  extern __shared__ __align__(16) unsigned char s_raw[];
+  typedef MPack<T, VEC> CoefSlot[8][64];
+  CoefSlot *s_coef = reinterpret_cast<CoefSlot *>(s_raw);
 
-  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, wv = PRIV ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int blk = blockIdx.x;
-  const int xcd = blk & 7, slot = (blk >> 3) * 4 + wv;
-  const int group = (slot / P.nlev4) * 8 + xcd;
-  int lev = slot % P.nlev4;
-  if (group >= P.ngroups) return;  // whole workgroups exit together
+  const int xcd = blk & 7, slot = (blk >> 3) * WPB + wv;
+  const int nlevp = PRIV ? P.nlev : P.nlev4;
+  const int group = (slot / nlevp) * 8 + xcd;
+  int lev = slot % nlevp;
+  if (group >= P.ngroups) return;  // shared mode: whole workgroups exit together; private mode has no barriers
   const bool shadow = lev >= P.nlev;
   if (shadow) lev = P.nlev - 1;
   const int wx = group % P.nwx, st = group / P.nwx;
@@ -102,10 +111,11 @@ __global__ __launch_bounds__(256, 2) void k_bgrid_stream2(const BStream2P<T, FB>
     T u[VEC], v[VEC];      // T_{k-1} row r
     T up[VEC], vp[VEC];    // T_{k-2} row r-1
     FB fu[VEC], fv[VEC];   // fbar    row r-1
-    T share[2][VEC];       // this wave's quarter of the coefficient rows r-1 (planes wv, wv+4)
+    T share[NSHARE][VEC];  // this wave's quarter of the coefficient rows r-1 (planes wv, wv+4); PRIV: all 8
   };
   // this wave's coefficient planes, resolved once (never index the kernel argument inside the row loop)
   const T *cp[2] = {P.coef[wv], P.coef[wv + 4]};
+  (void)cp;
   auto row_index = [&](int r) {
     if (P.wrap) {
       r = r < 0 ? r + rows : (r >= rows ? r - rows : r);
@@ -124,8 +134,13 @@ __global__ __launch_bounds__(256, 2) void k_bgrid_stream2(const BStream2P<T, FB>
       mload<FB, VEC>(x.fu, P.fu_in + boff + rc);
       mload<FB, VEC>(x.fv, P.fv_in + boff + rc);
     }
-    mload<T, VEC>(x.share[0], cp[0] + rc);
-    mload<T, VEC>(x.share[1], cp[1] + rc);
+    if (PRIV) {
+#pragma unroll
+      for (int q = 0; q < NSHARE; ++q) mload<T, VEC>(x.share[q], P.coef[q < 8 ? q : 0] + rc);
+    } else {
+      mload<T, VEC>(x.share[0], cp[0] + rc);
+      mload<T, VEC>(x.share[1], cp[1] + rc);
+    }
   };
 
   BgLevel<T, VEC> L[S];
@@ -142,15 +157,21 @@ __global__ __launch_bounds__(256, 2) void k_bgrid_stream2(const BStream2P<T, FB>
   }
   int cur = 0;  // LDS ring slot of this iteration
 
-  auto step = [&](Row &x, int r) {
+  auto publish = [&](Row &x) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < NSHARE; ++q) {
       MPack<T, VEC> pk;
 #pragma unroll
       for (int k = 0; k < VEC; ++k) pk.s[k] = x.share[q][k];
-      s_coef[cur][wv + 4 * q][lane] = pk;
+      s_coef[cur][PRIV ? q : wv + 4 * q][lane] = pk;
     }
-    __syncthreads();
+  };
+
+  auto step = [&](Row &x, int r) {
+    if (!PRIV) {
+      publish(x);
+      __syncthreads();
+    }
 
     T cu[S + 1][VEC], cv[S + 1][VEC];  // newest row of every level this iteration
     FB nau[S + 1][VEC], nav[S + 1][VEC];
@@ -162,11 +183,19 @@ __global__ __launch_bounds__(256, 2) void k_bgrid_stream2(const BStream2P<T, FB>
       int sl = cur - (j - 1);
       if (sl < 0) sl += NS;
       T K[8][VEC];
+      if (PRIV && j == 1) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const MPack<T, VEC> pq = s_coef[sl][q][lane];
+        for (int q = 0; q < 8; ++q) {
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) K[q][k] = pq.s[k];
+          for (int k = 0; k < VEC; ++k) K[q][k] = x.share[PRIV ? q : 0][k];
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const MPack<T, VEC> pq = s_coef[sl][q][lane];
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) K[q][k] = pq.s[k];
+        }
       }
       T su[VEC], sv[VEC], lu[VEC], lv[VEC];
 #pragma unroll
@@ -227,6 +256,7 @@ __global__ __launch_bounds__(256, 2) void k_bgrid_stream2(const BStream2P<T, FB>
         if (j >= 1) { accu[j][k] = nau[j][k]; accv[j][k] = nav[j][k]; }
       }
     }
+    if (PRIV) publish(x);  // after level S has read the slot this overwrites (same wave: LDS executes in order)
     cur = (cur + 1 == NS) ? 0 : cur + 1;
   };
 
@@ -260,11 +290,9 @@ __global__ __launch_bounds__(256, 2) void k_bgrid_stream2(const BStream2P<T, FB>
 
 static bool b2al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-int bgrid_multi_max(const gcmf_plan *pl) { return pl->d.dtype == GCMF_F64 ? 3 : 4; }
-
 bool bgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
   if (pl->kind != K_BGRID || nbatch < 1) return false;
-  if (S < 2 || S > bgrid_multi_max(pl)) return false;
+  if (S < 2 || S > 4) return false;
   const int vec = pl->d.dtype == GCMF_F64 ? 2 : 4;
   if (pl->g.nx % vec || pl->g.nx < vec || pl->g.rows < S + 2) return false;
   for (int k = 0; k < 8; ++k)
@@ -272,7 +300,7 @@ bool bgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
   return true;
 }
 
-template <typename T, typename FB, int VEC, int S, int D> static int launch_b2(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
+template <typename T, typename FB, int VEC, int S, int D, bool PRIV> static int launch_b2(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
   constexpr int M = (S + VEC - 1) / VEC * VEC, W = 64 * VEC, WI = W - 2 * M;
   const Geom &g = pl->g;
   BStream2P<T, FB> P;
@@ -294,7 +322,13 @@ template <typename T, typename FB, int VEC, int S, int D> static int launch_b2(g
   P.nlev4 = (P.nlev + 3) / 4 * 4;
   int H = pl->strip_rows;
   if (H <= 0) {  // see launch_c2 (gcmf_cgrid_stream2.hip)
-    const long long per_strip = (long long)P.nwx * P.nlev4, cap = 2048, hmax = 96;
+    long long cap = (sizeof(T) == 8 && S > 3) ? 1024 : 2048;  // f64 at four levels: one wave per SIMD
+    if (PRIV) {  // one-wave workgroups: registers or the LDS ring bound the residency
+      const long long by_lds = (160 * 1024) / ((long long)(S - 1) * 8 * 64 * sizeof(MPack<T, VEC>));
+      const long long by_reg = (sizeof(T) == 8 && S > 2) ? 4 : 8;
+      cap = 256 * (by_lds < by_reg ? by_lds : by_reg) * 85 / 100;
+    }
+    const long long per_strip = (long long)P.nwx * (PRIV ? P.nlev : P.nlev4), hmax = 96;
     const long long ns_min = (nrows + hmax - 1) / hmax;
     const long long rounds = (ns_min * per_strip + cap - 1) / cap;
     long long ns = rounds * cap / per_strip;
@@ -313,29 +347,38 @@ template <typename T, typename FB, int VEC, int S, int D> static int launch_b2(g
   for (int t = 0; t < 4; ++t) P.pk[t] = a.pk[t];
   P.c = a.c;
   const long long groups_per_xcd = (P.ngroups + 7) / 8;
-  const long long blocks_per_xcd = (groups_per_xcd * P.nlev4 + 3) / 4;
-  dim3 block(256), grid((unsigned)(blocks_per_xcd * 8));
-  hipLaunchKernelGGL((k_bgrid_stream2<T, FB, VEC, S, D>), grid, block, 0, s, P);
+  const long long blocks_per_xcd = PRIV ? groups_per_xcd * P.nlev : (groups_per_xcd * P.nlev4 + 3) / 4;
+  dim3 block(PRIV ? 64 : 256), grid((unsigned)(blocks_per_xcd * 8));
+  const size_t lds = (size_t)(PRIV ? S - 1 : S + 1) * 8 * 64 * sizeof(MPack<T, VEC>);
+  hipLaunchKernelGGL((k_bgrid_stream2<T, FB, VEC, S, D, PRIV>), grid, block, lds, s, P);
   GCMF_HIP(hipGetLastError());
   return GCMF_OK;
 }
 
+template <typename T, typename FB, int S, int DMAX> static int launch_b2_sel(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
+  // single-level fields: private coefficient rings (no shadow waves); env GCMF_VEC_PRIV=0 keeps the padded lock-step form
+  static const bool priv_ok = !(getenv("GCMF_VEC_PRIV") && atoi(getenv("GCMF_VEC_PRIV")) == 0);
+  if (a.nbatch == 1 && priv_ok) return launch_b2<T, FB, 2, S, 1, true>(pl, a, s);
+  if (DMAX == 1 || pl->prefetch_rows == 1) return launch_b2<T, FB, 2, S, 1, false>(pl, a, s);
+  return launch_b2<T, FB, 2, S, DMAX, false>(pl, a, s);
+}
+
 int launch_bgrid_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
-  const int d2 = pl->prefetch_rows != 1;
   if (pl->d.dtype == GCMF_F64) {
     switch (a.S) {
-      case 2: return d2 ? launch_b2<double, double, 2, 2, 2>(pl, a, s) : launch_b2<double, double, 2, 2, 1>(pl, a, s);
-      case 3: return launch_b2<double, double, 2, 3, 1>(pl, a, s);
+      case 2: return launch_b2_sel<double, double, 2, 2>(pl, a, s);
+      case 3: return launch_b2_sel<double, double, 3, 1>(pl, a, s);
+      case 4: return launch_b2_sel<double, double, 4, 2>(pl, a, s);  // one wave per SIMD: registers to spare
     }
     return GCMF_ERR_INVALID_ARG;
   }
   switch (a.S * 2 + (a.fb_is_f32 ? 1 : 0)) {
-    case 4: return d2 ? launch_b2<float, double, 2, 2, 2>(pl, a, s) : launch_b2<float, double, 2, 2, 1>(pl, a, s);
-    case 5: return d2 ? launch_b2<float, float, 2, 2, 2>(pl, a, s) : launch_b2<float, float, 2, 2, 1>(pl, a, s);
-    case 6: return d2 ? launch_b2<float, double, 2, 3, 2>(pl, a, s) : launch_b2<float, double, 2, 3, 1>(pl, a, s);
-    case 7: return d2 ? launch_b2<float, float, 2, 3, 2>(pl, a, s) : launch_b2<float, float, 2, 3, 1>(pl, a, s);
-    case 8: return d2 ? launch_b2<float, double, 2, 4, 2>(pl, a, s) : launch_b2<float, double, 2, 4, 1>(pl, a, s);
-    case 9: return d2 ? launch_b2<float, float, 2, 4, 2>(pl, a, s) : launch_b2<float, float, 2, 4, 1>(pl, a, s);
+    case 4: return launch_b2_sel<float, double, 2, 2>(pl, a, s);
+    case 5: return launch_b2_sel<float, float, 2, 2>(pl, a, s);
+    case 6: return launch_b2_sel<float, double, 3, 2>(pl, a, s);
+    case 7: return launch_b2_sel<float, float, 3, 2>(pl, a, s);
+    case 8: return launch_b2_sel<float, double, 4, 2>(pl, a, s);
+    case 9: return launch_b2_sel<float, float, 4, 2>(pl, a, s);
   }
   return GCMF_ERR_INVALID_ARG;
 }

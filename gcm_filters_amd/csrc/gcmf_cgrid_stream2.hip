@@ -11,6 +11,7 @@
 // 4w + 2f + 14w/4 + 4w + 2f bytes per cell.level whatever S is (78 B with f32 state and f64 fbar; 65 B for S = 1).
 // Arithmetic per level is the single-step kernel's: bit-identical results.
 #include "gcmf_multi_common.hpp"
+#include <cstdlib>
 
 namespace gcmf {
 
@@ -85,19 +86,27 @@ template <typename T, int VEC> struct CgLevel {
   }
 };
 
-template <typename T, typename FB, int VEC, int S, int D>
-__global__ __launch_bounds__(256, 2) void k_cgrid_stream2(const CStream2P<T, FB> P) {
+// PRIV (single-level fields): one-wave workgroups, each an independent (window, strip) group; the wave fetches all 14
+// coefficient rows itself, level 1 uses them straight from registers and levels 2..S read them back from the wave's own
+// LDS ring of S-1 slots, refilled at the end of the iteration (no barrier, no shadow waves).
+template <typename T, typename FB, int VEC, int S, int D, bool PRIV>
+__global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) == 8 && (PRIV || S > 2) ? 1 : 2)) void k_cgrid_stream2(const CStream2P<T, FB> P) {
   constexpr int M = (S + VEC - 1) / VEC * VEC;  // level j is stale j cells per side; windows start on a VEC boundary
   constexpr int W = 64 * VEC, WI = W - 2 * M;
-  constexpr int NS = S + 1;
-  __shared__ MPack<T, VEC> s_coef[NS][14][64];
+  constexpr int NS = PRIV ? S - 1 : S + 1;
+  constexpr int NSHARE = PRIV ? 14 : 4;
+  constexpr int WPB = PRIV ? 1 : 4;  // waves per workgroup
+  extern __shared__ __align__(16) unsigned char s_raw[];
+  typedef MPack<T, VEC> CoefSlot[14][64];
 
-  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, wv = PRIV ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  CoefSlot *s_coef = reinterpret_cast<CoefSlot *>(s_raw);
   const int blk = blockIdx.x;
-  const int xcd = blk & 7, slot = (blk >> 3) * 4 + wv;
-  const int group = (slot / P.nlev4) * 8 + xcd;
-  int lev = slot % P.nlev4;
-  if (group >= P.ngroups) return;  // whole workgroups exit together
+  const int xcd = blk & 7, slot = (blk >> 3) * WPB + wv;
+  const int nlevp = PRIV ? P.nlev : P.nlev4;
+  const int group = (slot / nlevp) * 8 + xcd;
+  int lev = slot % nlevp;
+  if (group >= P.ngroups) return;  // shared mode: whole workgroups exit together; private mode has no barriers
   const bool shadow = lev >= P.nlev;
   if (shadow) lev = P.nlev - 1;
   const int wx = group % P.nwx, st = group / P.nwx;
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void k_cgrid_stream2(const CStream2P<T, FB>
     T u[VEC], v[VEC];      // T_{k-1} row r
     T up[VEC], vp[VEC];    // T_{k-2} row r-1
     FB fu[VEC], fv[VEC];   // fbar    row r-1
-    T share[4][VEC];       // this wave's quarter of the coefficient rows (planes wv, wv+4, wv+8, wv+12)
+    T share[NSHARE][VEC];  // this wave's quarter of the coefficient rows (planes wv, wv+4, wv+8, wv+12); PRIV: all 14
   };
   // this wave's coefficient planes, resolved once: indexing the kernel argument inside the row loop costs a
   // dependent memory load plus a full vmcnt(0) drain per plane and row
@@ -141,10 +150,15 @@ __global__ __launch_bounds__(256, 2) void k_cgrid_stream2(const CStream2P<T, FB>
       mload<FB, VEC>(x.fu, P.fu_in + boff + rc);
       mload<FB, VEC>(x.fv, P.fv_in + boff + rc);
     }
+    if (PRIV) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int pidx = wv + 4 * q;
-      if (pidx < 14) mload<T, VEC>(x.share[q], cp[q] + (pidx < 7 ? ro : rc));
+      for (int q = 0; q < NSHARE; ++q) mload<T, VEC>(x.share[q], P.coef[q < 14 ? q : 0] + (q < 7 ? ro : rc));
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int pidx = wv + 4 * q;
+        if (pidx < 14) mload<T, VEC>(x.share[q], cp[q] + (pidx < 7 ? ro : rc));
+      }
     }
   };
 
@@ -165,11 +179,10 @@ __global__ __launch_bounds__(256, 2) void k_cgrid_stream2(const CStream2P<T, FB>
   }
   int cur = 0;  // LDS ring slot of this iteration
 
-  auto step = [&](Row &x, int r) {
-    // ---- exchange the coefficient rows of this iteration through LDS ----
+  auto publish = [&](Row &x) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int pidx = wv + 4 * q;
+    for (int q = 0; q < NSHARE; ++q) {
+      const int pidx = PRIV ? q : wv + 4 * q;
       if (pidx < 14) {
         MPack<T, VEC> pk;
 #pragma unroll
@@ -177,7 +190,14 @@ __global__ __launch_bounds__(256, 2) void k_cgrid_stream2(const CStream2P<T, FB>
         s_coef[cur][pidx][lane] = pk;
       }
     }
-    __syncthreads();
+  };
+
+  auto step = [&](Row &x, int r) {
+    // ---- exchange the coefficient rows of this iteration through LDS ----
+    if (!PRIV) {
+      publish(x);
+      __syncthreads();
+    }
 
     T cu[S + 1][VEC], cv[S + 1][VEC];  // newest row of every level this iteration
     FB nau[S + 1][VEC], nav[S + 1][VEC];
@@ -189,12 +209,20 @@ __global__ __launch_bounds__(256, 2) void k_cgrid_stream2(const CStream2P<T, FB>
       int sl = cur - (j - 1);
       if (sl < 0) sl += NS;
       T cA[7][VEC], cB[7][VEC];
+      if (PRIV && j == 1) {
 #pragma unroll
-      for (int q = 0; q < 7; ++q) {
-        const MPack<T, VEC> pa = s_coef[sl][q][lane];
-        const MPack<T, VEC> pb = s_coef[sl][7 + q][lane];
+        for (int q = 0; q < 7; ++q) {
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) { cA[q][k] = pa.s[k]; cB[q][k] = pb.s[k]; }
+          for (int k = 0; k < VEC; ++k) { cA[q][k] = x.share[q][k]; cB[q][k] = x.share[PRIV ? 7 + q : 0][k]; }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+          const MPack<T, VEC> pa = s_coef[sl][q][lane];
+          const MPack<T, VEC> pb = s_coef[sl][7 + q][lane];
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) { cA[q][k] = pa.s[k]; cB[q][k] = pb.s[k]; }
+        }
       }
       T su[VEC], sv[VEC], lu[VEC], lv[VEC];
 #pragma unroll
@@ -256,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void k_cgrid_stream2(const CStream2P<T, FB>
         if (j >= 1) { accu[j][k] = nau[j][k]; accv[j][k] = nav[j][k]; }
       }
     }
+    if (PRIV) publish(x);  // after level S has read the slot this overwrites (same wave: LDS executes in order)
     cur = (cur + 1 == NS) ? 0 : cur + 1;
   };
 
@@ -293,7 +322,7 @@ bool cgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
   if (pl->kind != K_CGRID || pl->cgrid_tile) return false;
   // f64: more than two levels spill registers.  f32: S = 6 / 8 fit only one wave per SIMD and measured slower than
   // S = 4 at two (234-252 G against 268-274 G cell.steps/s on config 5)
-  if (S < 2 || S > (pl->d.dtype == GCMF_F64 ? 2 : 4)) return false;
+  if (S < 2 || S > 4) return false;
   const int vec = pl->d.dtype == GCMF_F64 ? 2 : 4;
   if (pl->g.nx % vec || pl->g.nx < vec || pl->g.rows < S + 2) return false;
   // any batch size: the lock-step workgroups of 4 levels are padded with shadow waves that repeat the last level
@@ -305,7 +334,7 @@ bool cgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
   return true;
 }
 
-template <typename T, typename FB, int VEC, int S, int D> static int launch_c2(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
+template <typename T, typename FB, int VEC, int S, int D, bool PRIV> static int launch_c2(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
   constexpr int M = (S + VEC - 1) / VEC * VEC, W = 64 * VEC, WI = W - 2 * M;
   const Geom &g = pl->g;
   CStream2P<T, FB> P;
@@ -331,7 +360,13 @@ template <typename T, typename FB, int VEC, int S, int D> static int launch_c2(g
     // 2048 resident waves (2 per SIMD): the fewest strips of <= 96 rows (64-96 measured best on config 5: 273 G
     // against 262 G at 160) fix the number of rounds, then the strip
     // count grows to fill the last round
-    const long long per_strip = (long long)P.nwx * P.nlev4, cap = 2048, hmax = 96;
+    long long cap = (sizeof(T) == 8 && S > 2) ? 1024 : 2048;  // f64 beyond two levels: one wave per SIMD
+    if (PRIV) {  // one-wave workgroups: registers (f64: one wave per SIMD) or the LDS ring bound the residency
+      const long long by_lds = (160 * 1024) / ((long long)(S - 1) * 14 * 64 * sizeof(MPack<T, VEC>));
+      const long long by_reg = sizeof(T) == 8 ? 4 : 8;
+      cap = 256 * (by_lds < by_reg ? by_lds : by_reg) * 85 / 100;  // a little headroom measured best (139 vs 132 G)
+    }
+    const long long per_strip = (long long)P.nwx * (PRIV ? P.nlev : P.nlev4), hmax = 96;
     const long long ns_min = (nrows + hmax - 1) / hmax;
     const long long rounds = (ns_min * per_strip + cap - 1) / cap;
     long long ns = rounds * cap / per_strip;
@@ -350,25 +385,51 @@ template <typename T, typename FB, int VEC, int S, int D> static int launch_c2(g
   for (int t = 0; t < 4; ++t) P.pk[t] = a.pk[t];
   P.c = a.c;
   const long long groups_per_xcd = (P.ngroups + 7) / 8;
-  const long long blocks_per_xcd = (groups_per_xcd * P.nlev4 + 3) / 4;
-  dim3 block(256), grid((unsigned)(blocks_per_xcd * 8));
-  hipLaunchKernelGGL((k_cgrid_stream2<T, FB, VEC, S, D>), grid, block, 0, s, P);
+  const long long blocks_per_xcd = PRIV ? groups_per_xcd * P.nlev : (groups_per_xcd * P.nlev4 + 3) / 4;
+  dim3 block(PRIV ? 64 : 256), grid((unsigned)(blocks_per_xcd * 8));
+  const size_t lds = (size_t)(PRIV ? S - 1 : S + 1) * 14 * 64 * sizeof(MPack<T, VEC>);
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set && lds > 48 * 1024) {
+    GCMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cgrid_stream2<T, FB, VEC, S, D, PRIV>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_cgrid_stream2<T, FB, VEC, S, D, PRIV>), grid, block, lds, s, P);
   GCMF_HIP(hipGetLastError());
   return GCMF_OK;
 }
 
+template <typename T, typename FB, int S> static int launch_c2_sel(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
+  // single-level fields: private coefficient rings (no shadow waves); env GCMF_VEC_PRIV=0 keeps the padded lock-step form
+  static const bool priv_ok = !(getenv("GCMF_VEC_PRIV") && atoi(getenv("GCMF_VEC_PRIV")) == 0);
+  if (a.nbatch == 1 && priv_ok) return launch_c2<T, FB, 2, S, 1, true>(pl, a, s);  // 14 rows per operand row: one in flight
+  // two operand rows in flight per wave unless tuned down (f64 at S = 2: the registers of two waves per SIMD allow one)
+  if constexpr (sizeof(T) == 8 && S == 2) {
+    return launch_c2<T, FB, 2, S, 1, false>(pl, a, s);
+  } else {
+    if (pl->prefetch_rows == 1) return launch_c2<T, FB, 2, S, 1, false>(pl, a, s);
+    return launch_c2<T, FB, 2, S, 2, false>(pl, a, s);
+  }
+}
+
 int launch_cgrid_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
-  if (pl->d.dtype == GCMF_F64) return a.S == 2 ? launch_c2<double, double, 2, 2, 1>(pl, a, s) : GCMF_ERR_INVALID_ARG;
-  const int d2 = pl->prefetch_rows != 1;  // two operand rows in flight per wave unless tuned down
+  if (pl->d.dtype == GCMF_F64) {
+    switch (a.S) {
+      case 2: return launch_c2_sel<double, double, 2>(pl, a, s);
+      case 3: return launch_c2_sel<double, double, 3>(pl, a, s);
+      case 4: return launch_c2_sel<double, double, 4>(pl, a, s);
+    }
+    return GCMF_ERR_INVALID_ARG;
+  }
   // f32: two cells per lane (8-byte accesses).  Four would need > 256 registers per lane already for two levels;
   // with two cells S = 2 runs three waves per SIMD and measured 115 G cell.steps/s against 87 G (config 5).
   switch (a.S * 2 + (a.fb_is_f32 ? 1 : 0)) {
-    case 4: return d2 ? launch_c2<float, double, 2, 2, 2>(pl, a, s) : launch_c2<float, double, 2, 2, 1>(pl, a, s);
-    case 5: return d2 ? launch_c2<float, float, 2, 2, 2>(pl, a, s) : launch_c2<float, float, 2, 2, 1>(pl, a, s);
-    case 6: return d2 ? launch_c2<float, double, 2, 3, 2>(pl, a, s) : launch_c2<float, double, 2, 3, 1>(pl, a, s);
-    case 7: return d2 ? launch_c2<float, float, 2, 3, 2>(pl, a, s) : launch_c2<float, float, 2, 3, 1>(pl, a, s);
-    case 8: return d2 ? launch_c2<float, double, 2, 4, 2>(pl, a, s) : launch_c2<float, double, 2, 4, 1>(pl, a, s);
-    case 9: return d2 ? launch_c2<float, float, 2, 4, 2>(pl, a, s) : launch_c2<float, float, 2, 4, 1>(pl, a, s);
+    case 4: return launch_c2_sel<float, double, 2>(pl, a, s);
+    case 5: return launch_c2_sel<float, float, 2>(pl, a, s);
+    case 6: return launch_c2_sel<float, double, 3>(pl, a, s);
+    case 7: return launch_c2_sel<float, float, 3>(pl, a, s);
+    case 8: return launch_c2_sel<float, double, 4>(pl, a, s);
+    case 9: return launch_c2_sel<float, float, 4>(pl, a, s);
   }
   return GCMF_ERR_INVALID_ARG;
 }

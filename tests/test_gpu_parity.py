@@ -437,7 +437,8 @@ def test_out_f32_option(grid):
 
 @pytest.mark.parametrize("shape,nlev,dt", [((40, 64), 4, "f8"), ((33, 130), 8, "f8"), ((64, 256), 12, "f4"), ((25, 520), 4, "f4"),
                                            ((96, 160), 50, "f4"), ((6, 8), 4, "f8"), ((6, 8), 4, "f4"), ((48, 64), 7, "f8"),
-                                           ((120, 124), 4, "f4")])
+                                           ((120, 124), 4, "f4"), ((40, 64), 1, "f8"), ((64, 256), 1, "f4"),
+                                           ((33, 132), 2, "f4"), ((7, 8), 1, "f4")])
 @pytest.mark.parametrize("grid", ["VECTOR_C_GRID", "VECTOR_B_GRID"])
 def test_vector_temporal_blocking_bit_identical(grid, shape, nlev, dt):
     """The vector Laplacians advance S = 2..4 recurrence steps per HBM pass (k_cgrid_stream2 / k_bgrid_stream2);
