@@ -1,6 +1,7 @@
 // Helpers shared by the temporally blocked scalar kernels (gcmf_scalar_multi.hip, gcmf_scalar_skew.hip).
 #pragma once
 #include "gcmf_internal.hpp"
+#include "gcmf_recurrence.hpp"
 
 #include <cfloat>
 #include <type_traits>

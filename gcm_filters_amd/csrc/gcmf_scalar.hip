@@ -16,6 +16,7 @@
 //     and last chunk wrap;
 //   * 4 waves per workgroup work on 4 different row strips of the same x-chunk.
 #include "gcmf_internal.hpp"
+#include "gcmf_recurrence.hpp"
 
 #include <cfloat>
 #include <type_traits>
@@ -203,16 +204,15 @@ __global__ __launch_bounds__(256) void k_scalar_step(const ScalarP<T, FB> P) {
       if (lapl) {
         t0v[k] = L;
       } else {
-        const T a = -x - c * L;
+        constexpr bool FUSED = (KIND == K_FLUX);  // see gcmf_recurrence.hpp
+        const T a = cheb_a<FUSED>(x, c, L);
         if (first) {
           t0v[k] = a;
-          if (std::is_same<FB, T>::value) fbo[k] = (FB)((T)P.coef0 * x + (T)P.coef1 * a);
-          else fbo[k] = (FB)(P.coef0 * (double)x + P.coef1 * (double)a);
+          fbo[k] = cheb_acc_first<FUSED, T, FB>(P.coef0, P.coef1, x, a);
         } else {
-          const T tk = T(2) * a - x2[k];
+          const T tk = cheb_t<FUSED>(a, x2[k]);
           t0v[k] = tk;
-          if (std::is_same<FB, T>::value) fbo[k] = fb[k] + (FB)((T)P.coef0 * tk);
-          else fbo[k] = fb[k] + (FB)(P.coef0 * (double)tk);
+          fbo[k] = cheb_acc<FUSED, T, FB>(fb[k], P.coef0, tk);
         }
         if (last && P.area_weighted) fbo[k] = fbo[k] / (FB)ar[k];  // finalize (kernels.py:103-104)
       }
