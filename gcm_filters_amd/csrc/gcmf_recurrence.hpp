@@ -1,10 +1,11 @@
-// The Chebyshev recurrence arithmetic (reference gcm_filters/filter.py:162-212) shared by every kernel, single-step and
-// temporally blocked, so that they agree bit for bit with each other.
-//   FUSED = false (REGULAR / land-mask / B-grid kinds): numpy's operation order and roundings, one IEEE operation per
-//           numpy operation -- these kinds are bit-exact against the reference.
-//   FUSED = true  (flux-form and C-grid kinds, whose plan-time folded coefficients already differ from the reference in
-//           the last bit): -x - c L, 2 A - T_{k-2} and fbar += p_k T_k are one fused multiply-add each (one rounding and
-//           one instruction less per line; the blocked flux kernel is VALU-issue bound).
+// The Chebyshev recurrence arithmetic (reference gcm_filters/filter.py:162-212) shared by the scalar kernels, single-step
+// (gcmf_scalar.hip) and temporally blocked (gcmf_scalar_multi.hip), so that they agree bit for bit with each other.
+//   FUSED = false (REGULAR / land-mask kinds): numpy's operation order and roundings, one IEEE operation per numpy
+//           operation -- these kinds are bit-exact against the reference.
+//   FUSED = true  (flux-form kinds, whose plan-time folded coefficients already differ from the reference in the last
+//           bit): -x - c L, 2 A - T_{k-2} and fbar += p_k T_k are one fused multiply-add each (one rounding and one
+//           instruction less per line).
+// The vector kernels keep their own (unfused) copies of these lines next to their stencils.
 // The library is compiled with -ffp-contract=off: nothing is fused unless it is written here.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -231,19 +231,18 @@ __global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scal
       }
       // raw centre of level t-1 (NaN/inf survive in "-x", filter.py:171-173)
       const T x = FLAGGED ? unsan(xC, (Rf[t - 1] >> (2 * VEC + 2 * k)) & 3u) : xC;
-      const T av = -x - c * L;
+      constexpr bool FUSED = (KIND == K_FLUX);  // see gcmf_recurrence.hpp
+      const T av = cheb_a<FUSED>(x, c, L);
       T tk;
       if (t == 1 && first) {
         tk = av;
-        if (std::is_same<FB, T>::value) Fq[1][k] = (FB)((T)P.p0 * x + (T)P.pk[0] * av);
-        else Fq[1][k] = (FB)(P.p0 * (double)x + P.pk[0] * (double)av);
+        Fq[1][k] = cheb_acc_first<FUSED, T, FB>(P.p0, P.pk[0], x, av);
       } else {
         T x2;
         if (t == 1) x2 = Vp[k];
         else x2 = FLAGGED ? unsan(G[t >= 2 ? t - 2 : 0][0][k], (Rf[t >= 2 ? t - 2 : 0] >> (2 * k)) & 3u) : G[t >= 2 ? t - 2 : 0][0][k];
-        tk = T(2) * av - x2;
-        if (std::is_same<FB, T>::value) Fq[t][k] = Fq[t][k] + (FB)((T)P.pk[t - 1] * tk);
-        else Fq[t][k] = Fq[t][k] + (FB)(P.pk[t - 1] * (double)tk);
+        tk = cheb_t<FUSED>(av, x2);
+        Fq[t][k] = cheb_acc<FUSED, T, FB>(Fq[t][k], P.pk[t - 1], tk);
       }
       tkv[k] = tk;
       if (t == S - 1) out_v[k] = tk;
