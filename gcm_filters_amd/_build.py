@@ -18,6 +18,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-function", "-I", INCLUDE, "-I", CSRC]
 
 
+FLAGS += os.environ.get("GCMF_EXTRA_HIPCC_FLAGS", "").split()  # experiments (A/B builds on the GPU box)
+
+
 def hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):

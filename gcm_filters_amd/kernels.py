@@ -84,15 +84,14 @@ def compute_dtype(arrays: Sequence) -> int:
 
 
 def _fingerprint(a) -> Tuple:
-    """Cheap identity of a grid plane: buffer address, layout, and a strided sample of its values."""
+    """Cheap identity of a grid plane: buffer address, layout, and a strided sample of its values (256 of them:
+    the check runs on every filter call, 8 planes of a 2400x3600 grid cost ~40 us; 2048 samples cost 280 us)."""
     if _is_torch(a):
         return ("t", a.data_ptr(), tuple(a.shape), tuple(a.stride()), str(a.dtype), a._version, str(a.device))
     n = a.size
     flat = a.reshape(-1) if a.flags.c_contiguous else a.ravel()
-    step = max(1, n // 2048)
-    sample = flat[::step]
-    return ("n", a.__array_interface__["data"][0], a.shape, a.strides, a.dtype.str,
-            hash(np.ascontiguousarray(sample).tobytes()))
+    sample = flat[:: max(1, n // 256)]
+    return ("n", a.__array_interface__["data"][0], a.shape, a.strides, a.dtype.str, hash(sample.tobytes()))
 
 
 class _PlanCache:
