@@ -191,6 +191,14 @@ void gcmf_plan_destroy(gcmf_plan *pl) {
   if (pl->ev0) (void)hipEventDestroy(pl->ev0);
   if (pl->ev1) (void)hipEventDestroy(pl->ev1);
   if (pl->ev_busy) (void)hipEventDestroy(pl->ev_busy);
+  if (pl->s_in) { (void)hipStreamSynchronize(pl->s_in); (void)hipStreamDestroy(pl->s_in); }
+  if (pl->s_out) { (void)hipStreamSynchronize(pl->s_out); (void)hipStreamDestroy(pl->s_out); }
+  for (int q = 0; q < 2; ++q) {
+    if (pl->ev_in[q]) (void)hipEventDestroy(pl->ev_in[q]);
+    if (pl->ev_cmp[q]) (void)hipEventDestroy(pl->ev_cmp[q]);
+    if (pl->ev_out[q]) (void)hipEventDestroy(pl->ev_out[q]);
+  }
+  if (pl->stage) (void)hipFree(pl->stage);
   if (pl->stream) (void)hipStreamDestroy(pl->stream);
   delete pl;
 }
@@ -279,6 +287,7 @@ int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int 
     }                                                                                  \
   } while (0)
   if (const char *e = getenv("GCMF_CGRID_TILE")) pl->cgrid_tile = atoi(e);
+  if (const char *e = getenv("GCMF_HOST_CHUNK_MB")) pl->host_chunk_bytes = (size_t)(atof(e) * 1048576.0);
   PLAN_HIP(hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking));
   PLAN_HIP(hipEventCreate(&pl->ev0));
   PLAN_HIP(hipEventCreate(&pl->ev1));
@@ -476,25 +485,11 @@ int gcmf_prepare(gcmf_plan *pl, const void *const *in, void *const *out, int64_t
   return launch_prepare(pl, in, out, nbatch, (int)row_lo, (int)row_hi, (hipStream_t)stream);
 }
 
-// Shared driver of gcmf_apply and gcmf_laplacian.
-static int run_whole(gcmf_plan *pl, const double *p, int n_steps, double c, const void *const *in, void *const *out,
-                     int64_t nbatch, uint32_t flags, void *stream, bool lapl_only) {
-  if (!pl || !in || !out || nbatch < 0 || (!lapl_only && (!p || n_steps < 1))) {
-    set_error("gcmf_apply: bad argument");
-    return GCMF_ERR_INVALID_ARG;
-  }
-  for (int k = 0; k < pl->ncomp; ++k)
-    if (!in[k] || !out[k]) {
-      set_error("gcmf_apply: null component pointer");
-      return GCMF_ERR_INVALID_ARG;
-    }
-  if (!pl->full) {
-    set_error("gcmf_apply / gcmf_laplacian need a plan covering the whole grid; use gcmf_cheb_step on row slabs");
-    return GCMF_ERR_INVALID_ARG;
-  }
-  if (nbatch == 0) return GCMF_OK;
-  std::lock_guard<std::mutex> lk(pl->mu);
-  GCMF_HIP(hipSetDevice(pl->d.device));
+// Shared driver of gcmf_apply and gcmf_laplacian; the plan's mutex is held and the device is current.
+// `timed` = false: the caller (the pipelined host path) brackets the launches with the timing events itself.
+static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double c, const void *const *in,
+                            void *const *out, int64_t nbatch, uint32_t flags, void *stream, bool lapl_only,
+                            bool timed) {
   const bool on_dev = flags & GCMF_DEVICE_PTRS;
   // device pointers: run on exactly the caller's stream (NULL = the HIP default stream) so the work is
   // ordered with the caller's own kernels; host pointers: the plan's private stream unless one is given
@@ -547,7 +542,8 @@ static int run_whole(gcmf_plan *pl, const double *p, int n_steps, double c, cons
   }
   const int rows = (int)pl->rows_alloc;
   int launches = 0;
-  if (pl->timing) GCMF_HIP(hipEventRecord(pl->ev0, s));
+  const bool timing = pl->timing && timed;
+  if (timing) GCMF_HIP(hipEventRecord(pl->ev0, s));
   if (lapl_only) {
     StepArgs a{};
     for (int k = 0; k < nc; ++k) { a.t1[k] = din[k]; a.t0[k] = dout[k]; a.fb_out[k] = nullptr; }
@@ -686,20 +682,128 @@ static int run_whole(gcmf_plan *pl, const double *p, int n_steps, double c, cons
     }
     }
   }
-  if (pl->timing) GCMF_HIP(hipEventRecord(pl->ev1, s));
+  if (timing) GCMF_HIP(hipEventRecord(pl->ev1, s));
   GCMF_HIP(hipEventRecord(pl->ev_busy, s));
   pl->busy_valid = true;
-  pl->last_launches = launches;
+  pl->last_launches = timed ? launches : pl->last_launches + launches;
   if (!on_dev) {
     for (int k = 0; k < nc; ++k)
       GCMF_HIP(hipMemcpyAsync(out[k], dout[k], ncell * fbs, hipMemcpyDeviceToHost, s));
     GCMF_HIP(hipStreamSynchronize(s));
   }
-  if (pl->timing) {
+  if (timing) {
     GCMF_HIP(hipEventSynchronize(pl->ev1));
     GCMF_HIP(hipEventElapsedTime(&pl->last_ms, pl->ev0, pl->ev1));
   }
   return GCMF_OK;
+}
+
+// Host pointers and a batch of fields: the batch is cut into chunks of ~32 MB per component that stream through two
+// staging slots in HBM -- upload of chunk k+1 and download of chunk k-1 run on their own streams while chunk k is
+// filtered ("overlap H2D of chunk k+1 with compute of chunk k").  The host issues upload(k+1) and the
+// launches of chunk k+1 BEFORE download(k), so that a blocking download into pageable memory still overlaps with compute.
+static int run_host_pipelined(gcmf_plan *pl, const double *p, int n_steps, double c, const void *const *in,
+                              void *const *out, int64_t nbatch, uint32_t flags, void *stream, bool lapl_only,
+                              int64_t chunk_nb) {
+  const int nc = pl->ncomp;
+  const bool f32 = pl->d.dtype == GCMF_F32;
+  const size_t ts = dtype_size(pl->d.dtype);
+  const size_t fbs = lapl_only ? ts : ((f32 && !(flags & GCMF_OUT_F32)) ? 8 : ts);
+  const size_t cell = (size_t)pl->d.ny * pl->d.nx;
+  const size_t szI = align_up((size_t)chunk_nb * cell * ts, 256), szO = align_up((size_t)chunk_nb * cell * fbs, 256);
+  const size_t need = (size_t)nc * 2 * (szI + szO);
+  if (need > pl->stage_bytes) {
+    if (pl->stage) GCMF_HIP(hipFree(pl->stage));
+    pl->stage = nullptr;
+    pl->stage_bytes = 0;
+    GCMF_HIP(hipMalloc(&pl->stage, need));
+    pl->stage_bytes = need;
+  }
+  if (!pl->s_in) {
+    GCMF_HIP(hipStreamCreateWithFlags(&pl->s_in, hipStreamNonBlocking));
+    GCMF_HIP(hipStreamCreateWithFlags(&pl->s_out, hipStreamNonBlocking));
+    for (int q = 0; q < 2; ++q) {
+      GCMF_HIP(hipEventCreateWithFlags(&pl->ev_in[q], hipEventDisableTiming));
+      GCMF_HIP(hipEventCreateWithFlags(&pl->ev_cmp[q], hipEventDisableTiming));
+      GCMF_HIP(hipEventCreateWithFlags(&pl->ev_out[q], hipEventDisableTiming));
+    }
+  }
+  hipStream_t s_cmp = stream ? (hipStream_t)stream : pl->stream;
+  char *base = (char *)pl->stage;
+  auto In = [&](int slot, int k) { return base + ((size_t)(slot * nc + k)) * szI; };
+  auto Out = [&](int slot, int k) { return base + (size_t)2 * nc * szI + ((size_t)(slot * nc + k)) * szO; };
+  const int64_t nchunks = (nbatch + chunk_nb - 1) / chunk_nb;
+  auto nb_of = [&](int64_t ch) { return ch == nchunks - 1 ? nbatch - ch * chunk_nb : chunk_nb; };
+  const uint32_t dflags = flags | GCMF_DEVICE_PTRS;
+  int rc = GCMF_OK;
+  pl->last_launches = 0;
+
+  auto upload_and_launch = [&](int64_t ch) -> int {
+    const int slot = (int)(ch & 1);
+    const int64_t nb = nb_of(ch);
+    if (ch >= 2) GCMF_HIP(hipStreamWaitEvent(pl->s_in, pl->ev_cmp[slot], 0));  // In[slot] was read by chunk ch-2
+    for (int k = 0; k < nc; ++k)
+      GCMF_HIP(hipMemcpyAsync(In(slot, k), (const char *)in[k] + (size_t)ch * chunk_nb * cell * ts, (size_t)nb * cell * ts,
+                              hipMemcpyHostToDevice, pl->s_in));
+    GCMF_HIP(hipEventRecord(pl->ev_in[slot], pl->s_in));
+    GCMF_HIP(hipStreamWaitEvent(s_cmp, pl->ev_in[slot], 0));
+    if (ch >= 2) GCMF_HIP(hipStreamWaitEvent(s_cmp, pl->ev_out[slot], 0));  // Out[slot] was drained by chunk ch-2
+    if (ch == 0 && pl->timing) GCMF_HIP(hipEventRecord(pl->ev0, s_cmp));
+    const void *din[2] = {In(slot, 0), nc > 1 ? In(slot, 1) : nullptr};
+    void *dout[2] = {Out(slot, 0), nc > 1 ? Out(slot, 1) : nullptr};
+    int r = run_whole_locked(pl, p, n_steps, c, din, dout, nb, dflags, (void *)s_cmp, lapl_only, false);
+    if (r) return r;
+    if (ch == nchunks - 1 && pl->timing) GCMF_HIP(hipEventRecord(pl->ev1, s_cmp));
+    GCMF_HIP(hipEventRecord(pl->ev_cmp[slot], s_cmp));
+    return GCMF_OK;
+  };
+  auto download = [&](int64_t ch) -> int {
+    const int slot = (int)(ch & 1);
+    const int64_t nb = nb_of(ch);
+    GCMF_HIP(hipStreamWaitEvent(pl->s_out, pl->ev_cmp[slot], 0));
+    for (int k = 0; k < nc; ++k)
+      GCMF_HIP(hipMemcpyAsync((char *)out[k] + (size_t)ch * chunk_nb * cell * fbs, Out(slot, k), (size_t)nb * cell * fbs,
+                              hipMemcpyDeviceToHost, pl->s_out));
+    GCMF_HIP(hipEventRecord(pl->ev_out[slot], pl->s_out));
+    return GCMF_OK;
+  };
+
+  if ((rc = upload_and_launch(0))) return rc;
+  for (int64_t ch = 0; ch < nchunks; ++ch) {
+    if (ch + 1 < nchunks && (rc = upload_and_launch(ch + 1))) return rc;
+    if ((rc = download(ch))) return rc;
+  }
+  GCMF_HIP(hipStreamSynchronize(pl->s_out));
+  GCMF_HIP(hipStreamSynchronize(s_cmp));
+  if (pl->timing) GCMF_HIP(hipEventElapsedTime(&pl->last_ms, pl->ev0, pl->ev1));
+  return GCMF_OK;
+}
+
+static int run_whole(gcmf_plan *pl, const double *p, int n_steps, double c, const void *const *in, void *const *out,
+                     int64_t nbatch, uint32_t flags, void *stream, bool lapl_only) {
+  if (!pl || !in || !out || nbatch < 0 || (!lapl_only && (!p || n_steps < 1))) {
+    set_error("gcmf_apply: bad argument");
+    return GCMF_ERR_INVALID_ARG;
+  }
+  for (int k = 0; k < pl->ncomp; ++k)
+    if (!in[k] || !out[k]) {
+      set_error("gcmf_apply: null component pointer");
+      return GCMF_ERR_INVALID_ARG;
+    }
+  if (!pl->full) {
+    set_error("gcmf_apply / gcmf_laplacian need a plan covering the whole grid; use gcmf_cheb_step on row slabs");
+    return GCMF_ERR_INVALID_ARG;
+  }
+  if (nbatch == 0) return GCMF_OK;
+  std::lock_guard<std::mutex> lk(pl->mu);
+  GCMF_HIP(hipSetDevice(pl->d.device));
+  if (!(flags & GCMF_DEVICE_PTRS) && nbatch > 1 && pl->host_chunk_bytes > 0) {
+    const size_t entry = (size_t)pl->d.ny * pl->d.nx * dtype_size(pl->d.dtype);
+    int64_t chunk_nb = (int64_t)(pl->host_chunk_bytes / entry);
+    if (chunk_nb < 1) chunk_nb = 1;
+    if (chunk_nb < nbatch) return run_host_pipelined(pl, p, n_steps, c, in, out, nbatch, flags, stream, lapl_only, chunk_nb);
+  }
+  return run_whole_locked(pl, p, n_steps, c, in, out, nbatch, flags, stream, lapl_only, true);
 }
 
 int gcmf_apply(gcmf_plan *pl, const double *p, int n_steps, double c, const void *const *in, void *const *out,

@@ -116,6 +116,12 @@ struct gcmf_plan {
   hipStream_t side = nullptr;           // the band's early steps run here, concurrently with the blocked launch
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t stream = nullptr;
+  // pipelined host path (batched host arrays): staging slots, upload / download streams, per-slot events
+  void *stage = nullptr;
+  size_t stage_bytes = 0;
+  size_t host_chunk_bytes = 32u << 20;  // per component and chunk; 0 = no pipelining (env GCMF_HOST_CHUNK_MB)
+  hipStream_t s_in = nullptr, s_out = nullptr;
+  hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_busy = nullptr;  // end of the last gcmf_apply that used the plan's work buffers
   bool busy_valid = false;
