@@ -120,6 +120,7 @@ struct gcmf_plan {
   void *stage = nullptr;
   size_t stage_bytes = 0;
   size_t host_chunk_bytes = 32u << 20;  // per component and chunk; 0 = no pipelining (env GCMF_HOST_CHUNK_MB)
+  int host_register = 1;                // page-lock the caller's input during a pipelined call (env GCMF_HOST_REGISTER)
   hipStream_t s_in = nullptr, s_out = nullptr;
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
