@@ -566,8 +566,8 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
       while (k <= n_steps) {
         const int left = n_steps - k + 1;
         int S = 1;
-        const int cand[5] = {8, 6, 4, 3, 2};
-        for (int q = 0; q < 5; ++q)  // largest depth that does not strand a lone single step at the end
+        const int cand[7] = {8, 7, 6, 5, 4, 3, 2};
+        for (int q = 0; q < 7; ++q)  // largest depth that does not strand a lone single step at the end
           if (cand[q] <= left && left - cand[q] != 1 && cand[q] <= pl->multi_s && multi_supported(pl, cand[q])) {
             S = cand[q];
             break;

@@ -423,7 +423,9 @@ template <typename T, typename FB, int KIND> static int launch_multi_k(gcmf_plan
     case 2: return launch_multi_s<T, FB, KIND, 2, 2>(pl, a, s);
     case 3: return launch_multi_s<T, FB, KIND, 3, 2>(pl, a, s);
     case 4: return pl->prefetch_rows == 1 ? launch_multi_s<T, FB, KIND, 4, 1>(pl, a, s) : launch_multi_s<T, FB, KIND, 4, 2>(pl, a, s);
+    case 5: return launch_multi_s<T, FB, KIND, 5, 1>(pl, a, s);  // 5 and 7 serve remainders (63 = 7 x 8 + 7)
     case 6: return pl->prefetch_rows == 2 ? launch_multi_s<T, FB, KIND, 6, 2>(pl, a, s) : launch_multi_s<T, FB, KIND, 6, 1>(pl, a, s);
+    case 7: return launch_multi_s<T, FB, KIND, 7, 1>(pl, a, s);
     case 8:
       // one wave per SIMD is issue-bound, not latency-bound: a shallower prefetch frees registers (fewer
       // VGPR<->AGPR moves) and measures 4-5 % faster than 2 rows in flight
@@ -447,7 +449,7 @@ template <typename T, typename FB> static int launch_multi_t(gcmf_plan *pl, cons
 
 bool multi_supported(const gcmf_plan *pl, int S) {
   if (pl->ncomp != 1) return false;
-  if (!(S == 2 || S == 3 || S == 4 || S == 6 || S == 8)) return false;
+  if (S < 2 || S > 8) return false;
   const int vec = pl->d.dtype == GCMF_F64 ? 2 : 4;
   if (pl->g.nx % vec) return false;
   // the tripole seam couples mirrored columns: its top S rows are advanced by single steps (advance_multi)

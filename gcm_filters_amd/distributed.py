@@ -262,7 +262,7 @@ class SlabFilter:
         self.exchanges += 1
 
     # -- the filter ----------------------------------------------------------------------------
-    MULTI_DEPTHS = (8, 6, 4, 3, 2)  # scalar kinds support all of them, the C-grid 4 / 3 / 2 (f64: 2)
+    MULTI_DEPTHS = (8, 7, 6, 5, 4, 3, 2)  # scalar kinds support all of them, the vector kinds 4 / 3 / 2
 
     def apply_local(self, local: Sequence):
         """Filter this rank's rows.  `local`: ncomp tensors (nbatch, rows_owned, nx) on the device.  Returns

@@ -160,7 +160,7 @@ int gcmf_cheb_step(gcmf_plan *plan, const void *const *t1, const void *const *t2
                    int64_t row_lo, int64_t row_hi, void *stream);
 
 /*
- * S recurrence steps in ONE pass over HBM (temporal blocking, scalar grid types; S in {2,3,4,6,8}):
+ * S recurrence steps in ONE pass over HBM (temporal blocking, scalar grid types; S in 2..8):
  *   u = T_{k-1}, v = T_{k-2} (ignored with GCMF_STEP_FIRST)  ->  uo = T_{k-1+S}, vo = T_{k-2+S}
  *   fbar_out = fbar_in + sum_t pk[t] T_{k+t}  (t = 0..S-1; with FIRST: p0*T_0 + pk[0]*T_1 + ...)
  * on rows [row_lo, row_hi) of the slab allocation; the inputs must be valid on [row_lo-S, row_hi+S) (clipped
@@ -200,7 +200,7 @@ int gcmf_set_timing(gcmf_plan *plan, int enabled);
 
 /* Tunables: rows marched per wave of the single-step kernel (0 keeps the default); XCD-aware tile order
  * (1 on, 0 off, <0 keep); temporal blocking: low byte = recurrence steps fused per HBM pass (1 = off,
- * 2,3,4,6,8), higher bits = rows per wave strip (0 = auto); 0 keeps the default. */
+ * 2..8), higher bits = rows per wave strip (0 = auto); 0 keeps the default. */
 int gcmf_set_tuning(gcmf_plan *plan, int rows_per_wave, int xcd_remap, int multi);
 
 /* Last error text of the calling thread (never NULL). */

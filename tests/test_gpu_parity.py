@@ -337,7 +337,7 @@ def test_device_resident_tensors():
     ("TRIPOLAR_POP_WITH_LAND", (60, 160), "f8"), ("TRIPOLAR_REGULAR_WITH_LAND_AREA_WEIGHTED", (41, 264), "f8"),
     ("TRIPOLAR_POP_WITH_LAND", (30, 128), "f4"),
 ])
-@pytest.mark.parametrize("S,strip", [(2, 0), (3, 0), (4, 0), (4, 7), (6, 0), (8, 0), (8, 5)])
+@pytest.mark.parametrize("S,strip", [(2, 0), (3, 0), (4, 0), (4, 7), (5, 0), (6, 0), (7, 0), (8, 0), (8, 5)])
 def test_temporal_blocking_bit_identical(grid, shape, dt, S, strip):
     from gcm_filters_amd import _lib
     f, gv = T.scalar_case(grid, shape)
