@@ -223,3 +223,26 @@ def test_dataarray_with_grid_vars_and_vector(xr_model):
     wu, wv = O.filter_func_vec(O.make_spec(5.0, 1.0, "TAPER", n_steps=10), "VECTOR_B_GRID", u, v, gvv)
     np.testing.assert_allclose(uo.data, wu, rtol=1e-12)
     np.testing.assert_allclose(vo.data, wv, rtol=1e-12)
+
+
+def test_plan_cache_fingerprint_and_host_outputs():
+    """Host-side plumbing that runs on every call: the plan-cache key of a grid plane (address, layout, 256-value
+    sample) and the result allocator (page-locked pool on a GPU box, plain numpy here)."""
+    from gcm_filters_amd import kernels as K
+    a = np.arange(40 * 64, dtype=np.float64).reshape(40, 64)
+    fa = K._fingerprint(a)
+    assert fa == K._fingerprint(a)                       # stable
+    assert fa != K._fingerprint(a.copy())                # another buffer
+    assert fa != K._fingerprint(a.astype(np.float32))    # another dtype
+    assert K._fingerprint(a[:, ::2])[2:5] == ((40, 32), a[:, ::2].strides, "<f8")  # views keep their own layout
+    a[0, 0] += 1.0                                       # in-place edit of a sampled value is seen
+    assert fa != K._fingerprint(a)
+    big = np.zeros((600, 700))                           # > 256 samples: stride through the plane
+    fb = K._fingerprint(big)
+    big[-1, -1] = 1.0                                    # not necessarily sampled: only documented as "cheap check"
+    big[0, 0] = 2.0
+    assert fb != K._fingerprint(big)
+    out = K._host_output((3, 40, 64), np.float64)        # no HIP device here: ordinary array, right shape / dtype
+    assert out.shape == (3, 40, 64) and out.dtype == np.float64 and out.flags.c_contiguous and out.flags.writeable
+    small = K._host_output((4, 4), np.float32)
+    assert small.dtype == np.float32 and K._pinned_out >= 0
