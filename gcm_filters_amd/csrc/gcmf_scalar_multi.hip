@@ -179,10 +179,16 @@ __global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scal
     }
   };
 
-  // one level.  FLAGGED=false is the common case "no NaN/inf anywhere in this wave's windows": raw == sanitised.
-  auto level = [&](auto tt, auto flagged_c) {
+  // one level, in one of three wave-uniform modes:
+  //   0  no NaN / inf anywhere in this wave's windows: raw == sanitised, nothing to keep track of;
+  //   1  only NaN flags (ocean fields with NaN on land): a NaN cell stays NaN at every later level, so the arithmetic
+  //      runs on the sanitised values, a flagged cell's new window value is 0 and its flag is copied; its outputs
+  //      (states, fbar) are overwritten with NaN when they are stored -- no raw operands are rebuilt;
+  //   2  an inf is around: the raw operands are rebuilt from the flags (the general, slow form).
+  auto level = [&](auto tt, auto mode_c) {
     constexpr int t = decltype(tt)::value;
-    constexpr bool FLAGGED = decltype(flagged_c)::value;
+    constexpr int MODE = decltype(mode_c)::value;
+    constexpr bool FLAGGED = (MODE == 2);
     const T(&gS)[VEC] = G[t - 1][0];
     const T(&gC)[VEC] = G[t - 1][1];
     const T(&gN)[VEC] = G[t - 1][2];
@@ -248,7 +254,27 @@ __global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scal
       if (t == S - 1) out_v[k] = tk;
       if (t == S) out_u[k] = tk;
     }
-    if (t < S) {  // becomes the `new` row of this level's window
+    if (t < S && MODE == 1) {  // becomes the `new` row of this level's window; flagged cells: 0 and the same flag
+      unsigned nf = 0u;
+      bool odd = false;
+      const unsigned fx = (Rf[t - 1] >> (2 * VEC)) & OLD_MASK;  // flags of the centre row (NaN bits only in this mode)
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) odd = odd || (!((fx >> (2 * k)) & 1u) && !(mabs(tkv[k]) <= MLim<T>::big()));
+      if (__any(odd)) {  // a NaN / inf appeared on a cell that was finite: classify properly (next iteration: mode 2)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          unsigned f;
+          const T raw = ((fx >> (2 * k)) & 1u) ? (T)__builtin_nan("") : tkv[k];
+          G[t < S ? t : 0][2][k] = msan_flag(raw, f);
+          nf |= f << (2 * k);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) G[t < S ? t : 0][2][k] = ((fx >> (2 * k)) & 1u) ? T(0) : tkv[k];
+        nf = fx;
+      }
+      newflags[t < S ? t : 0] = nf;
+    } else if (t < S) {
       unsigned nf = 0u;
       bool odd = false;
 #pragma unroll
@@ -274,10 +300,10 @@ __global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scal
   // compiler's cross-level scheduling, which the one-wave-per-SIMD flux kernel needs more than it needs the saved
   // work (measured 330 -> 304 G with skipping), so it is enabled only where two waves share a SIMD.
   constexpr bool SKIP = (WavesPerSimd<T, KIND, S>::value == 2) && !GCMF_NO_SKIP;
-  auto level_all = [&](auto flagged_c, int r) {
+  auto level_all = [&](auto mode_c, int r) {
 #define GCMF_LEVEL(t_)                                                                           \
   if constexpr (S >= (t_)) {                                                                     \
-    if (!SKIP || (r - (t_) >= a - S + (t_) && r - (t_) < b + S - (t_))) level(std::integral_constant<int, (t_)>{}, flagged_c); \
+    if (!SKIP || (r - (t_) >= a - S + (t_) && r - (t_) < b + S - (t_))) level(std::integral_constant<int, (t_)>{}, mode_c); \
   }
     GCMF_LEVEL(1) GCMF_LEVEL(2) GCMF_LEVEL(3) GCMF_LEVEL(4) GCMF_LEVEL(5) GCMF_LEVEL(6) GCMF_LEVEL(7) GCMF_LEVEL(8)
 #undef GCMF_LEVEL
@@ -288,10 +314,24 @@ __global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scal
     unsigned anyf = newflags[0];
 #pragma unroll
     for (int t = 0; t < S; ++t) anyf |= Rf[t];
-    if (SAN && __any(anyf != 0u)) {
-      level_all(std::true_type{}, r);
+    const bool flagged_any = SAN && __any(anyf != 0u);
+    if (flagged_any) {
+      constexpr unsigned INF_BITS = 0xAAAAAAAAu;  // bit 1 of every 2-bit flag
+      // mode 1 only for the land-mask kinds: in the flux kernel (one wave per SIMD, 340+ registers) a third copy of the
+      // levels costs the finite path 7-9 % (scratch appears) and gains 3 % on NaN input
+      if (KIND != K_MASK || __any((anyf & INF_BITS) != 0u)) level_all(std::integral_constant<int, 2>{}, r);
+      else level_all(std::integral_constant<int, (KIND == K_MASK ? 1 : 2)>{}, r);
+      // a NaN cell's outputs are NaN (mode 1 computed them from sanitised operands; in mode 2 this is a no-op)
+      if (KIND == K_MASK) {
+        const unsigned fu = (Rf[S - 1] >> (2 * VEC)) & OLD_MASK, fv = (Rf[S >= 2 ? S - 2 : 0] >> (2 * VEC)) & OLD_MASK;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          if ((fu >> (2 * k)) & 1u) { out_u[k] = (T)__builtin_nan(""); Fq[S][k] = (FB)__builtin_nan(""); }
+          if ((fv >> (2 * k)) & 1u) out_v[k] = (T)__builtin_nan("");
+        }
+      }
     } else {
-      level_all(std::false_type{}, r);
+      level_all(std::integral_constant<int, 0>{}, r);
     }
 
     // stores: T_{k-1+S} row r-S, T_{k-2+S} row r-S+1, fbar row r-S

@@ -512,3 +512,39 @@ def test_pipelined_host_batches(grid, dt, monkeypatch):
     clear_plan_cache()
     for g, w in zip(list(got) + list(got_l), list(want) + list(want_l)):
         assert g.dtype == w.dtype and np.array_equal(g, w, equal_nan=True)
+
+
+@pytest.mark.parametrize("grid", ["REGULAR_WITH_LAND", "REGULAR_WITH_LAND_AREA_WEIGHTED",
+                                  "TRIPOLAR_REGULAR_WITH_LAND_AREA_WEIGHTED", "IRREGULAR_WITH_LAND"])
+@pytest.mark.parametrize("dt", ["f8", "f4"])
+def test_blocked_kernel_nan_and_inf_modes(grid, dt):
+    """The blocked kernel runs a wave in one of three modes per row (all finite / NaN flags only / an inf around).
+    NaN on land, NaN and +-inf on wet cells, far enough apart that different waves take different modes and switch
+    between them along their march: every depth must reproduce the single-step kernel bit for bit (NaN pattern incl.)."""
+    from gcm_filters_amd import _lib
+    shape = (96, 520)
+    f, gv = T.scalar_case(grid, shape)
+    f = np.where(gv["wet_mask"] == 0, np.nan, f)
+    wet = np.argwhere(gv["wet_mask"] == 1)
+    pick = lambda i: tuple(wet[(len(wet) * i) // 7])
+    f[pick(1)] = np.nan
+    f[pick(3)] = np.inf
+    f[pick(5)] = -np.inf
+    f = f.astype(dt)
+    gv = {k: v.astype(dt) for k, v in gv.items()}
+    dx = T.grid_dx_min(grid, gv) if O.DIMENSIONAL[grid] else 1.0
+    plan = ALL_KERNELS[GridType[grid]](**gv)._plan(_lib.dtype_code(dt), shape)
+    flt = Filter(filter_scale=2.0 * dx, dx_min=dx, n_steps=19, filter_shape=FilterShape.TAPER, grid_type=GridType[grid],
+                 grid_vars=gv)
+    try:
+        plan.set_tuning(multi_s=1)
+        with np.errstate(all="ignore"):
+            ref = flt.apply(f)
+        for S in (2, 4, 7, 8):
+            plan.set_tuning(multi_s=S)
+            got = flt.apply(f)
+            assert np.array_equal(np.isnan(ref), np.isnan(got)), (grid, dt, S)
+            assert np.array_equal(ref, got, equal_nan=True), (grid, dt, S)
+    finally:
+        plan.set_tuning(multi_s=8)
+    assert np.isnan(ref[gv["wet_mask"] == 0]).all() and np.isfinite(ref).sum() > ref.size // 3
