@@ -486,6 +486,8 @@ int gcmf_prepare(gcmf_plan *pl, const void *const *in, void *const *out, int64_t
   return launch_prepare(pl, in, out, nbatch, (int)row_lo, (int)row_hi, (hipStream_t)stream);
 }
 
+static const int64_t MAX_LAUNCH_BATCH = 32768;  // batch entries per launch (gridDim.y of the scalar kernels)
+
 // Shared driver of gcmf_apply and gcmf_laplacian; the plan's mutex is held and the device is current.
 // `timed` = false: the caller (the pipelined host path) brackets the launches with the timing events itself.
 static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double c, const void *const *in,
@@ -819,9 +821,32 @@ static int run_whole(gcmf_plan *pl, const double *p, int n_steps, double c, cons
     const size_t entry = (size_t)pl->d.ny * pl->d.nx * dtype_size(pl->d.dtype);
     int64_t chunk_nb = (int64_t)(pl->host_chunk_bytes / entry);
     if (chunk_nb < 1) chunk_nb = 1;
+    if (chunk_nb > MAX_LAUNCH_BATCH) chunk_nb = MAX_LAUNCH_BATCH;
     if (chunk_nb < nbatch) return run_host_pipelined(pl, p, n_steps, c, in, out, nbatch, flags, stream, lapl_only, chunk_nb);
   }
-  return run_whole_locked(pl, p, n_steps, c, in, out, nbatch, flags, stream, lapl_only, true);
+  if (nbatch <= MAX_LAUNCH_BATCH)
+    return run_whole_locked(pl, p, n_steps, c, in, out, nbatch, flags, stream, lapl_only, true);
+  // very long batches of small fields: the scalar kernels index the batch with gridDim.y (<= 65535)
+  const size_t cell = (size_t)pl->d.ny * pl->d.nx, ts = dtype_size(pl->d.dtype);
+  const size_t fbs = lapl_only ? ts : ((pl->d.dtype == GCMF_F32 && !(flags & GCMF_OUT_F32)) ? 8 : ts);
+  float ms_total = 0.f;
+  int launches = 0;
+  for (int64_t b0 = 0; b0 < nbatch; b0 += MAX_LAUNCH_BATCH) {
+    const int64_t nb = nbatch - b0 < MAX_LAUNCH_BATCH ? nbatch - b0 : MAX_LAUNCH_BATCH;
+    const void *in2[2] = {nullptr, nullptr};
+    void *out2[2] = {nullptr, nullptr};
+    for (int k = 0; k < pl->ncomp; ++k) {
+      in2[k] = (const char *)in[k] + (size_t)b0 * cell * ts;
+      out2[k] = (char *)out[k] + (size_t)b0 * cell * fbs;
+    }
+    int rc = run_whole_locked(pl, p, n_steps, c, in2, out2, nb, flags, stream, lapl_only, true);
+    if (rc) return rc;
+    ms_total += pl->last_ms;
+    launches += pl->last_launches;
+  }
+  pl->last_ms = ms_total;
+  pl->last_launches = launches;
+  return GCMF_OK;
 }
 
 int gcmf_apply(gcmf_plan *pl, const double *p, int n_steps, double c, const void *const *in, void *const *out,

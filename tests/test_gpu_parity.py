@@ -548,3 +548,19 @@ def test_blocked_kernel_nan_and_inf_modes(grid, dt):
     finally:
         plan.set_tuning(multi_s=8)
     assert np.isnan(ref[gv["wet_mask"] == 0]).all() and np.isfinite(ref).sum() > ref.size // 3
+
+
+def test_very_long_batch_of_small_fields():
+    """More batch entries than one launch can index (gridDim.y): the batch is cut into launches of 32768."""
+    import torch
+    shape, nb = (4, 8), 40000
+    _, gv = T.scalar_case("REGULAR_WITH_LAND", shape)
+    f = np.random.default_rng(3).random((nb,) + shape)
+    flt = Filter(filter_scale=4, dx_min=1, grid_type=GridType.REGULAR_WITH_LAND, grid_vars=gv)
+    got = flt.apply(torch.from_numpy(f).cuda()).cpu().numpy()
+    spec = O.make_spec(4, 1, "GAUSSIAN")
+    for b in (0, 32767, 32768, nb - 1):
+        want = O.filter_func(spec, "REGULAR_WITH_LAND", f[b], gv)
+        np.testing.assert_allclose(got[b], want, rtol=1e-12, atol=1e-15, err_msg=str(b))
+    host = flt.apply(f)            # host path (pipelined chunks are capped at the same size)
+    assert np.array_equal(host, got)
