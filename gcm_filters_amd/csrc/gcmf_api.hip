@@ -199,6 +199,7 @@ void gcmf_plan_destroy(gcmf_plan *pl) {
     if (pl->ev_out[q]) (void)hipEventDestroy(pl->ev_out[q]);
   }
   if (pl->stage) (void)hipFree(pl->stage);
+  if (pl->dev_p) (void)hipFree(pl->dev_p);
   if (pl->stream) (void)hipStreamDestroy(pl->stream);
   delete pl;
 }
@@ -289,6 +290,7 @@ int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int 
   if (const char *e = getenv("GCMF_CGRID_TILE")) pl->cgrid_tile = atoi(e);
   if (const char *e = getenv("GCMF_HOST_CHUNK_MB")) pl->host_chunk_bytes = (size_t)(atof(e) * 1048576.0);
   if (const char *e = getenv("GCMF_HOST_REGISTER")) pl->host_register = atoi(e);
+  if (const char *e = getenv("GCMF_ZERO_LAND")) pl->zero_land = atoi(e);
   PLAN_HIP(hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking));
   PLAN_HIP(hipEventCreate(&pl->ev0));
   PLAN_HIP(hipEventCreate(&pl->ev1));
@@ -515,6 +517,10 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
   const size_t oC = per; if (use_multi || use_vmulti) per += szT;
   const size_t oD = per; if (use_multi || use_vmulti) per += szT;
   const size_t oF = per; per += szF;
+  // flux kinds only: the land-mask kernels have a NaN-only mode that already makes NaN on land free, there the two
+  // extra passes would only cost (measured -6 %)
+  const bool zero_land = use_multi && pl->kind == K_FLUX && pl->zero_land && pl->lbits && pl->n_land > 0 && (pl->d.nx % 4) == 0 &&
+                         n_steps < 4096;  // k_land_fix keeps p in LDS
   const size_t oP = per; if (prep) per += szT;
   const size_t oIn = per; if (!on_dev) per += szT;
   const size_t oOut = per; if (!on_dev) per += szF;
@@ -565,6 +571,7 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
       void *pool[4] = {A[0], B[0], Cb[0], Db[0]};
       const void *u = x0[0], *v = nullptr;
       int k = 1;
+      bool land_zeroed = false;  // the first blocked launch kept the isolated cells out of the state
       while (k <= n_steps) {
         const int left = n_steps - k + 1;
         int S = 1;
@@ -584,11 +591,16 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
           m.u0 = u; m.v0 = v; m.uo = fr[0]; m.vo = fr[1];
           m.fb_in = F[0]; m.fb_out = is_last ? dout[0] : F[0];
           m.first = (k == 1); m.last = is_last; m.S = S; m.fb_is_f32 = fb32;
+
           for (int t = 0; t < S; ++t) m.pk[t] = p[k + t];
           m.p0 = p[0]; m.c = c; m.nbatch = nbatch; m.row_lo = 0; m.row_hi = rows;
           if ((rc = advance_multi(pl, m, s, &launches))) return rc;
           --launches;  // counted once more below
           u = fr[0]; v = fr[1];
+          if (k == 1 && zero_land && !is_last) {  // keep the isolated cells out of the state from here on
+            if ((rc = launch_zero_land(pl, fr[0], fr[1], nbatch, s))) return rc;
+            land_zeroed = true;
+          }
         } else {
           StepArgs a1{};
           a1.mode = (k == 1 ? GCMF_STEP_FIRST : 0u) | (is_last ? GCMF_STEP_LAST : 0u);
@@ -606,6 +618,23 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
         }
         ++launches;
         k += S;
+      }
+      if (land_zeroed) {  // the isolated cells' own polynomial, from the caller's untouched input
+        if (pl->dev_p_n < (size_t)n_steps + 1) {
+          if (pl->dev_p) GCMF_HIP(hipFree(pl->dev_p));
+          pl->dev_p = nullptr;
+          pl->dev_p_n = 0;
+          pl->host_p.clear();
+          GCMF_HIP(hipMalloc((void **)&pl->dev_p, ((size_t)n_steps + 1) * sizeof(double)));
+          pl->dev_p_n = (size_t)n_steps + 1;
+        }
+        // upload the coefficients only when they changed: a pageable upload stalls the host behind the stream
+        if (pl->host_p.size() != (size_t)n_steps + 1 || memcmp(pl->host_p.data(), p, pl->host_p.size() * sizeof(double)) != 0) {
+          pl->host_p.assign(p, p + n_steps + 1);
+          GCMF_HIP(hipStreamSynchronize(s));  // nothing may still read the old coefficients
+          GCMF_HIP(hipMemcpy(pl->dev_p, pl->host_p.data(), pl->host_p.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+        if ((rc = launch_land_fix(pl, din[0], dout[0], pl->dev_p, n_steps, c, fb32 ? 1 : 0, nbatch, s))) return rc;
       }
     } else if (use_vmulti) {
       // vector kinds: S = 2..4 steps per pass, (T_{k-1}, T_{k-2}) -> (T_{k+S-2}, T_{k+S-1}).  Neither output may overwrite

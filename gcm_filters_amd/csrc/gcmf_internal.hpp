@@ -135,6 +135,17 @@ struct gcmf_plan {
   int strip_rows = 0;  // rows per wave strip of that kernel (0 = auto)
   int prefetch_rows = 0;  // rows of operands in flight per wave (0 = default per S)
   int cgrid_tile = 0;     // 1: force the LDS-tile C-grid kernel instead of the streaming one (A/B testing)
+  // Land kept out of the state (whole-grid scalar plans): bit 0 of lbits[cell] = the cell exchanges with a neighbour.
+  // A cell that does not (land under a wet mask; a flux-form cell whose four faces are closed) has L = 0 and evolves
+  // on its own: gcmf_apply zeroes such cells in the two states the first blocked launch wrote -- NaN on land then never
+  // reaches the NaN / inf bookkeeping of the blocked kernels -- and writes their polynomial into the result with
+  // k_land_fix at the end.
+  const uint8_t *lbits = nullptr;
+  int64_t n_land = 0;
+  int zero_land = 1;      // env GCMF_ZERO_LAND=0 turns it off
+  double *dev_p = nullptr;   // p[0..n_steps] of the last filter, for k_land_fix
+  size_t dev_p_n = 0;
+  std::vector<double> host_p;
   std::mutex mu;
 };
 
@@ -163,6 +174,10 @@ inline int launch_vec_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s)
 int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launches);
 int launch_prepare(gcmf_plan *pl, const void *const *in, void *const *out, int64_t nbatch, int row_lo,
                    int row_hi, hipStream_t s);
+// the isolated cells' own polynomial, written over out (gcmf_landfix.hip); dp = p[0..n_steps] on the device
+int launch_zero_land(gcmf_plan *pl, void *a, void *b, int64_t nbatch, hipStream_t s);
+int launch_land_fix(gcmf_plan *pl, const void *in, void *out, const double *dp, int n_steps, double c, int fb_is_f32,
+                    int64_t nbatch, hipStream_t s);
 // plan-time precompute (gcmf_precompute.hip): fills pl->g from the raw global planes (device pointers)
 int precompute(gcmf_plan *pl, const void *const *dplanes, const void *const *hplanes_or_null);
 }  // namespace gcmf

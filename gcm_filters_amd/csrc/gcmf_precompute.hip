@@ -53,6 +53,33 @@ __global__ void k_pre_mask(const T *m, uint8_t *bits, int ny, int nx, int tripol
   }
 }
 
+// ---- cells that exchange nothing with their neighbours ---------------------------------------------------
+// flux form: all four faces of the cell are closed (and, on the tripole seam, the partner's face onto it)
+template <typename T>
+__global__ void k_pre_isolated(const T *cE, const T *cN, uint8_t *bits, int ny, int nx, int tripolar, int *count) {
+  int mine = 0;
+  CELL_LOOP(ny, nx) {
+    CELL_JI(nx)
+    const int iw = wrapi(i - 1, nx);
+    bool open = (AT(cE, j, i) != T(0)) || (AT(cE, j, iw) != T(0)) || (AT(cN, j, i) != T(0));
+    if (tripolar) {
+      if (j > 0) open = open || (AT(cN, j - 1, i) != T(0));
+      if (j == ny - 1) open = open || (AT(cN, ny - 1, nx - 1 - i) != T(0));
+    } else {
+      open = open || (AT(cN, wrapi(j - 1, ny), i) != T(0));
+    }
+    bits[q_] = open ? 1u : 0u;
+    if (!open) ++mine;
+  }
+  if (mine) atomicAdd(count, mine);
+}
+__global__ void k_count_land(const uint8_t *bits, long long n, int *count) {
+  int mine = 0;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x)
+    mine += (bits[q] & 1u) ? 0 : 1;
+  if (mine) atomicAdd(count, mine);
+}
+
 // ---- IRREGULAR_WITH_LAND: W/S-face form -> east/north-face coefficient planes ------------------------
 // reference: wflux = (g - W g)/dxw*dyw * (m*W m*kappa_w); L = (E wflux - wflux + N sflux - sflux)/area
 template <typename T>
@@ -368,6 +395,23 @@ template <typename T> static int precompute_t(gcmf_plan *pl, const void *const *
   }
   GCMF_HIP(hipGetLastError());
 
+  // whole-grid scalar plans: which cells never exchange with a neighbour (see gcmf_plan::lbits)
+  int *dcount = nullptr;
+  uint8_t *gisol = nullptr;
+  const bool flux_kind = (gt == GCMF_IRREGULAR_WITH_LAND || gt == GCMF_MOM5U || gt == GCMF_MOM5T || gt == GCMF_TRIPOLAR_POP_WITH_LAND);
+  if (pl->full && (gbits || flux_kind)) {
+    if ((rc = galloc((void **)&dcount, sizeof(int)))) return rc;
+    GCMF_HIP(hipMemsetAsync(dcount, 0, sizeof(int), s));
+    if (gbits) {
+      hipLaunchKernelGGL(k_count_land, grid, block, 0, s, gbits, (long long)plane, dcount);
+    } else {
+      if ((rc = dev_alloc(pl, (void **)&gisol, plane))) return rc;
+      hipLaunchKernelGGL(k_pre_isolated<T>, grid, block, 0, s, (const T *)gplanes[0], (const T *)gplanes[1], gisol, ny, nx,
+                         pl->tripolar ? 1 : 0, dcount);
+    }
+    GCMF_HIP(hipGetLastError());
+  }
+
   // validation results
   int flags = 0;
   GCMF_HIP(hipMemcpyAsync(&flags, dflags, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -402,6 +446,13 @@ template <typename T> static int precompute_t(gcmf_plan *pl, const void *const *
     void *slab = nullptr;
     if ((rc = cut_rows(pl, gbits, &slab, 1, s))) return rc;
     g.mbits = (const uint8_t *)slab;
+  }
+  if (dcount) {
+    int n_land = 0;
+    GCMF_HIP(hipMemcpyAsync(&n_land, dcount, sizeof(int), hipMemcpyDeviceToHost, s));
+    GCMF_HIP(hipStreamSynchronize(s));
+    pl->n_land = n_land;
+    pl->lbits = gisol ? gisol : g.mbits;  // a whole-grid plan's slab layout is the global layout
   }
   if (area_idx >= 0) {
     void *slab = nullptr;

@@ -564,3 +564,42 @@ def test_very_long_batch_of_small_fields():
         np.testing.assert_allclose(got[b], want, rtol=1e-12, atol=1e-15, err_msg=str(b))
     host = flt.apply(f)            # host path (pipelined chunks are capped at the same size)
     assert np.array_equal(host, got)
+
+
+@pytest.mark.parametrize("grid", ["IRREGULAR_WITH_LAND", "MOM5U", "MOM5T", "TRIPOLAR_POP_WITH_LAND"])
+@pytest.mark.parametrize("dt", ["f8", "f4"])
+def test_land_kept_out_of_the_state(grid, dt, monkeypatch):
+    """Flux kinds: cells whose four faces are closed are zeroed in the state after the first blocked launch and get their
+    (neighbour-free) polynomial from k_land_fix at the end.  Must equal the plain path bit for bit -- finite, NaN and
+    +-inf values on land, a batch, both step-count parities -- and the oracle within tolerance."""
+    from gcm_filters_amd.kernels import clear_plan_cache
+    shape = (64, 256)
+    f0, gv = T.scalar_case(grid, shape)
+    land = gv["wet_mask"] == 0
+    rng = np.random.default_rng(9)
+    f = np.stack([f0, np.where(land, np.nan, f0), np.where(land, 7.5 * rng.standard_normal(shape), f0)])
+    lj, li = np.argwhere(land)[len(np.argwhere(land)) // 2]
+    f[2, lj, li] = np.inf
+    f = f.astype(dt)
+    gv = {k: v.astype(dt) for k, v in gv.items()}
+    dx = T.grid_dx_min(grid, gv)
+    outs = {}
+    for z in ("1", "0"):
+        monkeypatch.setenv("GCMF_ZERO_LAND", z)
+        clear_plan_cache()
+        res = []
+        for n_steps in (8, 13):
+            flt = Filter(filter_scale=2.0 * dx, dx_min=dx, n_steps=n_steps, filter_shape=FilterShape.TAPER,
+                         grid_type=GridType[grid], grid_vars=gv)
+            with np.errstate(all="ignore"):
+                res.append(flt.apply(f))
+        outs[z] = res
+    clear_plan_cache()
+    for a, b in zip(outs["1"], outs["0"]):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert np.isnan(outs["1"][0][1][land]).all() and np.isfinite(outs["1"][0][1][~land]).all()
+    spec = O.make_spec(2.0 * dx, dx, "TAPER", n_steps=13)
+    with np.errstate(all="ignore"):
+        want = O.filter_func(spec, grid, f[:2], gv)
+    assert np.array_equal(np.isnan(outs["1"][1][:2]), np.isnan(want))
+    assert rel_err(outs["1"][1][:2], want) <= (1e-4 if dt == "f4" else 1e-11)
