@@ -132,7 +132,12 @@ int gcmf_plan_rows(const gcmf_plan *plan, int64_t *rows_alloc, int64_t *first_ow
  * Only valid on single-slab plans (row_begin = 0, row_end = ny).
  * `stream`: hipStream_t to run on.  With GCMF_DEVICE_PTRS the work is enqueued asynchronously on exactly
  * that stream (NULL = the HIP default stream), ordered with the caller's other work on it.  With host
- * pointers the call stages through HBM and is synchronous (NULL = a private stream of the plan).
+ * pointers the call stages through HBM and is synchronous (NULL = a private stream of the plan); a batch of host
+ * fields is cut into chunks whose upload, filtering and download overlap, and the input range is page-locked
+ * (hipHostRegister, best effort) while the call runs -- see DESIGN.md section 6 and the GCMF_HOST_* variables.
+ * Scheduling is internal: up to 8 (vector kinds: 4) recurrence steps per pass over HBM; flux-form scalar grids keep
+ * cells with four closed faces (land) out of the recurrence state and add their neighbour-free polynomial at the end.
+ * The result is the reference's for every cell, land included.
  */
 int gcmf_apply(gcmf_plan *plan, const double *p, int n_steps, double c, const void *const *in,
                void *const *out, int64_t nbatch, uint32_t flags, void *stream);
