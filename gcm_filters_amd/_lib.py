@@ -29,6 +29,7 @@ EXPORTS = [
     "gcmf_grid_is_tripolar", "gcmf_plan_rows", "gcmf_apply", "gcmf_laplacian", "gcmf_cheb_step", "gcmf_prepare",
     "gcmf_last_timing", "gcmf_set_timing", "gcmf_set_tuning", "gcmf_last_error", "gcmf_version",
     "gcmf_multi_supported", "gcmf_cheb_multi", "gcmf_multi_supported_vec", "gcmf_cheb_multi_vec",
+    "gcmf_has_land", "gcmf_zero_land", "gcmf_land_fix",
 ]
 
 
@@ -88,6 +89,12 @@ def load() -> C.CDLL:
         lib.gcmf_cheb_multi_vec.argtypes = [vp, vpp, vpp, vpp, vpp, vpp, vpp, C.POINTER(C.c_double), C.c_int, C.c_double,
                                             C.c_double, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, C.c_int64, vp]
         lib.gcmf_cheb_multi_vec.restype = C.c_int
+        lib.gcmf_has_land.argtypes = [vp]
+        lib.gcmf_has_land.restype = C.c_int
+        lib.gcmf_zero_land.argtypes = [vp, vpp, vpp, C.c_int64, vp]
+        lib.gcmf_zero_land.restype = C.c_int
+        lib.gcmf_land_fix.argtypes = [vp, C.POINTER(C.c_double), C.c_int, C.c_double, vpp, vpp, C.c_int64, C.c_uint32, vp]
+        lib.gcmf_land_fix.restype = C.c_int
         lib.gcmf_prepare.argtypes = [vp, vpp, vpp, C.c_int64, C.c_int64, C.c_int64, vp]
         lib.gcmf_prepare.restype = C.c_int
         lib.gcmf_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
@@ -223,6 +230,17 @@ class Plan:
                                          pk.ctypes.data_as(C.POINTER(C.c_double)), len(pk), float(p0), float(c),
                                          int(mode), OUT_F32 if out_f32 else 0, int(nbatch), int(row_lo), int(row_hi),
                                          C.c_void_p(stream or None)))
+
+    def has_land(self) -> bool:
+        return bool(load().gcmf_has_land(self._h))
+
+    def zero_land(self, a, b, nbatch, *, stream: int = 0):
+        check(load().gcmf_zero_land(self._h, _ptr_array(a), _ptr_array(b), int(nbatch), C.c_void_p(stream or None)))
+
+    def land_fix(self, p, c, ins, outs, nbatch, *, out_f32: bool = False, stream: int = 0):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        check(load().gcmf_land_fix(self._h, p.ctypes.data_as(C.POINTER(C.c_double)), len(p) - 1, float(c), _ptr_array(ins),
+                                   _ptr_array(outs), int(nbatch), OUT_F32 if out_f32 else 0, C.c_void_p(stream or None)))
 
     def prepare(self, ins, outs, nbatch, row_lo, row_hi, *, stream: int = 0):
         check(load().gcmf_prepare(self._h, _ptr_array(ins), _ptr_array(outs), int(nbatch), int(row_lo), int(row_hi),

@@ -59,6 +59,26 @@ static int ensure_work(gcmf_plan *pl, size_t bytes) {
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// p[0..n_steps] on the device for k_land_fix; uploaded only when it changed (a pageable upload stalls the host behind
+// the stream)
+static int ensure_dev_p(gcmf_plan *pl, const double *p, int n_steps, hipStream_t s) {
+  const size_t n = (size_t)n_steps + 1;
+  if (pl->dev_p_n < n) {
+    if (pl->dev_p) GCMF_HIP(hipFree(pl->dev_p));
+    pl->dev_p = nullptr;
+    pl->dev_p_n = 0;
+    pl->host_p.clear();
+    GCMF_HIP(hipMalloc((void **)&pl->dev_p, n * sizeof(double)));
+    pl->dev_p_n = n;
+  }
+  if (pl->host_p.size() != n || memcmp(pl->host_p.data(), p, n * sizeof(double)) != 0) {
+    pl->host_p.assign(p, p + n);
+    GCMF_HIP(hipStreamSynchronize(s));  // nothing may still read the old coefficients
+    GCMF_HIP(hipMemcpy(pl->dev_p, pl->host_p.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  }
+  return GCMF_OK;
+}
+
 // One temporally blocked advance of S steps on rows [row_lo, row_hi) of a scalar plan.
 //
 // Tripolar grids: the fold couples column i of the top row with column nx-1-i, i.e. with a DIFFERENT wave of the
@@ -479,6 +499,32 @@ int gcmf_cheb_multi_vec(gcmf_plan *pl, const void *const *u, const void *const *
   return launch_vec_multi(pl, m, (hipStream_t)stream);
 }
 
+static bool land_ok(const gcmf_plan *pl, int n_steps) {
+  return pl && pl->kind == K_FLUX && pl->zero_land && pl->lbits && pl->n_land > 0 && (pl->d.nx % 4) == 0 && n_steps < 4096;
+}
+
+int gcmf_has_land(const gcmf_plan *pl) { return land_ok(pl, 0) ? 1 : 0; }
+
+int gcmf_zero_land(gcmf_plan *pl, void *const *a, void *const *b, int64_t nbatch, void *stream) {
+  if (!pl || !a || !b || !a[0] || !b[0] || nbatch < 1) return GCMF_ERR_INVALID_ARG;
+  if (!land_ok(pl, 0)) return GCMF_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> lk(pl->mu);
+  GCMF_HIP(hipSetDevice(pl->d.device));
+  return launch_zero_land(pl, a[0], b[0], nbatch, (hipStream_t)stream);
+}
+
+int gcmf_land_fix(gcmf_plan *pl, const double *p, int n_steps, double c, const void *const *in, void *const *out,
+                  int64_t nbatch, uint32_t flags, void *stream) {
+  if (!pl || !p || !in || !out || !in[0] || !out[0] || n_steps < 1 || nbatch < 1) return GCMF_ERR_INVALID_ARG;
+  if (!land_ok(pl, n_steps)) return GCMF_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> lk(pl->mu);
+  GCMF_HIP(hipSetDevice(pl->d.device));
+  int rc = ensure_dev_p(pl, p, n_steps, (hipStream_t)stream);
+  if (rc) return rc;
+  const int fb32 = (pl->d.dtype == GCMF_F32 && (flags & GCMF_OUT_F32)) ? 1 : 0;
+  return launch_land_fix(pl, in[0], out[0], pl->dev_p, n_steps, c, fb32, nbatch, (hipStream_t)stream);
+}
+
 int gcmf_prepare(gcmf_plan *pl, const void *const *in, void *const *out, int64_t nbatch, int64_t row_lo,
                  int64_t row_hi, void *stream) {
   if (!pl || !in || !out) return GCMF_ERR_INVALID_ARG;
@@ -519,8 +565,7 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
   const size_t oF = per; per += szF;
   // flux kinds only: the land-mask kernels have a NaN-only mode that already makes NaN on land free, there the two
   // extra passes would only cost (measured -6 %)
-  const bool zero_land = use_multi && pl->kind == K_FLUX && pl->zero_land && pl->lbits && pl->n_land > 0 && (pl->d.nx % 4) == 0 &&
-                         n_steps < 4096;  // k_land_fix keeps p in LDS
+  const bool zero_land = use_multi && land_ok(pl, n_steps);  // n_steps < 4096: k_land_fix keeps p in LDS
   const size_t oP = per; if (prep) per += szT;
   const size_t oIn = per; if (!on_dev) per += szT;
   const size_t oOut = per; if (!on_dev) per += szF;
@@ -620,20 +665,7 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
         k += S;
       }
       if (land_zeroed) {  // the isolated cells' own polynomial, from the caller's untouched input
-        if (pl->dev_p_n < (size_t)n_steps + 1) {
-          if (pl->dev_p) GCMF_HIP(hipFree(pl->dev_p));
-          pl->dev_p = nullptr;
-          pl->dev_p_n = 0;
-          pl->host_p.clear();
-          GCMF_HIP(hipMalloc((void **)&pl->dev_p, ((size_t)n_steps + 1) * sizeof(double)));
-          pl->dev_p_n = (size_t)n_steps + 1;
-        }
-        // upload the coefficients only when they changed: a pageable upload stalls the host behind the stream
-        if (pl->host_p.size() != (size_t)n_steps + 1 || memcmp(pl->host_p.data(), p, pl->host_p.size() * sizeof(double)) != 0) {
-          pl->host_p.assign(p, p + n_steps + 1);
-          GCMF_HIP(hipStreamSynchronize(s));  // nothing may still read the old coefficients
-          GCMF_HIP(hipMemcpy(pl->dev_p, pl->host_p.data(), pl->host_p.size() * sizeof(double), hipMemcpyHostToDevice));
-        }
+        if ((rc = ensure_dev_p(pl, p, n_steps, s))) return rc;
         if ((rc = launch_land_fix(pl, din[0], dout[0], pl->dev_p, n_steps, c, fb32 ? 1 : 0, nbatch, s))) return rc;
       }
     } else if (use_vmulti) {

@@ -135,7 +135,7 @@ struct gcmf_plan {
   int strip_rows = 0;  // rows per wave strip of that kernel (0 = auto)
   int prefetch_rows = 0;  // rows of operands in flight per wave (0 = default per S)
   int cgrid_tile = 0;     // 1: force the LDS-tile C-grid kernel instead of the streaming one (A/B testing)
-  // Land kept out of the state (whole-grid scalar plans): bit 0 of lbits[cell] = the cell exchanges with a neighbour.
+  // Land kept out of the state (scalar plans; slab-row layout): bit 0 of lbits[cell] = the cell exchanges with a neighbour.
   // A cell that does not (land under a wet mask; a flux-form cell whose four faces are closed) has L = 0 and evolves
   // on its own: gcmf_apply zeroes such cells in the two states the first blocked launch wrote -- NaN on land then never
   // reaches the NaN / inf bookkeeping of the blocked kernels -- and writes their polynomial into the result with

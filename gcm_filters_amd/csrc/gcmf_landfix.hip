@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_zero_land(T *a, T *b, const uint8_t *lb
 }
 
 int launch_zero_land(gcmf_plan *pl, void *a, void *b, int64_t nbatch, hipStream_t s) {
-  const long long ncell = (long long)pl->d.ny * pl->d.nx, ntotal = ncell * nbatch;
+  const long long ncell = (long long)pl->rows_alloc * pl->d.nx, ntotal = ncell * nbatch;
   long long nb = (ntotal / 4 + 255) / 256;
   if (nb > 65536) nb = 65536;
   dim3 block(256), grid((unsigned)nb);
@@ -86,7 +86,7 @@ int launch_zero_land(gcmf_plan *pl, void *a, void *b, int64_t nbatch, hipStream_
 template <typename T, typename FB>
 static int launch_lf(gcmf_plan *pl, const void *in, void *out, const double *dp, int n_steps, double c, int64_t nbatch,
                      hipStream_t s) {
-  const long long ncell = (long long)pl->d.ny * pl->d.nx, ntotal = ncell * nbatch;
+  const long long ncell = (long long)pl->rows_alloc * pl->d.nx, ntotal = ncell * nbatch;
   const T *area = pl->area_weighted ? (const T *)pl->g.area : nullptr;
   long long nb = (ntotal / 4 + 255) / 256;
   if (nb > 32768) nb = 32768;

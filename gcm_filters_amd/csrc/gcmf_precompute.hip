@@ -395,17 +395,17 @@ template <typename T> static int precompute_t(gcmf_plan *pl, const void *const *
   }
   GCMF_HIP(hipGetLastError());
 
-  // whole-grid scalar plans: which cells never exchange with a neighbour (see gcmf_plan::lbits)
+  // scalar plans: which cells never exchange with a neighbour (see gcmf_plan::lbits), in slab-row layout
   int *dcount = nullptr;
   uint8_t *gisol = nullptr;
   const bool flux_kind = (gt == GCMF_IRREGULAR_WITH_LAND || gt == GCMF_MOM5U || gt == GCMF_MOM5T || gt == GCMF_TRIPOLAR_POP_WITH_LAND);
-  if (pl->full && (gbits || flux_kind)) {
+  if (gbits || flux_kind) {
     if ((rc = galloc((void **)&dcount, sizeof(int)))) return rc;
     GCMF_HIP(hipMemsetAsync(dcount, 0, sizeof(int), s));
     if (gbits) {
       hipLaunchKernelGGL(k_count_land, grid, block, 0, s, gbits, (long long)plane, dcount);
     } else {
-      if ((rc = dev_alloc(pl, (void **)&gisol, plane))) return rc;
+      if ((rc = galloc((void **)&gisol, plane))) return rc;
       hipLaunchKernelGGL(k_pre_isolated<T>, grid, block, 0, s, (const T *)gplanes[0], (const T *)gplanes[1], gisol, ny, nx,
                          pl->tripolar ? 1 : 0, dcount);
     }
@@ -451,8 +451,14 @@ template <typename T> static int precompute_t(gcmf_plan *pl, const void *const *
     int n_land = 0;
     GCMF_HIP(hipMemcpyAsync(&n_land, dcount, sizeof(int), hipMemcpyDeviceToHost, s));
     GCMF_HIP(hipStreamSynchronize(s));
-    pl->n_land = n_land;
-    pl->lbits = gisol ? gisol : g.mbits;  // a whole-grid plan's slab layout is the global layout
+    pl->n_land = n_land;  // of the whole grid
+    if (gisol) {
+      void *slab = nullptr;
+      if ((rc = cut_rows(pl, gisol, &slab, 1, s))) return rc;
+      pl->lbits = (const uint8_t *)slab;
+    } else {
+      pl->lbits = g.mbits;
+    }
   }
   if (area_idx >= 0) {
     void *slab = nullptr;

@@ -65,6 +65,15 @@ class HipSlabEngine:
     def multi_supported(self, S, nbatch=1):
         return self.plan.multi_supported_vec(S, nbatch)
 
+    def has_land(self):
+        return self.plan.has_land()
+
+    def zero_land(self, a, b, nbatch):
+        self.plan.zero_land(self._ptrs(a), self._ptrs(b), nbatch, stream=self._stream())
+
+    def land_fix(self, p, c, ins, outs, nbatch):
+        self.plan.land_fix(p, c, self._ptrs(ins), self._ptrs(outs), nbatch, stream=self._stream())
+
     def multi(self, u, v, uo, vo, fb_in, fb_out, pk, p0, c, mode, nbatch, row_lo, row_hi):
         """S = len(pk) recurrence steps in one HBM pass (gcmf_cheb_multi_vec); per-component tensor lists."""
         self.plan.cheb_multi_vec(self._ptrs(u), self._ptrs(v), self._ptrs(uo), self._ptrs(vo), self._ptrs(fb_in),
@@ -285,6 +294,8 @@ class SlabFilter:
         n = self.n_steps
         can_multi = hasattr(self.engine, "multi") and self.multi_depth >= 2
         prepared = False
+        keep_land_out = can_multi and hasattr(self.engine, "has_land") and self.engine.has_land()
+        land_zeroed = False
         u, v = X, None          # T_{k-1}, T_{k-2}
         valid = 0               # ghost rows of u (and at least valid-1 of v) that are up to date
         events = []
@@ -331,6 +342,11 @@ class SlabFilter:
                 else:
                     self.engine.multi(*args, lo, hi)
                 u, v = free[0], free[1]
+                if k == 1 and not is_last and keep_land_out:
+                    # flux kinds: land (cells with four closed faces) leaves the state here; its own polynomial is
+                    # written into the result by land_fix below (what gcmf_apply does internally)
+                    self.engine.zero_land(comps(u), comps(v), nbatch)
+                    land_zeroed = True
             else:
                 if k == 1 and self.area_weighted and not prepared:
                     # T_0 = field * area on every valid row (the blocked kernel fuses this, single steps do not)
@@ -346,6 +362,8 @@ class SlabFilter:
                 events.append((e0, e1, S))
             valid = v_out
             k += S
+        if land_zeroed:
+            self.engine.land_fix(p, self.c, comps(X), comps(O), nbatch)
         if events:
             t.cuda.synchronize()
             self.kernel_ms += sum(a.elapsed_time(b) for a, b, _ in events)

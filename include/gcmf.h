@@ -192,6 +192,20 @@ int gcmf_cheb_multi_vec(gcmf_plan *plan, const void *const *u, const void *const
                         int S, double p0, double c, uint32_t mode, uint32_t flags, int64_t nbatch,
                         int64_t row_lo, int64_t row_hi, void *stream);
 
+/*
+ * Land kept out of the recurrence state (flux-form scalar grid types; what gcmf_apply does internally, for slab
+ * drivers).  A cell whose four faces are closed has L = 0 at every step (the wet mask zeroes its fluxes,
+ * kernels.py:286-315, 538-585) and evolves on its own.  gcmf_has_land: 1 if the plan has such cells and the two calls
+ * below are available.  gcmf_zero_land: zero them in two state arrays (slab layout, e.g. the outputs of the first
+ * gcmf_cheb_multi_vec call) so that NaN on land stops feeding the NaN / inf bookkeeping of the blocked kernels.
+ * gcmf_land_fix: write their neighbour-free polynomial (prepare / finalize included, same operations and order as the
+ * stencil kernels) over `out`, computed from the original field `in` (slab layout); p = n_steps + 1 host doubles.
+ */
+int gcmf_has_land(const gcmf_plan *plan);
+int gcmf_zero_land(gcmf_plan *plan, void *const *a, void *const *b, int64_t nbatch, void *stream);
+int gcmf_land_fix(gcmf_plan *plan, const double *p, int n_steps, double c, const void *const *in,
+                  void *const *out, int64_t nbatch, uint32_t flags, void *stream);
+
 /* T_0 = prepare(field) = field * area for the AREA_WEIGHTED grid types (kernels.py:100-101),
  * a copy otherwise; rows [row_lo,row_hi) of the slab allocation. */
 int gcmf_prepare(gcmf_plan *plan, const void *const *in, void *const *out, int64_t nbatch,
