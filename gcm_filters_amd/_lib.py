@@ -22,7 +22,7 @@ ERR_KAPPA_W_GT1, ERR_KAPPA_S_GT1, ERR_KAPPA_NONE_ONE = 16, 17, 18
 ERR_WET_SOUTH_ROW, ERR_DXN_FOLD, ERR_DYN_FOLD = 19, 20, 21
 F32, F64 = 0, 1
 DEVICE_PTRS, OUT_F32 = 0x1, 0x2
-STEP_FIRST, STEP_LAST = 0x1, 0x2
+STEP_FIRST, STEP_LAST, STEP_LAND_ZERO = 0x1, 0x2, 0x4
 
 EXPORTS = [
     "gcmf_plan_create", "gcmf_plan_destroy", "gcmf_grid_nplanes", "gcmf_grid_ncomp", "gcmf_grid_is_dimensional",

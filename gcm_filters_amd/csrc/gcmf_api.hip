@@ -449,6 +449,7 @@ int gcmf_cheb_multi(gcmf_plan *pl, const void *u, const void *v, void *uo, void 
   m.p0 = p0; m.c = c; m.S = S; m.first = first; m.last = last;
   m.fb_is_f32 = (pl->d.dtype == GCMF_F32) && (flags & GCMF_OUT_F32);
   m.nbatch = nbatch; m.row_lo = (int)row_lo; m.row_hi = (int)row_hi;
+  m.land_zero = (mode & GCMF_STEP_LAND_ZERO) ? 1 : 0;
   return advance_multi(pl, m, (hipStream_t)stream, nullptr);
 }
 
@@ -500,7 +501,7 @@ int gcmf_cheb_multi_vec(gcmf_plan *pl, const void *const *u, const void *const *
 }
 
 static bool land_ok(const gcmf_plan *pl, int n_steps) {
-  return pl && pl->kind == K_FLUX && pl->zero_land && pl->lbits && pl->n_land > 0 && (pl->d.nx % 4) == 0 && n_steps < 4096;
+  return pl && (pl->kind == K_FLUX || pl->kind == K_MASK) && pl->zero_land && pl->lbits && pl->n_land > 0 && (pl->d.nx % 4) == 0 && n_steps < 4096;
 }
 
 int gcmf_has_land(const gcmf_plan *pl) { return land_ok(pl, 0) ? 1 : 0; }
@@ -636,6 +637,7 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
           m.u0 = u; m.v0 = v; m.uo = fr[0]; m.vo = fr[1];
           m.fb_in = F[0]; m.fb_out = is_last ? dout[0] : F[0];
           m.first = (k == 1); m.last = is_last; m.S = S; m.fb_is_f32 = fb32;
+          m.land_zero = land_zeroed ? 1 : 0;
 
           for (int t = 0; t < S; ++t) m.pk[t] = p[k + t];
           m.p0 = p[0]; m.c = c; m.nbatch = nbatch; m.row_lo = 0; m.row_hi = rows;

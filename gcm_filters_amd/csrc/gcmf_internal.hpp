@@ -78,6 +78,7 @@ struct MultiArgs {
   int S, first, last, fb_is_f32;
   int64_t nbatch;
   int row_lo, row_hi;
+  int land_zero;  // the caller guarantees that isolated (land) cells of u0 and v0 are zero: GCMF_STEP_LAND_ZERO
 };
 
 // Arguments of one S-step vector launch (gcmf_cgrid_stream2.hip / gcmf_bgrid_stream2.hip): T_{k-1}, T_{k-2} -> T_{k+S-2}, T_{k+S-1}.

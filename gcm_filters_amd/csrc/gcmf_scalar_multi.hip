@@ -30,8 +30,15 @@ namespace gcmf {
 
 // resident waves per SIMD the register budget allows: the flux form carries 3 coefficient lag windows and fits two
 // waves only up to S = 4; the coefficient-free kinds fit two waves at every depth
+// K_MASKZ: the land-mask kind when the caller guarantees that land cells of the input states are zero (gcmf_apply and
+// the slab driver zero them after the first launch, see gcmf_plan::lbits).  Land then stays zero on its own
+// (L is forced to 0 there, 2(-0 - c 0) - 0 = 0), so the stencil needs no per-neighbour wet test: 18 of ~45 VALU
+// instructions per cell and level go away.  Same sums on wet cells (a land neighbour contributed 0 before as well).
+constexpr int K_MASKZ = 5;
+template <int KIND> struct IsMask { static constexpr bool value = (KIND == K_MASK || KIND == K_MASKZ); };
+
 template <typename T, int KIND, int S> struct WavesPerSimd {
-  static constexpr int value = (KIND == K_FLUX && S > 4) ? 1 : ((KIND == K_MASK && S > 6 && sizeof(T) == 4) ? 1 : 2);
+  static constexpr int value = (KIND == K_FLUX && S > 4) ? 1 : ((IsMask<KIND>::value && S > 6 && sizeof(T) == 4) ? 1 : 2);
 };
 
 template <typename T, typename FB, int KIND, int S, int D>
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scal
       mload<T, VEC>(x.ra, P.ra + rc);
       x.closed = out_c;  // beyond a closed boundary: no flux (coefficients zeroed on delivery)
     }
-    if (KIND == K_MASK) {
+    if (IsMask<KIND>::value) {
       unsigned bb = 0;
       const uint8_t *mp = P.mbits + rc;
       if (VEC == 2) bb = *reinterpret_cast<const unsigned short *>(mp);
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scal
         raq[1][k] = cur.closed ? T(0) : cur.ra[k];
       }
     }
-    if (KIND == K_MASK) Bq[1] = cur.bits;
+    if (IsMask<KIND>::value) Bq[1] = cur.bits;
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       Fq[1][k] = first ? FB(0) : cur.fb[k];
@@ -219,6 +226,14 @@ __global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scal
         L = L + xW;
         L = L + gN[k];
         L = L + gS[k];
+      } else if (KIND == K_MASKZ) {
+        const unsigned bb = (Bq[t] >> (8 * k)) & 0xFFu;
+        const T wf = (T)__popc((bb >> 1) & 0xFu);
+        L = -wf * xC + xE;
+        L = L + xW;
+        L = L + gN[k];
+        L = L + gS[k];
+        L = (bb & 1u) ? L : T(0);
       } else if (KIND == K_MASK) {
         const unsigned bb = (Bq[t] >> (8 * k)) & 0xFFu;
         const T mC = (bb & 1u) ? xC : T(0);
@@ -319,10 +334,10 @@ __global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scal
       constexpr unsigned INF_BITS = 0xAAAAAAAAu;  // bit 1 of every 2-bit flag
       // mode 1 only for the land-mask kinds: in the flux kernel (one wave per SIMD, 340+ registers) a third copy of the
       // levels costs the finite path 7-9 % (scratch appears) and gains 3 % on NaN input
-      if (KIND != K_MASK || __any((anyf & INF_BITS) != 0u)) level_all(std::integral_constant<int, 2>{}, r);
-      else level_all(std::integral_constant<int, (KIND == K_MASK ? 1 : 2)>{}, r);
+      if (!IsMask<KIND>::value || __any((anyf & INF_BITS) != 0u)) level_all(std::integral_constant<int, 2>{}, r);
+      else level_all(std::integral_constant<int, (IsMask<KIND>::value ? 1 : 2)>{}, r);
       // a NaN cell's outputs are NaN (mode 1 computed them from sanitised operands; in mode 2 this is a no-op)
-      if (KIND == K_MASK) {
+      if (IsMask<KIND>::value) {
         const unsigned fu = (Rf[S - 1] >> (2 * VEC)) & OLD_MASK, fv = (Rf[S >= 2 ? S - 2 : 0] >> (2 * VEC)) & OLD_MASK;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
@@ -480,7 +495,7 @@ template <typename T, typename FB, int KIND> static int launch_multi_k(gcmf_plan
 template <typename T, typename FB> static int launch_multi_t(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   switch (pl->kind) {
     case K_REG: return launch_multi_k<T, FB, K_REG>(pl, a, s);
-    case K_MASK: return launch_multi_k<T, FB, K_MASK>(pl, a, s);
+    case K_MASK: return a.land_zero ? launch_multi_k<T, FB, K_MASKZ>(pl, a, s) : launch_multi_k<T, FB, K_MASK>(pl, a, s);
     case K_FLUX: return launch_multi_k<T, FB, K_FLUX>(pl, a, s);
   }
   set_error("launch_scalar_multi: plan is not a scalar kind");

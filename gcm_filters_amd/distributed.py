@@ -319,7 +319,7 @@ class SlabFilter:
             lo = fo - (v_out if self.gs else 0)
             hi = fo + ro + (v_out if self.gn else 0)
             is_last = (k + S - 1 == n)
-            mode = (_lib.STEP_FIRST if k == 1 else 0) | (_lib.STEP_LAST if is_last else 0)
+            mode = (_lib.STEP_FIRST if k == 1 else 0) | (_lib.STEP_LAST if is_last else 0) | (_lib.STEP_LAND_ZERO if land_zeroed else 0)
             if self.time_kernels:
                 e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
                 e0.record()

@@ -74,6 +74,8 @@ typedef enum gcmf_dtype { GCMF_F32 = 0, GCMF_F64 = 1 } gcmf_dtype;
 /* Chebyshev step modes for gcmf_cheb_step */
 #define GCMF_STEP_FIRST 0x1u /* T1 = A(T0);            fbar  = p0*T0 + p1*T1                  */
 #define GCMF_STEP_LAST 0x2u  /* fbar result is finalised (divided by area) into fbar_out      */
+#define GCMF_STEP_LAND_ZERO 0x4u /* gcmf_cheb_multi[_vec]: the caller guarantees that the cells gcmf_zero_land zeroes are
+                                    zero in both input states (lets the land-mask kernels drop their per-neighbour tests) */
 
 typedef struct gcmf_plan gcmf_plan;
 
@@ -193,9 +195,9 @@ int gcmf_cheb_multi_vec(gcmf_plan *plan, const void *const *u, const void *const
                         int64_t row_lo, int64_t row_hi, void *stream);
 
 /*
- * Land kept out of the recurrence state (flux-form scalar grid types; what gcmf_apply does internally, for slab
- * drivers).  A cell whose four faces are closed has L = 0 at every step (the wet mask zeroes its fluxes,
- * kernels.py:286-315, 538-585) and evolves on its own.  gcmf_has_land: 1 if the plan has such cells and the two calls
+ * Land kept out of the recurrence state (flux-form and land-mask scalar grid types; what gcmf_apply does internally,
+ * for slab drivers).  A land cell / a cell whose four faces are closed has L = 0 at every step (the wet mask zeroes
+ * it or its fluxes, kernels.py:163-187, 286-315, 538-585) and evolves on its own.  gcmf_has_land: 1 if the plan has such cells and the two calls
  * below are available.  gcmf_zero_land: zero them in two state arrays (slab layout, e.g. the outputs of the first
  * gcmf_cheb_multi_vec call) so that NaN on land stops feeding the NaN / inf bookkeeping of the blocked kernels.
  * gcmf_land_fix: write their neighbour-free polynomial (prepare / finalize included, same operations and order as the
