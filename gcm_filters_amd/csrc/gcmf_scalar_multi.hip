@@ -120,7 +120,14 @@ __global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scal
     const long long ro = (long long)row_index(r, out_u) * nx + col;
     const long long rc = (long long)row_index(r - 1, out_c) * nx + col;
     mload<T, VEC>(x.u, P.u0 + boff + ro);
-    if (!first) {
+    // unconditional (the first launch reads stand-ins it then ignores): a conditionally loaded 16-byte operand ends
+    // up in scratch and is re-read from there every row (seen in the K_REG / K_MASK instantiations)
+    // (not in the flux kernel: its instantiations keep these operands in registers as they are, and its schedule is
+    // sensitive to any change)
+    if (KIND != K_FLUX) {
+      mload<T, VEC>(x.v, (first ? P.u0 : P.v0) + boff + rc);
+      mload<FB, VEC>(x.fb, (first ? (const FB *)P.fb_out : P.fb_in) + boff + rc);
+    } else if (!first) {
       mload<T, VEC>(x.v, P.v0 + boff + rc);
       mload<FB, VEC>(x.fb, P.fb_in + boff + rc);
     }
@@ -137,7 +144,9 @@ __global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scal
       else bb = *reinterpret_cast<const unsigned *>(mp);
       x.bits = out_c ? 0u : bb;
     }
-    if (first && P.area_weighted) mload<T, VEC>(x.ar, P.area + ro);
+    // same reason: unconditional, from the address of x.u when there is no area to apply (an L1 hit)
+    if (KIND != K_FLUX) mload<T, VEC>(x.ar, (first && P.area_weighted) ? P.area + ro : P.u0 + boff + ro);
+    else if (first && P.area_weighted) mload<T, VEC>(x.ar, P.area + ro);
   };
 
   // flag layout in Rf[t]: bits [2k, 2k+1] = cell k of slot `old`, bits [2*VEC + 2k, ..+1] = cell k of slot `mid`
@@ -341,8 +350,10 @@ __global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scal
         const unsigned fu = (Rf[S - 1] >> (2 * VEC)) & OLD_MASK, fv = (Rf[S >= 2 ? S - 2 : 0] >> (2 * VEC)) & OLD_MASK;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-          if ((fu >> (2 * k)) & 1u) { out_u[k] = (T)__builtin_nan(""); Fq[S][k] = (FB)__builtin_nan(""); }
-          if ((fv >> (2 * k)) & 1u) out_v[k] = (T)__builtin_nan("");
+          const bool nu = (fu >> (2 * k)) & 1u, nv = (fv >> (2 * k)) & 1u;  // selects, not conditional stores: the
+          out_u[k] = nu ? (T)__builtin_nan("") : out_u[k];                  // arrays must stay in registers
+          Fq[S][k] = nu ? (FB)__builtin_nan("") : Fq[S][k];
+          out_v[k] = nv ? (T)__builtin_nan("") : out_v[k];
         }
       }
     } else {
