@@ -38,7 +38,10 @@ constexpr int K_MASKZ = 5;
 template <int KIND> struct IsMask { static constexpr bool value = (KIND == K_MASK || KIND == K_MASKZ); };
 
 template <typename T, int KIND, int S> struct WavesPerSimd {
-  static constexpr int value = (KIND == K_FLUX && S > 4) ? 1 : ((IsMask<KIND>::value && S > 6 && sizeof(T) == 4) ? 1 : 2);
+  // f32 state carries 4 cells per lane: the flux form spills at two waves per SIMD from S = 3 on (328 B of scratch at
+  // S = 4 made a 4-step remainder launch cost more than an 8-step one), the land-mask form from S = 6 on
+  static constexpr int value = (KIND == K_FLUX && (S > 4 || (sizeof(T) == 4 && S > 2))) ? 1
+                               : ((IsMask<KIND>::value && S > 5 && sizeof(T) == 4) ? 1 : 2);
 };
 
 template <typename T, typename FB, int KIND, int S, int D>
