@@ -26,7 +26,7 @@ template <typename T, typename FB> struct CStream2P {
   int nx, rows, out_lo, out_hi;
   int H, nwx, ngroups, nlev, nlev4, wrap, first, last;
   long long bstride;
-  double p0, pk[4], c;
+  double p0, pk[5], c;
 };
 
 template <typename T> __device__ __forceinline__ T c2san(T x) {
@@ -322,7 +322,10 @@ bool cgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
   if (pl->kind != K_CGRID || pl->cgrid_tile) return false;
   // f64: more than two levels spill registers.  f32: S = 6 / 8 fit only one wave per SIMD and measured slower than
   // S = 4 at two (234-252 G against 268-274 G cell.steps/s on config 5)
-  if (S < 2 || S > 4) return false;
+  // f32: S = 5 holds 238 VGPRs at two waves per SIMD and measured 282 G against 250 G for S = 4 on the same box
+  // (config 5); S = 6 spills (229 G).  f64: S <= 4 (one wave per SIMD from S = 3 on)
+  // single-level fields (wave-private LDS rings): S = 5 leaves five waves per CU and measured 90 G against 133 G at S = 4
+  if (S < 2 || S > ((pl->d.dtype == GCMF_F64 || nbatch == 1) ? 4 : 5)) return false;
   const int vec = pl->d.dtype == GCMF_F64 ? 2 : 4;
   if (pl->g.nx % vec || pl->g.nx < vec || pl->g.rows < S + 2) return false;
   // any batch size: the lock-step workgroups of 4 levels are padded with shadow waves that repeat the last level
@@ -382,7 +385,7 @@ template <typename T, typename FB, int VEC, int S, int D, bool PRIV> static int 
   P.last = a.last;
   P.bstride = (long long)g.rows * g.nx;
   P.p0 = a.p0;
-  for (int t = 0; t < 4; ++t) P.pk[t] = a.pk[t];
+  for (int t = 0; t < 5; ++t) P.pk[t] = a.pk[t];
   P.c = a.c;
   const long long groups_per_xcd = (P.ngroups + 7) / 8;
   const long long blocks_per_xcd = PRIV ? groups_per_xcd * P.nlev : (groups_per_xcd * P.nlev4 + 3) / 4;
@@ -430,6 +433,8 @@ int launch_cgrid_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
     case 7: return launch_c2_sel<float, float, 3>(pl, a, s);
     case 8: return launch_c2_sel<float, double, 4>(pl, a, s);
     case 9: return launch_c2_sel<float, float, 4>(pl, a, s);
+    case 10: return launch_c2<float, double, 2, 5, 1, false>(pl, a, s);
+    case 11: return launch_c2<float, float, 2, 5, 1, false>(pl, a, s);
   }
   return GCMF_ERR_INVALID_ARG;
 }

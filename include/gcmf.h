@@ -184,9 +184,9 @@ int gcmf_cheb_multi(gcmf_plan *plan, const void *u, const void *v, void *uo, voi
 /*
  * The same for every grid type, with per-component pointer arrays like gcmf_cheb_step (ncomp entries each).
  * Scalar plans forward to gcmf_cheb_multi.  VECTOR_C_GRID (reference kernels.py:591-699 inside the recurrence of
- * filter.py:225-283) advances S in {2,3,4} steps per pass (f64 plans: S = 2); levels are processed by lock-step
+ * filter.py:225-283) advances S in 2..5 steps per pass (f64 plans: 2..4); levels are processed by lock-step
  * workgroups of 4 (a batch that is not a multiple of 4 is padded internally, nothing is stored for the padding).
- * VECTOR_B_GRID (kernels.py:702-840): the same, S in {2,3,4} for f32 plans and {2,3} for f64 plans.
+ * VECTOR_B_GRID (kernels.py:702-840): the same.
  */
 int gcmf_multi_supported_vec(const gcmf_plan *plan, int S, int64_t nbatch);
 int gcmf_cheb_multi_vec(gcmf_plan *plan, const void *const *u, const void *const *v, void *const *uo,
