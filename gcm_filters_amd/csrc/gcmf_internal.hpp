@@ -156,6 +156,8 @@ size_t dtype_size(int dtype);
 int launch_scalar_step(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 int launch_vector_step(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 int launch_scalar_multi(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
+bool flux_multi2_supported(const gcmf_plan *pl, int S);
+int launch_flux_multi2(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_cgrid_stream(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 bool cgrid_stream_supported(const gcmf_plan *pl, const StepArgs &a);
 int launch_bgrid_stream(gcmf_plan *pl, const StepArgs &a, hipStream_t s);

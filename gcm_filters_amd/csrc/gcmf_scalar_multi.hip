@@ -21,6 +21,7 @@
 // Reference semantics per level: gcm_filters/filter.py:162-175,192-206 + the Laplacians of kernels.py (see
 // gcmf_scalar.hip for the per-kind citations).
 #include "gcmf_multi_common.hpp"
+#include <cstdlib>
 
 #ifndef GCMF_NO_SKIP
 #define GCMF_NO_SKIP 0
@@ -528,6 +529,9 @@ bool multi_supported(const gcmf_plan *pl, int S) {
 }
 
 int launch_scalar_multi(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
+  // deep flux launches: the two-rows-per-iteration kernel (gcmf_flux_multi2.hip); GCMF_FLUX2=0 keeps the one-row form
+  static const bool flux2 = !(getenv("GCMF_FLUX2") && atoi(getenv("GCMF_FLUX2")) == 0);
+  if (flux2 && flux_multi2_supported(pl, a.S)) return launch_flux_multi2(pl, a, s);
   if (pl->d.dtype == GCMF_F64) return launch_multi_t<double, double>(pl, a, s);
   if (a.fb_is_f32) return launch_multi_t<float, float>(pl, a, s);
   return launch_multi_t<float, double>(pl, a, s);
