@@ -208,6 +208,8 @@ def main():
         local = sf.scatter_from_global(wl["fields"])
         for _ in range(args.warmup):
             sf.apply_local(local)
+        sf.collect_kernel_times()
+        sf.kernel_ms, sf.kernel_launches = 0.0, 0
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -219,6 +221,7 @@ def main():
         tt = torch.tensor([elapsed], device="cpu" if share_gpu else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        sf.collect_kernel_times()
         kernel_ms, launches = sf.kernel_ms, sf.kernel_launches
         cells = ny_global * args.nx * nbatch
 

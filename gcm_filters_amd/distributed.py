@@ -151,6 +151,7 @@ class SlabFilter:
         self._bufs = {}
         self.kernel_ms = 0.0
         self.kernel_launches = 0
+        self._pending_events = []
         self.exchanges = 0
         self.time_kernels = False  # bench.py: bracket every step launch with events on the launch stream
         self.multi_depth = 8       # most recurrence steps fused per HBM pass (1 = single steps only)
@@ -270,6 +271,14 @@ class SlabFilter:
                 off += p.numel()
         self.exchanges += 1
 
+    def collect_kernel_times(self):
+        """Fold the launch events recorded since the last call into ``kernel_ms`` / ``kernel_launches`` (synchronises)."""
+        if self._pending_events:
+            self.torch.cuda.synchronize()
+            self.kernel_ms += sum(a.elapsed_time(b) for a, b, _ in self._pending_events)
+            self.kernel_launches += sum(n for _, _, n in self._pending_events)
+            self._pending_events = []
+
     # -- the filter ----------------------------------------------------------------------------
     MULTI_DEPTHS = (8, 7, 6, 5, 4, 3, 2)  # scalar kinds support all of them, the vector kinds 4 / 3 / 2
 
@@ -299,6 +308,7 @@ class SlabFilter:
         u, v = X, None          # T_{k-1}, T_{k-2}
         valid = 0               # ghost rows of u (and at least valid-1 of v) that are up to date
         events = []
+        nlaunch = 0
         k = 1
         while k <= n:
             left = n - k + 1
@@ -320,7 +330,7 @@ class SlabFilter:
             hi = fo + ro + (v_out if self.gn else 0)
             is_last = (k + S - 1 == n)
             mode = (_lib.STEP_FIRST if k == 1 else 0) | (_lib.STEP_LAST if is_last else 0) | (_lib.STEP_LAND_ZERO if land_zeroed else 0)
-            if self.time_kernels:
+            if self.time_kernels and k == 1:  # one pair of events per application (per-launch pairs cost 4 %)
                 e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
                 e0.record()
             if S >= 2:
@@ -357,15 +367,14 @@ class SlabFilter:
                                  comps(O) if is_last else comps(F), p[0] if k == 1 else p[k], p[1], self.c, mode,
                                  nbatch, lo, hi)
                 u, v = free[0], u
-            if self.time_kernels:
+            nlaunch += 1
+            if self.time_kernels and is_last:
                 e1.record()
-                events.append((e0, e1, S))
+                events.append((e0, e1, nlaunch))
             valid = v_out
             k += S
         if land_zeroed:
             self.engine.land_fix(p, self.c, comps(X), comps(O), nbatch)
-        if events:
-            t.cuda.synchronize()
-            self.kernel_ms += sum(a.elapsed_time(b) for a, b, _ in events)
-            self.kernel_launches += len(events)
+        if events:  # read back later (collect_kernel_times): a synchronisation here would serialise consecutive calls
+            self._pending_events.extend(events)
         return [O[k][:, fo: fo + ro, :] for k in range(self.ncomp)]

@@ -67,6 +67,7 @@ def _worker(rank, world, port, q):
             sf = SlabFilter(grid, gv, fk, shape[0], shape[1], halo=halo, dtype=np.dtype(dt), device=0)
             sf.time_kernels = True
             got = sf.gather_to_global(sf.apply_local(sf.scatter_from_global(fields)))
+            sf.collect_kernel_times()
             if vec:   # the blocked vector kernels really ran on the slabs
                 assert sf.kernel_launches < sf.n_steps, (sf.kernel_launches, sf.n_steps)
             if rank == 0:
