@@ -1,0 +1,93 @@
+"""Randomised row-slab sweep on one GPU (ranks share cuda:0, halos over gloo, like tests/test_gpu_distributed.py):
+grid types x shapes x halo widths x batches x dtypes x NaN-on-land, 2 or 3 ranks, checked against the oracle and the
+single-domain GPU filter.  usage: fuzz_slabs.py <seed> <ncases> <world>"""
+import os, socket, sys
+import numpy as np
+sys.path.insert(0, "/root/repo")
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def make_cases(seed, n, world):
+    from gcm_filters_amd import testing as T
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(n):
+        grid = T.ALL_GRIDS[rng.integers(len(T.ALL_GRIDS))]
+        ny = int(rng.integers(12 * world, 60 * world)); nx = int(rng.integers(2, 40)) * 4
+        if grid.startswith("TRIPOLAR"):
+            nx += nx % 2
+        halo = int(rng.integers(1, 10))
+        nb = int(rng.choice([1, 1, 2, 3, 4, 5]))
+        dt = "f8" if rng.random() < 0.6 else "f4"
+        nanland = bool(rng.random() < 0.5)
+        nsteps = int(rng.integers(3, 30))
+        cases.append((grid, (ny, nx), halo, nb, dt, nanland, nsteps))
+    return cases
+
+
+def worker(rank, world, port, cases, q):
+    import torch, warnings
+    import torch.distributed as dist
+    from gcm_filters_amd import Filter, FilterShape, GridType, testing as T
+    from gcm_filters_amd.distributed import SlabFilter
+    from oracle import gcmf_oracle as O
+    warnings.simplefilter("ignore")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bad = []
+    try:
+        for case in cases:
+            grid, shape, halo, nb, dt, nanland, nsteps = case
+            vec = grid in T.VECTOR_GRIDS
+            gv = T.vector_grid_vars(grid, shape) if vec else T.scalar_grid_vars(grid, shape)
+            fields = [np.stack([T.random_field(shape, 7 + 10 * c + b) for b in range(nb)]) for c in range(2 if vec else 1)]
+            if nanland and not vec and "wet_mask" in gv:
+                fields[0] = np.where(gv["wet_mask"] == 0, np.nan, fields[0])
+            gv = {k: v.astype(dt) for k, v in gv.items()}
+            fields = [f.astype(dt) for f in fields]
+            dx = T.grid_dx_min(grid, gv) if O.DIMENSIONAL[grid] else 1.0
+            fk = dict(filter_scale=3.0 * dx, dx_min=dx, filter_shape="TAPER", n_steps=nsteps)
+            try:
+                sf = SlabFilter(grid, gv, fk, shape[0], shape[1], halo=halo, dtype=np.dtype(dt), device=0)
+                got = sf.gather_to_global(sf.apply_local(sf.scatter_from_global(fields)))
+            except Exception as e:
+                bad.append((case, "EXC " + repr(e)[:150])); continue
+            if rank == 0:
+                flt = Filter(filter_scale=fk["filter_scale"], dx_min=dx, n_steps=nsteps, filter_shape=FilterShape.TAPER,
+                             grid_type=GridType[grid], grid_vars=gv)
+                one = flt.apply_to_vector(*fields) if vec else (flt.apply(fields[0]),)
+                for g, o in zip(got, one):
+                    if not np.array_equal(np.isnan(g), np.isnan(o)):
+                        bad.append((case, "NANPATTERN")); break
+                    nz = lambda a: np.nan_to_num(a, nan=0.0)
+                    e = float(np.abs(nz(g) - nz(o)).max() / max(np.abs(nz(o)).max(), 1e-300))
+                    if e > (2e-5 if dt == "f4" else 1e-12):
+                        bad.append((case, f"ERR {e:.2e}")); break
+        if rank == 0:
+            q.put(bad)
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    import torch.multiprocessing as mp
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    world = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    cases = make_cases(seed, n, world)
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, cases, q)) for r in range(world)]
+    [p.start() for p in procs]
+    [p.join(900) for p in procs]
+    codes = [p.exitcode for p in procs]
+    bad = q.get() if all(c == 0 for c in codes) else [("workers", f"exit codes {codes}")]
+    print(f"{n} slab cases, world {world}: {len(bad)} bad")
+    for b in bad[:20]:
+        print("  BAD", b)
