@@ -119,20 +119,22 @@ int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launche
     prep_band = true;
     lvl0 = Pb;
   }
-  auto level_buf = [&](int t) -> void * {  // where level t (1..S) of the band lives
+  // where level t (1..S) of the band lives.  Level S-1 goes to scratch as well (with its ghost row just below the band,
+  // which step S needs) and its band rows are copied into vo afterwards: no band step then reads anything the blocked
+  // launch writes, so the whole band chain runs beside it.
+  auto level_buf = [&](int t) -> void * {
     if (t == S) return m.uo;
-    if (t == S - 1 && !m.last) return m.vo;
     return E[t & 1];
   };
-  // Band steps 1..S-1 do not depend on the blocked launch (only step S reads the row just below the band from its
-  // output), so they run on a side stream concurrently with it: they are tiny, latency-bound launches (~6 us
-  // each) that fit beside the one-wave-per-SIMD blocked kernel.  All writes of the two streams are row-disjoint.
+  // The band steps do not depend on the blocked launch, so they run on a side stream concurrently with it: they are
+  // tiny, latency-bound launches (~6 us each) that fit beside the one-wave-per-SIMD blocked kernel.  All writes of
+  // the two streams are row-disjoint.
   if (!pl->side) {
     GCMF_HIP(hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking));
     GCMF_HIP(hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
     GCMF_HIP(hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
   }
-  const int n_early = S - 1;  // steps 1..n_early are independent of the blocked launch
+  const int n_early = S;  // steps 1..n_early are independent of the blocked launch
   GCMF_HIP(hipEventRecord(pl->ev_fork, s));
   GCMF_HIP(hipStreamWaitEvent(pl->side, pl->ev_fork, 0));
   if (prep_band) {  // T_0 = field * area for the band rows (the blocked kernel fuses this, single steps do not)
@@ -141,16 +143,10 @@ int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launche
     if ((rc = launch_prepare(pl, pin, pout, m.nbatch, rows - 2 * S, rows, n_early >= 1 ? pl->side : s))) return rc;
     if (launches) ++*launches;
   }
-  bool main_launched = false;
+  if ((rc = launch_scalar_multi(pl, mm, s))) return rc;
+  if (launches) ++*launches;
   for (int t = 1; t <= S; ++t) {
-    hipStream_t ts_ = (t <= n_early) ? pl->side : s;
-    if (t > n_early && !main_launched) {
-      if ((rc = launch_scalar_multi(pl, mm, s))) return rc;
-      if (launches) ++*launches;
-      GCMF_HIP(hipEventRecord(pl->ev_join, pl->side));
-      GCMF_HIP(hipStreamWaitEvent(s, pl->ev_join, 0));
-      main_launched = true;
-    }
+    hipStream_t ts_ = pl->side;
     StepArgs a{};
     a.mode = ((m.first && t == 1) ? GCMF_STEP_FIRST : 0u) | ((m.last && t == S) ? GCMF_STEP_LAST : 0u);
     a.coef0 = (m.first && t == 1) ? m.p0 : m.pk[t - 1];
@@ -163,12 +159,19 @@ int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launche
     a.t0[0] = level_buf(t);
     a.fb_in[0] = (m.first && t == 1) ? nullptr : ((t == 1) ? m.fb_in : (m.last ? m.fb_in : m.fb_out));
     a.fb_out[0] = (m.last && t < S) ? const_cast<void *>(m.fb_in) : m.fb_out;
-    a.row_lo = (t >= S - 1 && !(t == S - 1 && m.last)) ? blo : rows - 2 * S + t;
+    a.row_lo = (t == S) ? blo : rows - 2 * S + t;
     a.row_hi = rows;
     a.fb_lo = blo;
     if ((rc = launch_scalar_step(pl, a, ts_))) return rc;
     if (launches) ++*launches;
+    if (t == S - 1 && !m.last) {  // the band rows of T_{k+S-2} into the caller's plane (rows < blo are the blocked launch's)
+      const size_t rowb = (size_t)g.nx * ts, pitch = (size_t)rows * rowb;
+      GCMF_HIP(hipMemcpy2DAsync((char *)m.vo + (size_t)blo * rowb, pitch, (const char *)level_buf(t) + (size_t)blo * rowb, pitch,
+                                (size_t)S * rowb, (size_t)m.nbatch, hipMemcpyDeviceToDevice, ts_));
+    }
   }
+  GCMF_HIP(hipEventRecord(pl->ev_join, pl->side));
+  GCMF_HIP(hipStreamWaitEvent(s, pl->ev_join, 0));
   return GCMF_OK;
 }
 
