@@ -65,6 +65,7 @@ struct StepArgs {
   int64_t nbatch;
   int row_lo, row_hi;
   int fb_lo;  // scalar kinds: rows < fb_lo leave fbar untouched
+  int rpw;    // scalar kinds: rows marched per wave (0 = the plan's / default 2); the tripole band steps use 1
 };
 
 // Arguments of one temporally blocked launch: S recurrence steps in one pass (scalar kinds, one component).
@@ -144,6 +145,7 @@ struct gcmf_plan {
   const uint8_t *lbits = nullptr;
   int64_t n_land = 0;
   int zero_land = 1;      // env GCMF_ZERO_LAND=0 turns it off
+  int band_rpw = 0;       // rows per wave of the tripole band steps (0 = default)
   double *dev_p = nullptr;   // p[0..n_steps] of the last filter, for k_land_fix
   size_t dev_p_n = 0;
   std::vector<double> host_p;

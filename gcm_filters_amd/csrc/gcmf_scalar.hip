@@ -250,7 +250,7 @@ static int launch_k(gcmf_plan *pl, const StepArgs &a, hipStream_t s) {
   P.row_lo = a.row_lo;
   P.row_hi = a.row_hi;
   P.fb_lo = a.fb_lo;
-  P.rpw = pl->rows_per_wave > 0 ? pl->rows_per_wave : 2;  // measured on MI355X: 1-4 rows per wave within noise, 8+ slower
+  P.rpw = a.rpw > 0 ? a.rpw : (pl->rows_per_wave > 0 ? pl->rows_per_wave : 2);  // measured on MI355X: 1-4 rows per wave within noise, 8+ slower
   P.bstride = (long long)g.rows * g.nx;
   P.south_wrap = g.south_wrap;
   P.north_wrap = g.north_wrap;
