@@ -279,8 +279,19 @@ __global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scal
         Fq[t][k] = cheb_acc<FUSED, T, FB>(Fq[t][k], P.pk[t - 1], tk);
       }
       tkv[k] = tk;
-      if (t == S - 1) out_v[k] = tk;
-      if (t == S) out_u[k] = tk;
+      if (MODE == 1 && t >= S - 1) {
+        // mode 1 ran on sanitised operands: what leaves the wave is NaN on a NaN cell (in mode 2 it already is)
+        const bool isn = (Rf[t - 1] >> (2 * VEC + 2 * k)) & 1u;
+        const T val = isn ? (T)__builtin_nan("") : tk;
+        if (t == S - 1) out_v[k] = val;
+        if (t == S) {
+          out_u[k] = val;
+          Fq[S][k] = isn ? (FB)__builtin_nan("") : Fq[S][k];
+        }
+      } else {
+        if (t == S - 1) out_v[k] = tk;
+        if (t == S) out_u[k] = tk;
+      }
     }
     if (t < S && MODE == 1) {  // becomes the `new` row of this level's window; flagged cells: 0 and the same flag
       unsigned nf = 0u;
@@ -349,17 +360,6 @@ __global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scal
       // levels costs the finite path 7-9 % (scratch appears) and gains 3 % on NaN input
       if (!IsMask<KIND>::value || __any((anyf & INF_BITS) != 0u)) level_all(std::integral_constant<int, 2>{}, r);
       else level_all(std::integral_constant<int, (IsMask<KIND>::value ? 1 : 2)>{}, r);
-      // a NaN cell's outputs are NaN (mode 1 computed them from sanitised operands; in mode 2 this is a no-op)
-      if (IsMask<KIND>::value) {
-        const unsigned fu = (Rf[S - 1] >> (2 * VEC)) & OLD_MASK, fv = (Rf[S >= 2 ? S - 2 : 0] >> (2 * VEC)) & OLD_MASK;
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-          const bool nu = (fu >> (2 * k)) & 1u, nv = (fv >> (2 * k)) & 1u;  // selects, not conditional stores: the
-          out_u[k] = nu ? (T)__builtin_nan("") : out_u[k];                  // arrays must stay in registers
-          Fq[S][k] = nu ? (FB)__builtin_nan("") : Fq[S][k];
-          out_v[k] = nv ? (T)__builtin_nan("") : out_v[k];
-        }
-      }
     } else {
       level_all(std::integral_constant<int, 0>{}, r);
     }
