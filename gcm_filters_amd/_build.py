@@ -1,4 +1,4 @@
-"""Build libgcmf.so (HIP, gfx950 only) in-tree with hipcc.  No torch, no cmake: four translation units."""
+"""Build libgcmf.so (HIP, gfx950 only) in-tree with hipcc.  No torch, no cmake: the translation units compile in parallel."""
 from __future__ import annotations
 
 import os
