@@ -315,6 +315,10 @@ class SlabFilter:
             if self.world > 1 and valid == 0:
                 self._exchange([u] if v is None else [u, v])
                 valid = s
+                if land_zeroed:
+                    # a neighbour that overlapped its exchange with the first launch sent its rows before it zeroed
+                    # them (ranks with unequal row counts decide differently): the ghost rows must honour LAND_ZERO too
+                    self.engine.zero_land(comps(u), comps(v), nbatch)
             budget = min(left, valid if self.world > 1 else left)
             S = 1
             if can_multi:

@@ -27,6 +27,10 @@ CASES = [
     ("VECTOR_B_GRID", (49, 64), 4, 2, "f4"),
     ("TRIPOLAR_POP_WITH_LAND", (120, 64), 4, 2, "f8"),   # NaN on land + land kept out of the state + overlapped exchange
     ("MOM5U", (64, 64), 8, 3, "f4"),
+    # 58 rows over 3 ranks = 19 / 19 / 20: only the 20-row rank overlaps its exchange with the first launch and sends its
+    # rows before zeroing their land; the receivers run the land-mask kernels in LAND_ZERO mode (found by tools/fuzz_slabs.py)
+    ("TRIPOLAR_REGULAR_WITH_LAND_AREA_WEIGHTED", (58, 16), 5, 5, "f8"),
+    ("REGULAR_WITH_LAND", (58, 16), 5, 2, "f4"),
 ]
 
 
