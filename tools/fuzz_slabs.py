@@ -26,7 +26,9 @@ def make_cases(seed, n, world):
         dt = "f8" if rng.random() < 0.6 else "f4"
         nanland = bool(rng.random() < 0.5)
         nsteps = int(rng.integers(3, 30))
-        cases.append((grid, (ny, nx), halo, nb, dt, nanland, nsteps))
+        depth = int(rng.choice([8, 8, 8, 5, 4, 2, 1]))
+        overlap = bool(rng.random() < 0.7)
+        cases.append((grid, (ny, nx), halo, nb, dt, nanland, nsteps, depth, overlap))
     return cases
 
 
@@ -42,7 +44,7 @@ def worker(rank, world, port, cases, q):
     bad = []
     try:
         for case in cases:
-            grid, shape, halo, nb, dt, nanland, nsteps = case
+            grid, shape, halo, nb, dt, nanland, nsteps, depth, overlap = case
             vec = grid in T.VECTOR_GRIDS
             gv = T.vector_grid_vars(grid, shape) if vec else T.scalar_grid_vars(grid, shape)
             fields = [np.stack([T.random_field(shape, 7 + 10 * c + b) for b in range(nb)]) for c in range(2 if vec else 1)]
@@ -54,6 +56,7 @@ def worker(rank, world, port, cases, q):
             fk = dict(filter_scale=3.0 * dx, dx_min=dx, filter_shape="TAPER", n_steps=nsteps)
             try:
                 sf = SlabFilter(grid, gv, fk, shape[0], shape[1], halo=halo, dtype=np.dtype(dt), device=0)
+                sf.multi_depth, sf.overlap = depth, overlap
                 got = sf.gather_to_global(sf.apply_local(sf.scatter_from_global(fields)))
             except Exception as e:
                 bad.append((case, "EXC " + repr(e)[:150])); continue
