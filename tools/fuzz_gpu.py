@@ -52,6 +52,12 @@ for it in range(ncase):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             flt = Filter(filter_scale=scale, dx_min=dx, filter_shape=FilterShape[shp], n_steps=n_steps, grid_type=GridType[grid], grid_vars=gv)
+            if "--tune" in sys.argv:  # random blocking depth / strip height / prefetch depth of the plan this case uses
+                from gcm_filters_amd import _lib
+                from gcm_filters_amd.kernels import ALL_KERNELS
+                plan = ALL_KERNELS[GridType[grid]](**gv)._plan(_lib.dtype_code(dt), shape)
+                plan.set_tuning(multi_s=int(rng.integers(1, 9)), strip_rows=int(rng.choice([0, 0, 3, 5, 9, 17, 40])),
+                                prefetch_rows=int(rng.choice([0, 0, 1, 2])))
             got = flt.apply_to_vector(*fields) if vec else (flt.apply(fields[0]),)
         spec = O.FilterSpec(flt.n_steps, flt.filter_spec.s_max, np.asarray(flt.filter_spec.p), flt.filter_spec.dx_min_sq)
         with np.errstate(all="ignore"):
