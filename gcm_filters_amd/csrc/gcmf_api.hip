@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 
 namespace gcmf {
 
@@ -58,6 +59,35 @@ static int ensure_work(gcmf_plan *pl, size_t bytes) {
 }
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Page-locked caller ranges, process wide and reference counted: two plans (two dask threads) may stream the same host
+// array at once, and the first to finish must not unregister it under the other's transfers.
+static std::mutex g_reg_mu;
+static std::map<const void *, std::pair<size_t, int>> g_reg;
+static bool host_register(const void *p, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  auto it = g_reg.find(p);
+  if (it != g_reg.end()) {
+    if (it->second.first < bytes) return false;  // a shorter range is locked: leave this call on the pageable path
+    ++it->second.second;
+    return true;
+  }
+  if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  g_reg[p] = {bytes, 1};
+  return true;
+}
+static void host_unregister(const void *p) {
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  auto it = g_reg.find(p);
+  if (it == g_reg.end()) return;
+  if (--it->second.second == 0) {
+    (void)hipHostUnregister(const_cast<void *>(p));
+    g_reg.erase(it);
+  }
+}
 
 // p[0..n_steps] on the device for k_land_fix; uploaded only when it changed (a pageable upload stalls the host behind
 // the stream)
@@ -847,15 +877,14 @@ static int run_host_pipelined(gcmf_plan *pl, const double *p, int n_steps, doubl
   bool registered[2] = {false, false};
   if (pl->host_register)
     for (int k = 0; k < nc; ++k) {
-      registered[k] = hipHostRegister(const_cast<void *>(in[k]), (size_t)nbatch * cell * ts, hipHostRegisterDefault) == hipSuccess;
-      if (!registered[k]) (void)hipGetLastError();
+      registered[k] = host_register(in[k], (size_t)nbatch * cell * ts);
     }
   auto finish = [&](int r) {
     (void)hipStreamSynchronize(pl->s_in);
     (void)hipStreamSynchronize(pl->s_out);
     (void)hipStreamSynchronize(s_cmp);
     for (int k = 0; k < nc; ++k)
-      if (registered[k]) (void)hipHostUnregister(const_cast<void *>(in[k]));
+      if (registered[k]) host_unregister(in[k]);
     return r;
   };
   if ((rc = upload_and_launch(0))) return finish(rc);

@@ -603,3 +603,32 @@ def test_land_kept_out_of_the_state(grid, dt, monkeypatch):
         want = O.filter_func(spec, grid, f[:2], gv)
     assert np.array_equal(np.isnan(outs["1"][1][:2]), np.isnan(want))
     assert rel_err(outs["1"][1][:2], want) <= (1e-4 if dt == "f4" else 1e-11)
+
+
+def test_two_plans_stream_the_same_host_array(monkeypatch):
+    """Two threads (dask workers) filter the SAME batched host array with different plans at once: the page-locking of
+    the caller's input is reference counted, so the first call to finish does not unlock it under the other's uploads."""
+    import threading
+    from gcm_filters_amd.kernels import clear_plan_cache
+    shape, nb = (96, 256), 24
+    monkeypatch.setenv("GCMF_HOST_CHUNK_MB", str(2.0 * shape[0] * shape[1] * 8 / 2**20))  # chunks of two fields
+    clear_plan_cache()
+    f = np.stack([T.random_field(shape, 300 + b) for b in range(nb)])
+    flts = []
+    for grid in ("REGULAR_WITH_LAND", "IRREGULAR_WITH_LAND"):
+        _, gv = T.scalar_case(grid, shape)
+        dx = T.grid_dx_min(grid, gv) if O.DIMENSIONAL[grid] else 1.0
+        flts.append(Filter(filter_scale=6 * dx, dx_min=dx, grid_type=GridType[grid], grid_vars=gv))
+    want = [flt.apply(f) for flt in flts]
+    for _ in range(3):
+        got = [None, None]
+
+        def work(i):
+            got[i] = flts[i].apply(f)
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+    clear_plan_cache()
