@@ -48,7 +48,7 @@ struct Geom {
   int fold;        // row rows-1's northern neighbour is itself mirrored in x (tripole seam)
   int area_weighted;
   const void *coef[MAX_COEF];  // K_FLUX: cE, cN, ra;  K_CGRID: 14;  K_BGRID: 8
-  const uint8_t *mbits;        // K_MASK: bit0 wet, bit1 E wet, bit2 W wet, bit3 N wet, bit4 S wet
+  const uint8_t *mbits;        // K_MASK: bit0 wet, bit1 E wet, bit2 W wet, bit3 N wet, bit4 S wet, bits 5-7 their count
   const void *area;            // prepare / finalize plane (area-weighted types)
 };
 

@@ -49,6 +49,7 @@ __global__ void k_pre_mask(const T *m, uint8_t *bits, int ny, int nx, int tripol
     }
     if (mn != T(0)) b |= 8u;
     if (ms != T(0)) b |= 16u;
+    b |= (unsigned)__popc((b >> 1) & 0xFu) << 5;  // bits 5-7: number of wet neighbours (saves the kernels a popcount)
     bits[q_] = (uint8_t)b;
   }
 }

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void k_scalar_step(const ScalarP<T, FB> P) {
       } else if (KIND == K_MASK) {  // m (-wf g + gE + gW + gN + gS), g = m nan_to_num(f) (kernels.py:175-186)
         const unsigned b = mb[k];
         const T mC = (b & 1u) ? gC : T(0);
-        const T wf = (T)__popc((b >> 1) & 0xFu);
+        const T wf = (T)(b >> 5);  // wet-neighbour count, precomputed in bits 5-7
         L = -wf * mC + ((b & 2u) ? gE : T(0));
         L = L + ((b & 4u) ? gW : T(0));
         L = L + ((b & 8u) ? gN : T(0));

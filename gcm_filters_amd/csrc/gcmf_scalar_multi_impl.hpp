@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scal
         L = L + gS[k];
       } else if (KIND == K_MASKZ) {
         const unsigned bb = (Bq[t] >> (8 * k)) & 0xFFu;
-        const T wf = (T)__popc((bb >> 1) & 0xFu);
+        const T wf = (T)(bb >> 5);  // wet-neighbour count, precomputed in bits 5-7
         L = -wf * xC + xE;
         L = L + xW;
         L = L + gN[k];
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scal
       } else if (KIND == K_MASK) {
         const unsigned bb = (Bq[t] >> (8 * k)) & 0xFFu;
         const T mC = (bb & 1u) ? xC : T(0);
-        const T wf = (T)__popc((bb >> 1) & 0xFu);
+        const T wf = (T)(bb >> 5);  // wet-neighbour count, precomputed in bits 5-7
         L = -wf * mC + ((bb & 2u) ? xE : T(0));
         L = L + ((bb & 4u) ? xW : T(0));
         L = L + ((bb & 8u) ? gN[k] : T(0));
