@@ -908,6 +908,12 @@ static int run_whole(gcmf_plan *pl, const double *p, int n_steps, double c, cons
       set_error("gcmf_apply: null component pointer");
       return GCMF_ERR_INVALID_ARG;
     }
+  for (int k = 0; k < pl->ncomp; ++k)
+    for (int q = 0; q < pl->ncomp; ++q)
+      if (in[k] == out[q]) {  // the input is read by the first launch, by neighbouring strips and by k_land_fix at the end
+        set_error("gcmf_apply: `out` must not alias `in` (filtering in place is not supported)");
+        return GCMF_ERR_INVALID_ARG;
+      }
   if (!pl->full) {
     set_error("gcmf_apply / gcmf_laplacian need a plan covering the whole grid; use gcmf_cheb_step on row slabs");
     return GCMF_ERR_INVALID_ARG;

@@ -130,7 +130,7 @@ int gcmf_plan_rows(const gcmf_plan *plan, int64_t *rows_alloc, int64_t *first_ow
  * A(x) = -x - c L(x).   `p` has n_steps+1 entries (host memory), n_steps >= 1.
  * `c` = 2/s_max (dimensional Laplacians) or 2/(s_max*dx_min^2)   (filter.py:170-173).
  * `in` / `out`: ncomp pointers (1 scalar, 2 vector) to (nbatch, ny, nx) arrays; `in` has the plan
- * dtype and is not modified; `out` is f64 unless the plan is f32 and GCMF_OUT_F32 is given.
+ * dtype and is not modified; `out` is f64 unless the plan is f32 and GCMF_OUT_F32 is given and must not alias `in`.
  * Only valid on single-slab plans (row_begin = 0, row_end = ny).
  * `stream`: hipStream_t to run on.  With GCMF_DEVICE_PTRS the work is enqueued asynchronously on exactly
  * that stream (NULL = the HIP default stream), ordered with the caller's other work on it.  With host

@@ -632,3 +632,18 @@ def test_two_plans_stream_the_same_host_array(monkeypatch):
         for g, w in zip(got, want):
             assert np.array_equal(g, w)
     clear_plan_cache()
+
+
+def test_in_place_is_rejected():
+    """gcmf_apply reads the input again at the end (land cells) and across strips: out == in is an argument error."""
+    import torch
+    from gcm_filters_amd import _lib
+    shape = (40, 64)
+    _, gv = T.scalar_case("IRREGULAR_WITH_LAND", shape)
+    lap = ALL_KERNELS[GridType.IRREGULAR_WITH_LAND](**gv)
+    plan = lap._plan(_lib.F64, shape, 0)
+    d = torch.zeros(shape, dtype=torch.float64, device="cuda")
+    p = np.array([0.5, 0.3, 0.2])
+    with pytest.raises(_lib.GcmfError) as e:
+        plan.apply(p, 0.25, [d.data_ptr()], [d.data_ptr()], 1, device_ptrs=True)
+    assert "alias" in str(e.value)
