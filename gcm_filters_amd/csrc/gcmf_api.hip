@@ -720,8 +720,8 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
         for (int q = 0; q < 4 && nf < 2; ++q)
           if (pool[q][0] != u[0] && pool[q][0] != v[0]) { fr[nf][0] = pool[q][0]; fr[nf][1] = pool[q][1]; ++nf; }
         int S = 1;
-        const int cand[4] = {5, 4, 3, 2};
-        for (int q = 0; q < 4; ++q)  // largest depth that does not strand a lone single step at the end
+        const int cand[5] = {6, 5, 4, 3, 2};
+        for (int q = 0; q < 5; ++q)  // largest depth that does not strand a lone single step at the end
           if (cand[q] <= left && left - cand[q] != 1 && cand[q] <= pl->multi_s && vec_multi_supported(pl, nbatch, cand[q])) {
             S = cand[q];
             break;

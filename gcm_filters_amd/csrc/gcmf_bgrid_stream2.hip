@@ -25,7 +25,7 @@ template <typename T, typename FB> struct BStream2P {
   int nx, rows, out_lo, out_hi;
   int H, nwx, ngroups, nlev, nlev4, wrap, first, last;
   long long bstride;
-  double p0, pk[5], c;
+  double p0, pk[6], c;
 };
 
 template <typename T> __device__ __forceinline__ T b2san(T x) {
@@ -292,7 +292,7 @@ static bool b2al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u
 
 bool bgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
   if (pl->kind != K_BGRID || nbatch < 1) return false;
-  if (S < 2 || S > ((pl->d.dtype == GCMF_F64 || nbatch == 1) ? 4 : 5)) return false;  // see cgrid_multi_supported
+  if (S < 2 || S > ((pl->d.dtype == GCMF_F64 || nbatch == 1) ? 4 : 6)) return false;  // see cgrid_multi_supported
   const int vec = pl->d.dtype == GCMF_F64 ? 2 : 4;
   if (pl->g.nx % vec || pl->g.nx < vec || pl->g.rows < S + 2) return false;
   for (int k = 0; k < 8; ++k)
@@ -344,7 +344,7 @@ template <typename T, typename FB, int VEC, int S, int D, bool PRIV> static int 
   P.last = a.last;
   P.bstride = (long long)g.rows * g.nx;
   P.p0 = a.p0;
-  for (int t = 0; t < 5; ++t) P.pk[t] = a.pk[t];
+  for (int t = 0; t < 6; ++t) P.pk[t] = a.pk[t];
   P.c = a.c;
   const long long groups_per_xcd = (P.ngroups + 7) / 8;
   const long long blocks_per_xcd = PRIV ? groups_per_xcd * P.nlev : (groups_per_xcd * P.nlev4 + 3) / 4;
@@ -381,6 +381,8 @@ int launch_bgrid_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
     case 9: return launch_b2_sel<float, float, 4, 2>(pl, a, s);
     case 10: return launch_b2_sel<float, double, 5, 1>(pl, a, s);
     case 11: return launch_b2_sel<float, float, 5, 1>(pl, a, s);
+    case 12: return launch_b2_sel<float, double, 6, 1>(pl, a, s);
+    case 13: return launch_b2_sel<float, float, 6, 1>(pl, a, s);
   }
   return GCMF_ERR_INVALID_ARG;
 }

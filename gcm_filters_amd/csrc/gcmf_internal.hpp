@@ -90,7 +90,7 @@ struct VecMultiArgs {
   void *u2o[2];          // T_{k+S-1} out (must not alias u0 / uprev / u1o)
   const void *fb_in[2];
   void *fb_out[2];
-  double pk[5];          // p[k] .. p[k+S-1]; with `first`: p[1] .. p[S]
+  double pk[6];          // p[k] .. p[k+S-1]; with `first`: p[1] .. p[S]
   double p0, c;
   int S, first, last, fb_is_f32;
   int64_t nbatch;

@@ -186,7 +186,7 @@ int gcmf_cheb_multi(gcmf_plan *plan, const void *u, const void *v, void *uo, voi
  * Scalar plans forward to gcmf_cheb_multi.  VECTOR_C_GRID (reference kernels.py:591-699 inside the recurrence of
  * filter.py:225-283) advances S in 2..5 steps per pass (f64 plans: 2..4); levels are processed by lock-step
  * workgroups of 4 (a batch that is not a multiple of 4 is padded internally, nothing is stored for the padding).
- * VECTOR_B_GRID (kernels.py:702-840): the same.
+ * VECTOR_B_GRID (kernels.py:702-840): the same, f32 batches up to S = 6.
  */
 int gcmf_multi_supported_vec(const gcmf_plan *plan, int S, int64_t nbatch);
 int gcmf_cheb_multi_vec(gcmf_plan *plan, const void *const *u, const void *const *v, void *const *uo,

@@ -62,7 +62,7 @@ class OracleSlabEngine:
     # --- temporally blocked advance, emulated with S single oracle steps on a shrinking row range ---
     def multi_supported(self, S, nbatch=1):
         if self.name in O.VECTOR:  # mirrors cgrid_multi_supported / bgrid_multi_supported: S <= 4
-            return S in (2, 3, 4, 5) and self.rows_alloc >= S + 2
+            return S in (2, 3, 4, 5, 6) and self.rows_alloc >= S + 2
         return 2 <= S <= 8 and self.rows_alloc >= 3 * S + 2
 
     def multi(self, u, v, uo, vo, fb_in, fb_out, pk, p0, c, mode, nbatch, row_lo, row_hi):

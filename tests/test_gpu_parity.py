@@ -464,7 +464,7 @@ def test_vector_temporal_blocking_bit_identical(grid, shape, nlev, dt):
             plan.set_timing(True)
             ref = flt.apply_to_vector(u, v)
             assert plan.last_timing()[1] == n_steps
-            for S in (2, 3, 4, 5):
+            for S in (2, 3, 4, 5, 6):
                 plan.set_tuning(multi_s=S)
                 got = flt.apply_to_vector(u, v)
                 n_launch = plan.last_timing()[1]
