@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the fused iterated-Laplacian filter on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {2,3,4,5}] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {2,3,4,5}] [--scaling strong|weak] [--no-cpu] [--no-extra]
 
-A "step" is ONE whole filter application (all n_steps Chebyshev/Laplacian steps) of the workload's field,
+A "step" is ONE whole filter application (all n_steps Chebyshev/Laplacian steps) of the workload's field(s),
 inputs already resident in HBM.  metric = grid-cells * Laplacian-steps / second (BASELINE.json).
 Default workload = BASELINE config 3, the one the north-star target is quoted on:
 IRREGULAR_WITH_LAND 2400x3600 fp64, Taper filter, filter_scale = 16 dx_min  =>  n_steps 63.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the grid is cut into row slabs along y with
-halo rows exchanged over RCCL (gcm_filters_amd/distributed.py); see --scaling.
+N > 1: one rank per GPU.  Under torch.distributed.run the ranks are already there; started as a plain
+`python bench.py --gpus N` the script launches its own N ranks (a child `python -m torch.distributed.run`, started
+before this process touches a GPU).  Scalar configs are cut into row slabs along y with halo rows exchanged over
+xGMI (gcm_filters_amd/distributed.py); the default is STRONG scaling (the one BASELINE grid cut N ways), a weak
+figure (N x ny rows) is measured in the same run and printed as `weak`.  Config 5 (50 levels) shards its levels
+over the ranks: no communication at all.
 
-Prints ONE JSON line on rank 0 (see the task contract) with `roofline` and `cpu_baseline` objects.
+Prints ONE JSON line on rank 0 (task contract) with `roofline`, `cpu_baseline`, `parity` and `extra_configs`.
+The run FAILS (exit 1) if the timed workload's output differs from the oracle / the reference-generated probes.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,97 +31,283 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-# algorithmic HBM bytes per cell per Laplacian step (SURVEY 8d / DESIGN.md): 5 state words + folded coefficients
-# w = sizeof(state), f = sizeof(fbar) (f64 even for f32 state: NumPy >= 2 promotion), L = levels sharing the 2-D planes
-B_ALG = {
-    "REGULAR": lambda w, f, L: 3 * w + 2 * f,
-    "REGULAR_WITH_LAND": lambda w, f, L: 3 * w + 2 * f + 1.0 / L,
-    "IRREGULAR_WITH_LAND": lambda w, f, L: 3 * w + 2 * f + 3 * w / L,
-    "TRIPOLAR_POP_WITH_LAND": lambda w, f, L: 3 * w + 2 * f + 3 * w / L,
-    "VECTOR_C_GRID": lambda w, f, L: 2 * (3 * w + 2 * f) + 14 * w / L,
-    "VECTOR_B_GRID": lambda w, f, L: 2 * (3 * w + 2 * f) + 8 * w / L,
-}
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0   # measured float4-copy ceiling, same guide
+GOLDEN_FULLSIZE = os.path.join(REPO, "tests", "golden", "reference_fullsize.npz")
+# (config, scale override) -> key in reference_fullsize.npz (outputs of the imported reference, tests/golden/make_golden.py)
+FIXTURE_KEY = {(2, 0.0): "cfg2_n56", (2, 50.0): "cfg2_n56", (2, 10.0): "cfg2_n11", (3, 0.0): "cfg3_n63", (4, 0.0): "cfg4_n56",
+               (5, 0.0): "cfg5_lev0_n44"}
+NCOEF = {"REGULAR": 0, "REGULAR_WITH_LAND": None, "IRREGULAR_WITH_LAND": 3, "TRIPOLAR_POP_WITH_LAND": 3,
+         "VECTOR_C_GRID": 14, "VECTOR_B_GRID": 8}
 
 
-def build_workload(cfg: int, ny: int, nx: int, nlev: int, f32: bool = False, f64: bool = False):
-    """Synthetic inputs of BASELINE.json configs: returns dict(grid, fields, grid_vars, filter kwargs)."""
-    from gcm_filters_amd import FilterShape, testing as T
-
-    shape = (ny, nx)
-    if cfg == 1:  # BASELINE config 1 scaled up is not asked for; REGULAR at the benchmark size for reference
-        grid = "REGULAR"
-        gv = {}
-        fields = [T.random_field(shape, 100)]
-        fk = dict(filter_scale=50.0, dx_min=1.0, filter_shape=FilterShape.GAUSSIAN)
-    elif cfg == 2:
-        grid = "REGULAR_WITH_LAND"
-        gv = {"wet_mask": T.land_mask(shape)}
-        fields = [T.random_field(shape, 100)]
-        fk = dict(filter_scale=50.0, dx_min=1.0, filter_shape=FilterShape.GAUSSIAN)
-    elif cfg == 3:
-        grid = "IRREGULAR_WITH_LAND"
-        gv = T.scalar_grid_vars(grid, shape)
-        fields = [T.random_field(shape, 100)]
-        dx = T.grid_dx_min(grid, gv)
-        fk = dict(filter_scale=16 * dx, dx_min=dx, filter_shape=FilterShape.TAPER)
-    elif cfg == 4:
-        grid = "TRIPOLAR_POP_WITH_LAND"
-        gv = T.scalar_grid_vars(grid, shape)
-        fields = [T.random_field(shape, 100)]
-        dx = T.grid_dx_min(grid, gv)
-        fk = dict(filter_scale=50 * dx, dx_min=dx, filter_shape=FilterShape.GAUSSIAN)
-    elif cfg == 5:
-        grid = "VECTOR_C_GRID"
-        cdt = np.float64 if f64 else np.float32   # BASELINE config 5 is f32; --f64 is an extra measurement
-        gv = {k: v.astype(cdt) for k, v in T.vector_grid_vars(grid, shape).items()}
-        gv["kappa_aniso"] = np.zeros(shape, dtype=cdt)
-        fields = [np.stack([T.random_field(shape, 42 + c + 2 * l).astype(cdt) for l in range(nlev)])
-                  for c in range(2)]
-        dx = T.grid_dx_min(grid, gv)
-        fk = dict(filter_scale=40 * dx, dx_min=dx, filter_shape=FilterShape.GAUSSIAN)
-    elif cfg == 6:  # not a BASELINE config: the POP B-grid vector Laplacian at the benchmark size, fp64
-        grid = "VECTOR_B_GRID"
-        gv = T.vector_grid_vars(grid, shape)
-        if nlev <= 1:
-            fields = [T.random_field(shape, 42), T.random_field(shape, 43)]
-        else:
-            fields = [np.stack([T.random_field(shape, 42 + c + 2 * l) for l in range(nlev)]) for c in range(2)]
-        if f32:
-            gv = {k: v.astype(np.float32) for k, v in gv.items()}
-            fields = [f.astype(np.float32) for f in fields]
-        dx = T.grid_dx_min(grid, gv)
-        fk = dict(filter_scale=40 * dx, dx_min=dx, filter_shape=FilterShape.GAUSSIAN)
-    else:
-        raise SystemExit(f"unknown --config {cfg}")
-    return dict(grid=grid, fields=fields, grid_vars=gv, fk=fk)
+def b_alg(grid, w, f, L):
+    """SURVEY 8d / BASELINE.md 4: algorithmic bytes per cell and Laplacian step of the ONE-PASS-PER-STEP streaming model
+    (read T_{k-1}, T_{k-2}, fbar; write T_k, fbar; + folded coefficient planes shared by L levels)."""
+    ncomp = 2 if grid.startswith("VECTOR") else 1
+    coef = 1.0 if NCOEF[grid] is None else NCOEF[grid] * w
+    return ncomp * (3 * w + 2 * f) + coef / L
 
 
-def cpu_baseline(wl, budget_steps: int):
-    """The reference's numpy path (oracle port), single thread like the reference runs one 2-D field,
-    on a bounded sample: the SAME grid and field with the polynomial truncated to `budget_steps` steps."""
+def min_bytes_per_cell_launch(grid, w, f, L):
+    """Compulsory HBM bytes per cell of ONE temporally blocked launch, whatever its depth S: every operand plane
+    read once (T_{k-1}, T_{k-2}, fbar, coefficients), every result written once (T_{k+S-1}, T_{k+S-2}, fbar)."""
+    ncomp = 2 if grid.startswith("VECTOR") else 1
+    coef = 1.0 if NCOEF[grid] is None else NCOEF[grid] * w
+    return ncomp * 2 * (2 * w + f) + coef / L
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (numpy restatement of the reference) on the host cores
+# ------------------------------------------------------------------------------------------------------------------
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(wl, budget_steps):
+    """(i) SURVEY 8d: single process / thread -- what the reference does for one 2-D field -- on a bounded sample: the
+    SAME grid and field (one level of a batched workload), polynomial truncated to `budget_steps` steps if longer.
+    Returns (record, oracle outputs, n_steps actually run)."""
     from oracle import gcmf_oracle as O
 
     fk = wl["fk"]
-    full = O.make_spec(fk["filter_scale"], fk["dx_min"], fk["filter_shape"].name)
+    full = O.make_spec(fk["filter_scale"], fk["dx_min"], fk["filter_shape"])
     n = min(budget_steps, full.n_steps)
     spec = O.FilterSpec(n, full.s_max, full.p[: n + 1], full.dx_min_sq)
-    fields = [f if f.ndim == 2 else f[0] for f in wl["fields"]]  # one level of a batched workload
+    fields = [f if f.ndim == 2 else f[0] for f in wl["fields"]]
     t0 = time.perf_counter()
     with np.errstate(all="ignore"):
         if len(fields) == 2:
-            O.filter_func_vec(spec, wl["grid"], fields[0], fields[1], wl["grid_vars"])
+            res = O.filter_func_vec(spec, wl["grid"], fields[0], fields[1], wl["grid_vars"])
         else:
-            O.filter_func(spec, wl["grid"], fields[0], wl["grid_vars"])
+            res = (O.filter_func(spec, wl["grid"], fields[0], wl["grid_vars"]),)
     dt = time.perf_counter() - t0
     ny, nx = fields[0].shape
-    return {"value": ny * nx * n / dt, "unit": "cell-steps/s", "cores": 1, "kind": "port",
-            "sample": f"same {ny}x{nx} grid and field, 1 level, "
-                      + ("whole polynomial" if n == full.n_steps else f"polynomial truncated to n_steps={n}")
-                      + f" (n_steps={n}, {dt:.1f} s, numpy {np.__version__}, host has {os.cpu_count()} cores)"}
+    rec = {"value": ny * nx * n / dt, "unit": "cell-steps/s", "cores": 1, "kind": "port",
+           "sample": f"same {ny}x{nx} grid and field, 1 level, "
+                     + ("whole polynomial" if n == full.n_steps else f"polynomial truncated to n_steps={n}")
+                     + f" (n_steps={n}, {dt:.1f} s)",
+           "host": {"cpu_count": os.cpu_count(), "cpu_model": _cpu_model(), "numpy": np.__version__}}
+    return rec, res, n
 
 
-def main():
+def _pool_level(job):
+    """One level of config 5 through the oracle (worker of cpu_baseline_pool); inputs rebuilt from seeds in the worker."""
+    cfg, ny, nx, level, n = job
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    from gcm_filters_amd import testing as T
+    from oracle import gcmf_oracle as O
+
+    wl = T.baseline_workload(cfg, (ny, nx), levels=[level])
+    fk = wl["fk"]
+    full = O.make_spec(fk["filter_scale"], fk["dx_min"], fk["filter_shape"])
+    spec = O.FilterSpec(n, full.s_max, full.p[: n + 1], full.dx_min_sq)
+    t0 = time.perf_counter()
+    with np.errstate(all="ignore"):
+        O.filter_func_vec(spec, wl["grid"], wl["fields"][0][0], wl["fields"][1][0], wl["grid_vars"])
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_pool(cfg, ny, nx, nlev, budget_steps):
+    """(ii) SURVEY 8d / BASELINE.md 3: an os.cpu_count()-way process pool of the oracle over the levels of a batched
+    workload -- the analogue of the reference's dask="parallelized" over non-core dims (gcm_filters/filter.py:485).
+    Bounded: one level per worker, polynomial truncated to `budget_steps`; workers capped by free memory (~3 GB each)."""
+    import multiprocessing as mp
+
+    workers = min(os.cpu_count() or 1, nlev)
+    try:
+        avail = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] * 1024
+        workers = max(1, min(workers, int(avail // (3 << 30))))
+    except Exception:
+        pass
+    jobs = [(cfg, ny, nx, l, budget_steps) for l in range(workers)]
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(workers) as pool:
+        per = pool.map(_pool_level, jobs)
+    wall = time.perf_counter() - t0
+    return {"value": workers * ny * nx * budget_steps / max(per), "unit": "cell-steps/s", "cores": workers, "kind": "port",
+            "sample": f"{workers} levels of the {nlev}, one per worker process, polynomial truncated to n_steps={budget_steps}; "
+                      f"slowest worker {max(per):.1f} s, pool wall incl. start-up and input generation {wall:.1f} s",
+            "host": {"cpu_count": os.cpu_count(), "cpu_model": _cpu_model(), "numpy": np.__version__}}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# parity helpers
+# ------------------------------------------------------------------------------------------------------------------
+def rel_err_and_nan(got, want):
+    """max |got - want| / max |want| over the finite cells of `want`, and whether the NaN patterns agree."""
+    worst, same = 0.0, True
+    for g, w in zip(got, want):
+        g, w = np.asarray(g, dtype=np.float64), np.asarray(w, dtype=np.float64)
+        same = same and bool(np.array_equal(np.isnan(g), np.isnan(w)))
+        ok = np.isfinite(w)
+        if ok.any():
+            with np.errstate(invalid="ignore"):
+                worst = max(worst, float(np.nanmax(np.abs(g[ok] - w[ok])) / np.abs(w[ok]).max()))
+    return worst, same
+
+
+def golden_probe_check(cfg, scale, shape, outs, row_begin=0, row_end=None):
+    """Compare (device or host) outputs `outs` (ncomp arrays (..., rows, nx); rows = [row_begin, row_end) of the grid)
+    with the probes the imported reference produced for this BASELINE config (tests/golden/reference_fullsize.npz).
+    Returns None when no fixture covers the workload, else dict(rel_err, n_probes, key); vector configs: level 0."""
+    from gcm_filters_amd import testing as T
+
+    key = FIXTURE_KEY.get((cfg, float(scale)))
+    if key is None or tuple(shape) != T.BASELINE_SHAPE or not os.path.exists(GOLDEN_FULLSIZE):
+        return None
+    with np.load(GOLDEN_FULLSIZE) as z:
+        want = np.atleast_2d(z[key + "/probe"])
+    jj, ii = T.probe_points(T.BASELINE_SHAPE)
+    row_end = shape[0] if row_end is None else row_end
+    mine = (jj >= row_begin) & (jj < row_end)
+    got = np.full(want.shape, np.nan)
+    for c, o in enumerate(outs):
+        lev0 = o if o.ndim == 2 else o.reshape(-1, o.shape[-2], o.shape[-1])[0]
+        v = lev0[jj[mine] - row_begin, ii[mine]]
+        got[c, mine] = v.double().cpu().numpy() if hasattr(v, "cpu") else np.asarray(v, dtype=np.float64)
+    return {"key": key, "got": got, "want": want, "mine": mine}
+
+
+def finish_probe_check(chk):
+    got, want, mine = chk["got"], chk["want"], chk["mine"]
+    err = float(np.abs(got[:, mine] - want[:, mine]).max() / np.abs(want).max()) if mine.any() else 0.0
+    return {"fixture": "tests/golden/reference_fullsize.npz:" + chk["key"], "n_probes": int(mine.sum()) * got.shape[0],
+            "rel_err": err, "source": "imported reference (tests/golden/make_golden.py --fullsize)"}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def load_traffic(cfg, kernel_ran):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes -- only if the record names
+    the kernel that actually ran in this process (gcmf_last_kernel)."""
+    tf = os.path.join(REPO, "profiles", "hbm_traffic.json")
+    if not os.path.exists(tf):
+        return None, "no profiles/hbm_traffic.json"
+    try:
+        rec = json.load(open(tf)).get(f"config{cfg}")
+    except Exception as e:  # noqa: BLE001
+        return None, f"unreadable profiles/hbm_traffic.json: {e}"
+    if not rec:
+        return None, f"no record for config {cfg}"
+    prof = rec.get("kernel", "").replace("void ", "").strip()
+    if not kernel_ran or prof != kernel_ran:
+        return None, f"profiled kernel '{prof}' is not the kernel that ran ('{kernel_ran}'): traffic withheld"
+    return rec, f"profiles/hbm_traffic.json:config{cfg} <- {rec.get('source')} ({prof})"
+
+
+def run_single(cfg, args, dev, steps, warmup, scale=0.0, levels=None, tuned=False):
+    """Time `steps` filter applications of BASELINE config `cfg` on this process's GPU.  Returns a dict with the raw
+    measurements, the workload and the device outputs of the last application."""
+    import torch
+
+    from gcm_filters_amd import Filter, FilterShape, GridType, _lib, testing as T
+    from gcm_filters_amd.kernels import ALL_KERNELS
+
+    nlev = args.nlev if (args.nlev and cfg == args.config) else 0
+    wl = T.baseline_workload(cfg, (args.ny, args.nx), nlev=nlev, f32=args.f32, f64=args.f64, scale=scale, levels=levels)
+    grid, fk = wl["grid"], wl["fk"]
+    itemsize = wl["fields"][0].dtype.itemsize
+    nbatch = 1 if wl["fields"][0].ndim == 2 else wl["fields"][0].shape[0]
+    flt = Filter(grid_type=GridType[grid], grid_vars=wl["grid_vars"], filter_scale=fk["filter_scale"], dx_min=fk["dx_min"],
+                 filter_shape=FilterShape[fk["filter_shape"]])
+    n_steps = int(flt.n_steps)
+    cls = ALL_KERNELS[GridType[grid]]
+    lap = cls(*[wl["grid_vars"][k] for k in cls.required_grid_args()])
+    plan = lap._plan(_lib.F64 if itemsize == 8 else _lib.F32, (args.ny, args.nx), dev.index)
+    if tuned:
+        plan.set_tuning(args.rows_per_wave, args.xcd_remap, args.multi or 8, args.strip, args.prefetch)
+    plan.set_timing(True)
+    d_in = [torch.from_numpy(f).to(dev) for f in wl["fields"]]
+    run = (lambda: flt.apply_to_vector(d_in[0], d_in[1])) if len(d_in) == 2 else (lambda: (flt.apply(d_in[0]),))
+    outs = None
+    for _ in range(warmup):
+        outs = run()
+    plan.last_kernel()  # reset
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernel_ms, launches = 0.0, 0
+    for _ in range(steps):
+        outs = run()
+        ms, nl = plan.last_timing()  # hipEvents recorded inside gcmf_apply on the stream the kernels ran on
+        kernel_ms += ms
+        launches += nl
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    return dict(wl=wl, grid=grid, fk=fk, itemsize=itemsize, nbatch=nbatch, n_steps=n_steps, elapsed=elapsed,
+                kernel_ms=kernel_ms, launches=launches, outs=list(outs), kernel=plan.last_kernel(), flt=flt, d_in=d_in,
+                cells=args.ny * args.nx * nbatch)
+
+
+def roofline_of(cfg, r, steps, default_tuning):
+    w, nb, grid = r["itemsize"], r["nbatch"], r["grid"]
+    if not (r["launches"] and r["kernel_ms"] > 0):
+        return None
+    balg = b_alg(grid, w, 8, nb)
+    avg_ms = r["kernel_ms"] / r["launches"]
+    steps_per_launch = r["n_steps"] * steps / r["launches"]
+    achieved = balg * r["cells"] * steps_per_launch / (avg_ms * 1e-3) / 1e9
+    minb = min_bytes_per_cell_launch(grid, w, 8, nb) * r["cells"]
+    rec, src = load_traffic(cfg, r["kernel"]) if default_tuning else (None, "non-default tuning: traffic withheld")
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "traffic": rec.get("bytes_per_launch") if rec else None, "traffic_source": src,
+           "kernel": r["kernel"], "avg_launch_ms": avg_ms, "steps_per_launch": steps_per_launch,
+           "alg_bytes_per_launch": balg * r["cells"] * steps_per_launch, "alg_bytes_per_cell_step": balg,
+           "frac_note": "achieved/frac price every Laplacian step with SURVEY 8d's one-pass-per-step byte count; a blocked "
+                        "launch advances steps_per_launch steps per pass over HBM, so frac > 1 is possible and is NOT a "
+                        "hardware fraction -- hbm_frac / min_bytes_frac are",
+           "min_bytes_per_launch": minb,
+           # what the launch must move at least (each plane once) over its measured duration, against the 8 TB/s peak
+           "min_bytes_frac": minb / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "hbm_frac": None, "hbm_frac_of_copy_ceiling": None}
+    if rec:
+        gbs = rec["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+        out["hbm_frac"] = gbs / HBM_PEAK_GBS                      # counter bytes / this run's launch time / 8 TB/s
+        out["hbm_frac_of_copy_ceiling"] = gbs / HBM_COPY_GBS
+        out["traffic_over_min_bytes"] = rec["bytes_per_launch"] / minb
+        for k in ("bound", "valu_active_frac", "valu_arith_share", "counters_source"):
+            if k in rec:
+                out["bound" if k == "bound" else k] = rec[k]
+    return out
+
+
+def free_gpu():
+    import gc
+
+    import torch
+
+    from gcm_filters_amd.kernels import clear_plan_cache
+    clear_plan_cache()
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks as a child torch.distributed.run.  Nothing in this
+    process has touched a GPU yet (device_count() does not initialise HIP)."""
+    import torch
+
+    share = os.environ.get("GCMF_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count()
+    if have < args.gpus and not share:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} requested but only {have} HIP device(s) are visible "
+                         f"(set GCMF_BENCH_SHARE_GPU=1 to run all ranks on one GPU over gloo for testing)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -125,166 +318,281 @@ def main():
     ap.add_argument("--nlev", type=int, default=0, help="vertical levels of config 5 (default 50) / config 6 (default 1)")
     ap.add_argument("--f32", action="store_true", help="config 6 only: f32 state instead of f64")
     ap.add_argument("--f64", action="store_true", help="config 5 only: f64 state instead of the BASELINE's f32")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N>1: weak = every GPU owns a full ny-row slab of a (N*ny, nx) grid; strong = one (ny, nx) grid")
+    ap.add_argument("--filter-scale", type=float, default=0.0, help="filter scale in dx_min units (0 = the config's own)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N>1, scalar configs: strong = one (ny, nx) grid cut into N row slabs (reported as value); "
+                         "weak = every GPU owns ny rows of an (N*ny, nx) grid")
+    ap.add_argument("--no-weak", action="store_true", help="N>1: skip the second (weak-scaling) measurement")
     ap.add_argument("--halo", type=int, default=0, help="N>1: ghost rows per exchange (0 = auto)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--exchange", choices=["auto", "native", "torch"], default="auto",
+                    help="N>1 halo exchange: native = issued by libgcmf (peer copies + events); torch = torch.distributed P2P")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (and the oracle parity check)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs measurements (configs 2, 4, 5)")
     ap.add_argument("--cpu-steps", type=int, default=64, help="Laplacian steps of the CPU sample")
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--xcd-remap", type=int, default=-1)
     ap.add_argument("--multi", type=int, default=0, help="recurrence steps fused per HBM pass (0 = library default, 1 = off)")
     ap.add_argument("--strip", type=int, default=0, help="rows per wave strip of the temporally blocked kernel (0 = auto)")
     ap.add_argument("--prefetch", type=int, default=0, help="operand rows in flight per wave (0 = default)")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def workload_name(cfg, r, args, extra=""):
+    nb = r["nbatch"]
+    return (f"{'BASELINE config' if (cfg <= 5 and not args.f64) else 'extra config'} {cfg}"
+            f"{' (f64 variant)' if (args.f64 and cfg == 5) else ''}: {r['grid']} {args.ny}x{args.nx}"
+            + (f" x{nb} levels" if nb > 1 else "") + extra)
+
+
+def main_single(args):
     import torch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
-    # test hook: GCMF_BENCH_SHARE_GPU=1 runs all ranks on cuda:0 over gloo (a gpurun box has one GPU; RCCL refuses
-    # two ranks on one device).  The driver's real multi-GPU runs use one GPU per rank over RCCL.
-    share_gpu = os.environ.get("GCMF_BENCH_SHARE_GPU") == "1"
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    tuned = bool(args.rows_per_wave or args.xcd_remap >= 0 or args.multi or args.strip or args.prefetch)
+    tol = lambda itemsize: 1e-6 if itemsize == 8 else 1e-4   # north-star gate (fp64); f32 state: SURVEY 8d parity gate
+    r = run_single(args.config, args, dev, args.steps, args.warmup, scale=args.filter_scale, tuned=tuned)
+    value = r["cells"] * r["n_steps"] * args.steps / r["elapsed"]
+    fk = r["fk"]
+    out = {
+        "metric": "grid-cells*Laplacian-steps/sec", "value": value, "unit": "cell-steps/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * r["elapsed"] / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64" if r["itemsize"] == 8 else "f32", "data": "synthetic",
+        "config": {"workload": workload_name(args.config, r, args),
+                   "filter": f"{fk['filter_shape']} filter_scale={fk['filter_scale']:.6g} dx_min={fk['dx_min']:.6g}",
+                   "n_steps": r["n_steps"], "global_grid": [args.ny, args.nx], "parallelism": "single GPU"},
+    }
+    out["roofline"] = roofline_of(args.config, r, args.steps, not tuned)
+    nbatch_main = r["nbatch"]
+    failed = []
+    # ---- parity of the TIMED workload's output -----------------------------------------------------------------
+    parity = {"tolerance": tol(r["itemsize"])}
+    chk = golden_probe_check(args.config, args.filter_scale, (args.ny, args.nx), r["outs"])
+    if chk is not None:
+        parity["reference_probes"] = finish_probe_check(chk)
+        if not parity["reference_probes"]["rel_err"] <= parity["tolerance"]:
+            failed.append(f"reference probes: rel_err {parity['reference_probes']['rel_err']:.3e}")
+    if not args.no_cpu:
+        cpu, want, n_cpu = cpu_baseline(r["wl"], args.cpu_steps)
+        out["cpu_baseline"] = cpu
+        if n_cpu == r["n_steps"]:
+            got = [o if o.ndim == 2 else o[0] for o in r["outs"]]
+            what = "oracle, same grid / field / whole polynomial as the timed workload" + (" (level 0)" if r["nbatch"] > 1 else "")
+        else:  # the CPU sample ran a truncated polynomial: one more (untimed) GPU application with the same one
+            from gcm_filters_amd import filter as F
+            spec = r["flt"].filter_spec
+            short = F.FilterSpec(n_cpu, spec.s_max, np.asarray(spec.p)[: n_cpu + 1], spec.dx_min_sq)
+            lev0 = [d if d.ndim == 2 else d[:1] for d in r["d_in"]]
+            cls = r["flt"].Laplacian
+            gargs = [r["wl"]["grid_vars"][k] for k in cls.required_grid_args()]
+            if len(lev0) == 2:
+                got = F._create_filter_func_vec(short, cls)(lev0[0], lev0[1], *gargs)
+            else:
+                got = (F._create_filter_func(short, cls)(lev0[0], *gargs),)
+            got = [g.reshape(g.shape[-2:]) for g in got]
+            what = f"oracle, same grid / field, polynomial truncated to n_steps={n_cpu} on both sides (level 0)"
+        err, same = rel_err_and_nan([g.cpu().numpy() for g in got], want)
+        parity.update({"rel_err": err, "nan_pattern_equal": same, "checked_against": what})
+        if not (err <= parity["tolerance"] and same):
+            failed.append(f"oracle: rel_err {err:.3e}, nan_pattern_equal {same}")
+        del want
+    else:
+        out["cpu_baseline"] = None
+    out["parity"] = parity
+    # ---- the other BASELINE configs, briefly ---------------------------------------------------------------------
+    if not args.no_extra:
+        extras = []
+        for cfg in (2, 4, 5):
+            if cfg == args.config:
+                continue
+            r = None
+            free_gpu()
+            r = run_single(cfg, args, dev, steps=3, warmup=1)
+            rec = {"config": workload_name(cfg, r, args), "n_steps": r["n_steps"], "steps": 3, "warmup": 1,
+                   "value": r["cells"] * r["n_steps"] * 3 / r["elapsed"], "unit": "cell-steps/s",
+                   "ms_per_step": 1e3 * r["elapsed"] / 3, "dtype": "f64" if r["itemsize"] == 8 else "f32",
+                   "roofline": roofline_of(cfg, r, 3, True)}
+            chk = golden_probe_check(cfg, 0.0, (args.ny, args.nx), r["outs"])
+            if chk is not None:
+                rec["parity"] = dict(finish_probe_check(chk), tolerance=tol(r["itemsize"]))
+                if not rec["parity"]["rel_err"] <= rec["parity"]["tolerance"]:
+                    failed.append(f"config {cfg} reference probes: rel_err {rec['parity']['rel_err']:.3e}")
+            if cfg == 5 and not args.no_cpu:
+                rec["cpu_baseline_pool"] = cpu_baseline_pool(5, args.ny, args.nx, r["nbatch"], 4)
+            extras.append(rec)
+        out["extra_configs"] = extras
+    if args.config == 5 and not args.no_cpu:
+        out["cpu_baseline_pool"] = cpu_baseline_pool(5, args.ny, args.nx, nbatch_main, 4)
+    print(json.dumps(out))
+    if failed:
+        print("bench.py: PARITY FAILURE -- " + "; ".join(failed), file=sys.stderr)
+        return 1
+    return 0
+
+
+def main_multi(args, world, rank, local_rank):
+    import torch
+    import torch.distributed as dist
+
+    from gcm_filters_amd import testing as T
+
+    share_gpu = os.environ.get("GCMF_BENCH_SHARE_GPU") == "1"  # test hook: all ranks on cuda:0 over gloo
     if share_gpu:
         local_rank = 0
+    if not share_gpu and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} HIP devices visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if share_gpu:
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=dev)
+    cpu_dev = "cpu" if share_gpu else dev
 
-    from gcm_filters_amd import Filter, GridType
-    from gcm_filters_amd.kernels import ALL_KERNELS
-
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-
-    ny_global = args.ny * world if (world > 1 and args.scaling == "weak") else args.ny
-    if args.nlev <= 0:
-        args.nlev = 50 if args.config == 5 else 1
-    wl = build_workload(args.config, ny_global if world > 1 else args.ny, args.nx, args.nlev, args.f32, args.f64)
-    grid, fk = wl["grid"], wl["fk"]
-    itemsize = wl["fields"][0].dtype.itemsize
-    nbatch = 1 if wl["fields"][0].ndim == 2 else wl["fields"][0].shape[0]
-
-    if world == 1:
-        flt = Filter(grid_type=GridType[grid], grid_vars=wl["grid_vars"], **fk)
-        n_steps = int(flt.n_steps)
-        lap = ALL_KERNELS[GridType[grid]](*[wl["grid_vars"][k] for k in ALL_KERNELS[GridType[grid]].required_grid_args()])
-        from gcm_filters_amd import _lib
-        plan = lap._plan(_lib.F64 if itemsize == 8 else _lib.F32, (args.ny, args.nx), local_rank)
-        if args.rows_per_wave or args.xcd_remap >= 0 or args.multi or args.strip or args.prefetch:
-            plan.set_tuning(args.rows_per_wave, args.xcd_remap, args.multi or 8, args.strip, args.prefetch)
-        plan.set_timing(True)
-        d_in = [torch.from_numpy(f).to(dev) for f in wl["fields"]]
-        run = (lambda: flt.apply_to_vector(d_in[0], d_in[1])) if len(d_in) == 2 else (lambda: flt.apply(d_in[0]))
+    def timed(fn, barrier=True):
         for _ in range(args.warmup):
-            run()
+            fn()
+        dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        kernel_ms, launches = 0.0, 0
         for _ in range(args.steps):
-            run()
-            ms, nl = plan.last_timing()  # hipEvents on the stream the kernels ran on
-            kernel_ms += ms
-            launches += nl
+            fn()
         torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        cells = args.ny * args.nx * nbatch
+        dist.barrier()
+        el = time.perf_counter() - t0
+        tt = torch.tensor([el], device=cpu_dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    failed = []
+    cfg = args.config
+    if cfg in (5, 6):
+        # ---- levels over GPUs: the reference's own (dask) parallelism, zero communication -------------
+        from gcm_filters_amd import Filter, FilterShape, GridType
+        nlev = args.nlev or (50 if cfg == 5 else 8)
+        lo, hi = (rank * nlev) // world, ((rank + 1) * nlev) // world
+        wl = T.baseline_workload(cfg, (args.ny, args.nx), f32=args.f32, f64=args.f64, scale=args.filter_scale,
+                                 levels=list(range(lo, hi)))
+        grid, fk = wl["grid"], wl["fk"]
+        flt = Filter(grid_type=GridType[grid], grid_vars=wl["grid_vars"], filter_scale=fk["filter_scale"],
+                     dx_min=fk["dx_min"], filter_shape=FilterShape[fk["filter_shape"]])
+        n_steps = int(flt.n_steps)
+        d_in = [torch.from_numpy(f).to(dev) for f in wl["fields"]]
+        keep = {}
+
+        def one():
+            keep["o"] = flt.apply_to_vector(d_in[0], d_in[1]) if hi > lo else None
+        elapsed = timed(one)
+        itemsize = wl["fields"][0].dtype.itemsize
+        cells = nlev * args.ny * args.nx
+        scaling, par = "strong", f"levels x{world} ({nlev} levels in all, {hi - lo} on rank 0; no communication)"
+        chk = golden_probe_check(cfg, args.filter_scale, (args.ny, args.nx), keep["o"]) if (rank == 0 and hi > lo) else None
+        parity = dict(finish_probe_check(chk), tolerance=1e-6 if itemsize == 8 else 1e-4) if chk else None
+        weak = None
+        ny_global = args.ny
+        kernel_ms = launches = 0
     else:
         from gcm_filters_amd.distributed import SlabFilter
-        sf = SlabFilter(grid, wl["grid_vars"], fk, ny_global, args.nx, halo=args.halo or None,
-                        dtype=np.float64 if itemsize == 8 else np.float32, device=local_rank)
-        if args.multi:
-            sf.multi_depth = args.multi
-        sf.time_kernels = True
-        n_steps = sf.n_steps
-        local = sf.scatter_from_global(wl["fields"])
-        for _ in range(args.warmup):
-            sf.apply_local(local)
-        sf.collect_kernel_times()
-        sf.kernel_ms, sf.kernel_launches = 0.0, 0
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            sf.apply_local(local)
-        torch.cuda.synchronize()
-        dist.barrier()
-        elapsed = time.perf_counter() - t0
-        tt = torch.tensor([elapsed], device="cpu" if share_gpu else dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        sf.collect_kernel_times()
-        kernel_ms, launches = sf.kernel_ms, sf.kernel_launches
-        cells = ny_global * args.nx * nbatch
 
-    value = cells * n_steps * args.steps / elapsed
-    out = {
-        "metric": "grid-cells*Laplacian-steps/sec",
-        "value": value,
-        "unit": "cell-steps/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True,
-        "scaling": args.scaling if world > 1 else "weak",
-        "vs_baseline": None,
-        "dtype": "f64" if itemsize == 8 else "f32",
-        "data": "synthetic",
-        "config": {
-            "workload": f"{'BASELINE config' if (args.config <= 5 and not args.f64) else 'extra config'} {args.config}{' (f64 variant)' if args.f64 else ''}: {grid} {args.ny}x{args.nx}"
-                        + (f" x{nbatch} levels" if nbatch > 1 else "") + (f" per GPU, {world} row slabs" if world > 1 and args.scaling == "weak" else ""),
-            "filter": f"{fk['filter_shape'].name} filter_scale={fk['filter_scale']:.6g} dx_min={fk['dx_min']:.6g}",
-            "n_steps": n_steps,
-            "global_grid": [ny_global if world > 1 else args.ny, args.nx],
-            "parallelism": f"row-slabs x{world}" if world > 1 else "single GPU",
-        },
-    }
+        def build(ny_global, scaling):
+            wl = T.baseline_workload(cfg, (ny_global, args.nx), scale=args.filter_scale)
+            fk = dict(wl["fk"])
+            sf = SlabFilter(wl["grid"], wl["grid_vars"], fk, ny_global, args.nx, halo=args.halo or None,
+                            dtype=wl["fields"][0].dtype, device=local_rank, exchange=args.exchange)
+            if args.multi:
+                sf.multi_depth = args.multi
+            sf.time_kernels = True
+            return wl, sf, sf.scatter_from_global(wl["fields"])
+
+        def measure(ny_global, scaling):
+            wl, sf, local = build(ny_global, scaling)
+            keep = {}
+
+            def one():
+                keep["o"] = sf.apply_local(local)
+            for _ in range(args.warmup):
+                one()
+            sf.collect_kernel_times()
+            sf.kernel_ms, sf.kernel_launches = 0.0, 0
+            elapsed = timed(one)
+            sf.collect_kernel_times()
+            return wl, sf, keep["o"], elapsed
+
+        ny_global = args.ny * world if args.scaling == "weak" else args.ny
+        wl, sf, outs, elapsed = measure(ny_global, args.scaling)
+        grid, fk, n_steps = wl["grid"], wl["fk"], sf.n_steps
+        itemsize = wl["fields"][0].dtype.itemsize
+        cells = ny_global * args.nx
+        scaling = args.scaling
+        par = f"row-slabs x{world}, halo {sf.halo} rows exchanged every {sf.halo} steps ({sf.exchange_kind})"
+        kernel_ms, launches = sf.kernel_ms, sf.kernel_launches
+        # parity of the timed (strong) workload against the reference's probes: every rank checks the probes it owns
+        parity = None
+        chk = golden_probe_check(cfg, args.filter_scale, (ny_global, args.nx), outs, sf.row_begin, sf.row_end)
+        if chk is not None:
+            g = torch.from_numpy(np.nan_to_num(chk["got"])).to(cpu_dev)
+            m = torch.from_numpy(np.broadcast_to(chk["mine"], chk["got"].shape).astype(np.float64)).to(cpu_dev)
+            dist.all_reduce(g)
+            dist.all_reduce(m)
+            assert bool((m == 1).all()), "every probe must be owned by exactly one rank"
+            chk["got"], chk["mine"] = g.cpu().numpy(), np.ones(chk["mine"].shape, dtype=bool)
+            parity = dict(finish_probe_check(chk), tolerance=1e-6 if itemsize == 8 else 1e-4)
+        weak = None
+        if args.scaling == "strong" and not args.no_weak:
+            del sf, outs
+            free_gpu()
+            wl2, sf2, _, el2 = measure(args.ny * world, "weak")
+            weak = {"value": args.ny * world * args.nx * sf2.n_steps * args.steps / el2, "unit": "cell-steps/s",
+                    "ms_per_step": 1e3 * el2 / args.steps, "global_grid": [args.ny * world, args.nx],
+                    "note": "second figure: every GPU owns a full BASELINE-size slab of an (N*ny, nx) grid"}
+    if parity is not None and not parity["rel_err"] <= parity["tolerance"]:
+        failed.append(f"reference probes: rel_err {parity['rel_err']:.3e}")
     if rank == 0:
-        w = itemsize
-        b_alg = B_ALG[grid](w, 8, nbatch)
-        cells_per_launch = (cells // world) if world > 1 else cells
-        if launches and kernel_ms > 0:
-            # a launch of the temporally blocked kernel advances several steps: price every launch with the
-            # cell-steps it processed (sum over launches = cells * n_steps per filter application)
-            avg_ms = kernel_ms / launches
-            steps_per_launch = n_steps * args.steps / launches
-            achieved = b_alg * cells_per_launch * steps_per_launch / (avg_ms * 1e-3) / 1e9
-            # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/),
-            # valid for the default tuning at N=1 only
-            traffic, kname = None, {"VECTOR_C_GRID": "k_cgrid_stream", "VECTOR_B_GRID": "k_bgrid_stream"}.get(grid, "k_scalar_multi")
-            tf = os.path.join(REPO, "profiles", "hbm_traffic.json")
-            default_tuning = not (args.multi or args.strip or args.prefetch or args.rows_per_wave or args.xcd_remap >= 0)
-            if os.path.exists(tf) and world == 1 and default_tuning:
-                try:
-                    rec = json.load(open(tf)).get(f"config{args.config}", {})
-                    traffic, kname = rec.get("bytes_per_launch"), rec.get("kernel_short", kname)
-                except Exception:
-                    traffic = None
-            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "kernel": kname,
-                               "avg_launch_ms": avg_ms, "steps_per_launch": steps_per_launch,
-                               "alg_bytes_per_launch": b_alg * cells_per_launch * steps_per_launch,
-                               "alg_bytes_per_cell_step": b_alg}
-        else:
-            out["roofline"] = None
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_steps)
-        else:
-            out["cpu_baseline"] = None
+        out = {
+            "metric": "grid-cells*Laplacian-steps/sec", "value": cells * n_steps * args.steps / elapsed,
+            "unit": "cell-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": "f64" if itemsize == 8 else "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE config {cfg}: {grid} {ny_global}x{args.nx}"
+                                   + (f" x{args.nlev or 50} levels" if cfg == 5 else ""),
+                       "filter": f"{fk['filter_shape']} filter_scale={fk['filter_scale']:.6g} dx_min={fk['dx_min']:.6g}",
+                       "n_steps": n_steps, "global_grid": [ny_global, args.nx], "parallelism": par},
+            "parity": parity, "weak": weak, "cpu_baseline": None,
+            "roofline": None if not launches else {
+                "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "kernel_ms_per_step_rank0": kernel_ms / args.steps,
+                "launches_per_step_rank0": launches / args.steps,
+                "achieved": b_alg(grid, itemsize, 8, 1) * (cells / world) * n_steps * args.steps / (kernel_ms * 1e-3) / 1e9,
+                "frac": b_alg(grid, itemsize, 8, 1) * (cells / world) * n_steps * args.steps / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic": None, "note": "per GPU, rank 0: algorithmic bytes of its slab / time between its first and last launch "
+                                         "(includes exchange waits); see the N=1 line for the kernel-level roofline"},
+        }
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        if failed:
+            print("bench.py: PARITY FAILURE -- " + "; ".join(failed), file=sys.stderr)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 1 if failed else 0
+
+
+def main():
+    args = parse()
+    if args.nlev <= 0 and args.config == 6:
+        args.nlev = 0
+    world = int(os.environ.get("WORLD_SIZE", "0"))
+    if world == 0 and args.gpus > 1:
+        self_launch(args)  # does not return
+    world = max(world, 1)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
+    if world == 1:
+        return main_single(args)
+    return main_multi(args, world, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")))
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

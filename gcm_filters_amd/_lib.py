@@ -29,15 +29,17 @@ EXPORTS = [
     "gcmf_grid_is_tripolar", "gcmf_plan_rows", "gcmf_apply", "gcmf_laplacian", "gcmf_cheb_step", "gcmf_prepare",
     "gcmf_last_timing", "gcmf_set_timing", "gcmf_set_tuning", "gcmf_last_error", "gcmf_version",
     "gcmf_multi_supported", "gcmf_cheb_multi", "gcmf_multi_supported_vec", "gcmf_cheb_multi_vec",
-    "gcmf_has_land", "gcmf_zero_land", "gcmf_land_fix",
+    "gcmf_has_land", "gcmf_zero_land", "gcmf_land_fix", "gcmf_last_kernel",
+    "gcmf_comm_unique_id", "gcmf_comm_create", "gcmf_comm_destroy", "gcmf_halo_start", "gcmf_halo_finish",
 ]
+PLAN_SELF_RING = 0x1
 
 
 class PlanDesc(C.Structure):
     _fields_ = [
         ("grid_type", C.c_int32), ("dtype", C.c_int32), ("ny", C.c_int64), ("nx", C.c_int64),
         ("row_begin", C.c_int64), ("row_end", C.c_int64), ("halo", C.c_int32), ("device", C.c_int32),
-        ("planes_on_device", C.c_int32), ("reserved", C.c_int32),
+        ("planes_on_device", C.c_int32), ("flags", C.c_int32),
     ]
 
 
@@ -99,6 +101,19 @@ def load() -> C.CDLL:
         lib.gcmf_prepare.restype = C.c_int
         lib.gcmf_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         lib.gcmf_last_timing.restype = C.c_int
+        lib.gcmf_comm_unique_id.argtypes = [C.c_char_p]
+        lib.gcmf_comm_unique_id.restype = C.c_int
+        lib.gcmf_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, vpp]
+        lib.gcmf_comm_create.restype = C.c_int
+        lib.gcmf_comm_destroy.argtypes = [vp]
+        lib.gcmf_comm_destroy.restype = None
+        lib.gcmf_halo_start.argtypes = [vp, vpp, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, vp]
+        lib.gcmf_halo_start.restype = C.c_int
+        lib.gcmf_halo_finish.argtypes = [vp, vp]
+        lib.gcmf_halo_finish.restype = C.c_int
+        lib.gcmf_last_kernel.argtypes = [vp, C.c_char_p, C.c_int]
+        lib.gcmf_last_kernel.restype = C.c_int
         lib.gcmf_set_timing.argtypes = [vp, C.c_int]
         lib.gcmf_set_timing.restype = C.c_int
         lib.gcmf_set_tuning.argtypes = [vp, C.c_int, C.c_int, C.c_int]
@@ -144,14 +159,15 @@ class Plan:
     """Owning handle of a gcmf_plan."""
 
     def __init__(self, grid_type: int, dtype: int, ny: int, nx: int, planes: Sequence, *, device: int = 0,
-                 row_begin: int = 0, row_end: Optional[int] = None, halo: int = 0, planes_on_device: bool = False):
+                 row_begin: int = 0, row_end: Optional[int] = None, halo: int = 0, planes_on_device: bool = False,
+                 self_ring: bool = False):
         lib = load()
         self._h = None
         self.grid_type, self.dtype, self.ny, self.nx, self.device = int(grid_type), int(dtype), int(ny), int(nx), int(device)
         self.ncomp = lib.gcmf_grid_ncomp(self.grid_type)
         desc = PlanDesc(self.grid_type, self.dtype, self.ny, self.nx, int(row_begin),
                         int(self.ny if row_end is None else row_end), int(halo), self.device,
-                        1 if planes_on_device else 0, 0)
+                        1 if planes_on_device else 0, PLAN_SELF_RING if self_ring else 0)
         if planes_on_device:
             ptrs = [int(p) for p in planes]
             keep = None
@@ -255,8 +271,51 @@ class Plan:
         check(load().gcmf_last_timing(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def last_kernel(self) -> str:
+        buf = C.create_string_buffer(256)
+        check(load().gcmf_last_kernel(self._h, buf, 256))
+        return buf.value.decode()
+
     def set_tuning(self, rows_per_wave: int = 0, xcd_remap: int = -1, multi_s: int = 0, strip_rows: int = 0,
                    prefetch_rows: int = 0):
         check(load().gcmf_set_tuning(self._h, int(rows_per_wave), int(xcd_remap),
                                      (int(multi_s) & 0xFF) | ((int(strip_rows) & 0xFFFF) << 8)
                                      | ((int(prefetch_rows) & 0xF) << 24)))
+
+
+class Comm:
+    """Owning handle of a gcmf_comm: the RCCL communicator + side stream libgcmf issues halo exchanges on."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        check(load().gcmf_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, uid: bytes, world: int, rank: int, device: int):
+        self._h = None
+        out = C.c_void_p()
+        check(load().gcmf_comm_create(C.create_string_buffer(bytes(uid), 128), int(world), int(rank), int(device),
+                                      C.byref(out)))
+        self._h = out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().gcmf_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def halo_start(self, states: Sequence[int], nblocks, rows_alloc, nx, first_owned, rows_owned, halo, dtype, south, north,
+                   stream: int = 0):
+        check(load().gcmf_halo_start(self._h, _ptr_array(states), len(states), int(nblocks), int(rows_alloc), int(nx),
+                                     int(first_owned), int(rows_owned), int(halo), int(dtype),
+                                     -1 if south is None else int(south), -1 if north is None else int(north),
+                                     C.c_void_p(stream or None)))
+
+    def halo_finish(self, stream: int = 0):
+        check(load().gcmf_halo_finish(self._h, C.c_void_p(stream or None)))

@@ -307,7 +307,13 @@ int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int 
   pl->tripolar = gi.tripolar;
   pl->area_weighted = gi.area_weighted;
   pl->dimensional = gi.dimensional;
-  pl->full = (desc->row_begin == 0 && desc->row_end == desc->ny);
+  const bool ring_of_one = (desc->flags & GCMF_PLAN_SELF_RING) != 0;
+  if (ring_of_one && (gi.tripolar || desc->row_begin != 0 || desc->row_end != desc->ny)) {
+    delete pl;
+    set_error("gcmf_plan_create: GCMF_PLAN_SELF_RING needs a non-tripolar plan covering the whole grid");
+    return GCMF_ERR_INVALID_ARG;
+  }
+  pl->full = (desc->row_begin == 0 && desc->row_end == desc->ny) && !ring_of_one;
   int64_t gs = 0, gn = 0;
   if (!pl->full) {
     if (desc->halo < 1) {
@@ -407,6 +413,14 @@ int gcmf_last_timing(const gcmf_plan *pl, float *ms_total, int *n_launches) {
   if (!pl) return GCMF_ERR_INVALID_ARG;
   if (ms_total) *ms_total = pl->last_ms;
   if (n_launches) *n_launches = pl->last_launches;
+  return GCMF_OK;
+}
+int gcmf_last_kernel(gcmf_plan *pl, char *buf, int n) {
+  if (!pl || !buf || n < 1) return GCMF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(pl->mu);
+  snprintf(buf, (size_t)n, "%s", pl->last_kernel.c_str());
+  pl->last_kernel.clear();
+  pl->last_kernel_weight = 0;
   return GCMF_OK;
 }
 int gcmf_set_tuning(gcmf_plan *pl, int rows_per_wave, int xcd_remap, int multi_s) {

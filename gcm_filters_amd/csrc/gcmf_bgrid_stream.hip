@@ -200,6 +200,7 @@ template <typename T, typename FB> static int launch_bs(gcmf_plan *pl, const Ste
   const long long nwaves = (long long)P.ngroups * P.nlev;
   dim3 block(256), grid((unsigned)((nwaves + 3) / 4));
   hipLaunchKernelGGL((k_bgrid_stream<T, FB>), grid, block, 0, s, P);
+  note_kernel(pl, std::string("gcmf::k_bgrid_stream<") + tyname<T>() + ", " + tyname<FB>() + ">", 1);
   GCMF_HIP(hipGetLastError());
   return GCMF_OK;
 }

@@ -351,6 +351,8 @@ template <typename T, typename FB, int VEC, int S, int D, bool PRIV> static int 
   dim3 block(PRIV ? 64 : 256), grid((unsigned)(blocks_per_xcd * 8));
   const size_t lds = (size_t)(PRIV ? S - 1 : S + 1) * 8 * 64 * sizeof(MPack<T, VEC>);
   hipLaunchKernelGGL((k_bgrid_stream2<T, FB, VEC, S, D, PRIV>), grid, block, lds, s, P);
+  note_kernel(pl, std::string("gcmf::k_bgrid_stream2<") + tyname<T>() + ", " + tyname<FB>() + ", " + std::to_string(VEC) + ", " +
+                      std::to_string(S) + ", " + std::to_string(D) + ", " + (PRIV ? "true" : "false") + ">", S);
   GCMF_HIP(hipGetLastError());
   return GCMF_OK;
 }

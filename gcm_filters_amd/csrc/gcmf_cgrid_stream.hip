@@ -312,6 +312,7 @@ template <typename T, typename FB> static int launch_cs(gcmf_plan *pl, const Ste
   const long long waves_per_xcd = groups_per_xcd * P.nlev4;
   const long long blocks_per_xcd = (waves_per_xcd + 3) / 4;
   dim3 block(256), grid((unsigned)(blocks_per_xcd * 8));
+  note_kernel(pl, std::string("gcmf::k_cgrid_stream<") + tyname<T>() + ", " + tyname<FB>() + ", 2, " + (P.lockstep ? "true" : "false") + ">", 1);
   if (P.lockstep) hipLaunchKernelGGL((k_cgrid_stream<T, FB, 2, true>), grid, block, 0, s, P);
   else hipLaunchKernelGGL((k_cgrid_stream<T, FB, 2, false>), grid, block, 0, s, P);
   GCMF_HIP(hipGetLastError());

@@ -398,6 +398,8 @@ template <typename T, typename FB, int VEC, int S, int D, bool PRIV> static int 
     attr_set = true;
   }
   hipLaunchKernelGGL((k_cgrid_stream2<T, FB, VEC, S, D, PRIV>), grid, block, lds, s, P);
+  note_kernel(pl, std::string("gcmf::k_cgrid_stream2<") + tyname<T>() + ", " + tyname<FB>() + ", " + std::to_string(VEC) + ", " +
+                      std::to_string(S) + ", " + std::to_string(D) + ", " + (PRIV ? "true" : "false") + ">", S);
   GCMF_HIP(hipGetLastError());
   return GCMF_OK;
 }

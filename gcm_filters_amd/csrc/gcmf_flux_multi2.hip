@@ -291,6 +291,7 @@ template <typename T, typename FB, int S> static int launch_f2(gcmf_plan *pl, co
   P.c = a.c;
   dim3 block(256), grid((P.nwaves + 3) / 4, (unsigned)a.nbatch);
   hipLaunchKernelGGL((k_flux_multi2<T, FB, S>), grid, block, 0, s, P);
+  note_kernel(pl, std::string("gcmf::k_flux_multi2<") + tyname<T>() + ", " + tyname<FB>() + ", " + std::to_string(S) + ">", S);
   GCMF_HIP(hipGetLastError());
   return GCMF_OK;
 }

@@ -129,6 +129,10 @@ struct gcmf_plan {
   hipEvent_t ev_busy = nullptr;  // end of the last gcmf_apply that used the plan's work buffers
   bool busy_valid = false;
   bool timing = false;
+  // the recurrence kernel with the most steps per launch since gcmf_last_kernel was last read (instrumentation:
+  // bench.py ties its HBM-traffic figures to the kernel that actually ran)
+  std::string last_kernel;
+  int last_kernel_weight = 0;
   float last_ms = 0.f;
   int last_launches = 0;
   int rows_per_wave = 0;
@@ -153,6 +157,14 @@ struct gcmf_plan {
 };
 
 namespace gcmf {
+template <typename T> inline const char *tyname() { return sizeof(T) == 8 ? "double" : "float"; }
+// name as rocprofv3 prints it (without "void " and the argument list); weight = recurrence steps per launch
+inline void note_kernel(gcmf_plan *pl, const std::string &name, int weight) {
+  if (weight >= pl->last_kernel_weight) {
+    pl->last_kernel = name;
+    pl->last_kernel_weight = weight;
+  }
+}
 size_t dtype_size(int dtype);
 // kernel launchers (defined in gcmf_scalar.hip / gcmf_vector.hip)
 int launch_scalar_step(gcmf_plan *pl, const StepArgs &a, hipStream_t s);

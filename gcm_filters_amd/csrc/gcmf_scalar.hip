@@ -270,6 +270,8 @@ static int launch_k(gcmf_plan *pl, const StepArgs &a, hipStream_t s) {
   P.per_xcd = (pl->xcd_remap && nty >= 16) ? (P.ntiles + 7) / 8 : 0;
   dim3 grid(P.per_xcd ? 8 * P.per_xcd : P.ntiles, (unsigned)a.nbatch, 1);
   hipLaunchKernelGGL((k_scalar_step<T, FB, KIND, VEC>), grid, block, 0, s, P);
+  note_kernel(pl, std::string("gcmf::k_scalar_step<") + tyname<T>() + ", " + tyname<FB>() + ", " + std::to_string(KIND) + ", " +
+                      std::to_string(VEC) + ">", 1);
   GCMF_HIP(hipGetLastError());
   return GCMF_OK;
 }

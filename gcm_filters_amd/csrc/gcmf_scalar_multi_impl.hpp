@@ -485,6 +485,8 @@ static int launch_multi_s(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   P.c = a.c;
   dim3 block(256), grid((P.nwaves + 3) / 4, (unsigned)a.nbatch);
   hipLaunchKernelGGL((k_scalar_multi<T, FB, KIND, S, D>), grid, block, 0, s, P);
+  note_kernel(pl, std::string("gcmf::k_scalar_multi<") + tyname<T>() + ", " + tyname<FB>() + ", " + std::to_string(KIND) + ", " +
+                      std::to_string(S) + ", " + std::to_string(D) + ">", S);
   GCMF_HIP(hipGetLastError());
   return GCMF_OK;
 }

@@ -41,9 +41,9 @@ class HipSlabEngine:
     """Executes slab steps on the MI355X through libgcmf (gcmf_prepare / gcmf_cheb_step)."""
 
     def __init__(self, grid_type: GridType, dtype_code: int, ny: int, nx: int, planes: Sequence[np.ndarray],
-                 row_begin: int, row_end: int, halo: int, device: int):
+                 row_begin: int, row_end: int, halo: int, device: int, self_ring: bool = False):
         self.plan = _lib.Plan(grid_type.value, dtype_code, ny, nx, planes, device=device, row_begin=row_begin,
-                              row_end=row_end, halo=halo)
+                              row_end=row_end, halo=halo, self_ring=self_ring)
         self.rows_alloc, self.first_owned, self.rows_owned = (self.plan.rows_alloc, self.plan.first_owned,
                                                               self.plan.rows_owned)
 
@@ -86,11 +86,18 @@ class SlabFilter:
     Parameters mirror ``Filter``: ``grid_type`` (name or GridType), ``grid_vars`` = GLOBAL (ny, nx) host arrays
     (every rank folds its own slab from them), ``filter_kwargs`` = filter_scale, dx_min, filter_shape, ...
     ``engine_factory`` is for tests only (CPU stand-in for the HIP engine on the gloo backend).
+
+    ``exchange``: who issues the halo exchange -- ``"native"``: libgcmf itself (gcmf_halo_start / gcmf_halo_finish: RCCL
+    send / recv on a side stream, a few microseconds of host time per exchange), ``"torch"``: torch.distributed P2P ops
+    (any backend; what the gloo tests use), ``"auto"``: native on one-GPU-per-rank RCCL groups, torch otherwise.
+    ``self_ring`` (one rank, periodic grids): keep ghost rows and exchange with itself -- the whole slab choreography
+    incl. the native exchange on a single GPU.
     """
 
     def __init__(self, grid_type, grid_vars: Dict[str, np.ndarray], filter_kwargs: dict, ny: int, nx: int, *,
                  halo: Optional[int] = None, dtype=np.float64, group=None, device=None, engine_factory=None,
-                 rank: Optional[int] = None, world: Optional[int] = None):
+                 rank: Optional[int] = None, world: Optional[int] = None, exchange: str = "auto",
+                 self_ring: bool = False):
         import torch
         import torch.distributed as dist
 
@@ -98,6 +105,10 @@ class SlabFilter:
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
+        self.self_ring = bool(self_ring)
+        if self.self_ring and self.world != 1:
+            raise ValueError("self_ring is the one-rank form of the slab driver")
+        self.multi = self.world > 1 or self.self_ring   # ghost rows + exchanges are in play
         self.grid_type = GridType[grid_type] if isinstance(grid_type, str) else grid_type
         self.lap_cls = ALL_KERNELS[self.grid_type]
         self.ncomp = self.lap_cls._NCOMP
@@ -122,7 +133,7 @@ class SlabFilter:
         min_rows = self.ny // self.world
         if min_rows < 1:
             raise ValueError(f"{self.ny} rows cannot be split over {self.world} ranks")
-        if self.world == 1:
+        if not self.multi:
             self.halo = 0
         else:
             # default: 8 ghost rows (one blocked launch) per ~300 owned rows, at most 64: an exchange costs a few
@@ -137,16 +148,36 @@ class SlabFilter:
             device = torch.cuda.current_device() if torch.cuda.is_available() else -1
         self.device = torch.device("cuda", device) if device >= 0 else torch.device("cpu")
         factory = engine_factory or HipSlabEngine
-        self.engine = factory(self.grid_type, self.dtype_code, self.ny, self.nx, planes, self.row_begin, self.row_end,
-                              self.halo, device)
+        if self.self_ring:
+            if self.tripolar:
+                raise ValueError("self_ring needs a grid that is periodic in y")
+            self.engine = factory(self.grid_type, self.dtype_code, self.ny, self.nx, planes, self.row_begin, self.row_end,
+                                  self.halo, device, self_ring=True)
+        else:
+            self.engine = factory(self.grid_type, self.dtype_code, self.ny, self.nx, planes, self.row_begin,
+                                  self.row_end, self.halo, device)
         self.rows_alloc, self.first_owned, self.rows_owned = (self.engine.rows_alloc, self.engine.first_owned,
                                                               self.engine.rows_owned)
         # neighbours; None where the slab edge is a physical boundary (tripolar) or there is a single rank
         P, r = self.world, self.rank
         self.gs = self.first_owned                                   # southern ghost rows
         self.gn = self.rows_alloc - self.first_owned - self.rows_owned  # northern ghost rows
-        self.south = ((r - 1) % P) if (P > 1 and self.gs > 0) else None
-        self.north = ((r + 1) % P) if (P > 1 and self.gn > 0) else None
+        self.south = ((r - 1) % P) if (self.multi and self.gs > 0) else None
+        self.north = ((r + 1) % P) if (self.multi and self.gn > 0) else None
+        # who issues the exchange
+        if exchange not in ("auto", "native", "torch"):
+            raise ValueError(f"exchange must be 'auto', 'native' or 'torch', not {exchange!r}")
+        on_gpu = self.device.type == "cuda" and engine_factory is None
+        rccl_group = self.self_ring or (dist.is_initialized() and dist.get_backend(group) == "nccl")
+        if exchange == "native" and not (on_gpu and rccl_group):
+            raise ValueError("exchange='native' needs one MI355X per rank (RCCL process group or self_ring)")
+        self.exchange_kind = "native" if (self.multi and on_gpu and rccl_group and exchange != "torch") else "torch"
+        self.comm = None
+        if self.exchange_kind == "native" and self.multi:
+            uid = [_lib.Comm.unique_id() if self.rank == 0 else None]
+            if self.world > 1:
+                dist.broadcast_object_list(uid, src=self._global_rank(0), group=group)
+            self.comm = _lib.Comm(uid[0], self.world, self.rank, device)
         self.tdtype = torch.float64 if self.np_dtype == np.float64 else torch.float32
         self._bufs = {}
         self.kernel_ms = 0.0
@@ -213,8 +244,14 @@ class SlabFilter:
     def _exchange_start(self, tensors: List):
         """Pack the boundary rows and post the sends / receives; returns a ticket for ``_exchange_finish``.  Work
         enqueued on the compute stream AFTER this call (the interior of the slab) overlaps with the transfer."""
-        if self.world == 1 or (self.south is None and self.north is None):
+        if not self.multi or (self.south is None and self.north is None):
             return None
+        if self.comm is not None:  # libgcmf issues the RCCL send / recv pairs on its side stream
+            x0 = tensors[0]
+            self.comm.halo_start([x.data_ptr() for x in tensors], x0.shape[0] * x0.shape[1], self.rows_alloc, self.nx,
+                                 self.first_owned, self.rows_owned, self.halo, self.dtype_code, self.south, self.north,
+                                 stream=self.torch.cuda.current_stream().cuda_stream)
+            return "native"
         t, dist = self.torch, self.dist
         s, fo, ro = self.halo, self.first_owned, self.rows_owned
         top = [x[:, :, fo + ro - s: fo + ro, :] for x in tensors]      # -> northern neighbour's south ghosts
@@ -258,6 +295,10 @@ class SlabFilter:
 
     def _exchange_finish(self, ticket):
         if ticket is None:
+            return
+        if ticket == "native":
+            self.comm.halo_finish(stream=self.torch.cuda.current_stream().cuda_stream)
+            self.exchanges += 1
             return
         works, unpack, stage = ticket
         for w in works:
@@ -312,14 +353,14 @@ class SlabFilter:
         k = 1
         while k <= n:
             left = n - k + 1
-            if self.world > 1 and valid == 0:
+            if self.multi and valid == 0:
                 self._exchange([u] if v is None else [u, v])
                 valid = s
                 if land_zeroed:
                     # a neighbour that overlapped its exchange with the first launch sent its rows before it zeroed
                     # them (ranks with unequal row counts decide differently): the ghost rows must honour LAND_ZERO too
                     self.engine.zero_land(comps(u), comps(v), nbatch)
-            budget = min(left, valid if self.world > 1 else left)
+            budget = min(left, valid if self.multi else left)
             S = 1
             if can_multi:
                 for cand in self.MULTI_DEPTHS:
@@ -329,7 +370,7 @@ class SlabFilter:
                         S = cand
                         break
             free = [b for b in pool if b is not u and b is not v]
-            v_out = (valid - S) if self.world > 1 else 0
+            v_out = (valid - S) if self.multi else 0
             lo = fo - (v_out if self.gs else 0)
             hi = fo + ro + (v_out if self.gn else 0)
             is_last = (k + S - 1 == n)
@@ -340,7 +381,7 @@ class SlabFilter:
             if S >= 2:
                 args = (comps(u), None if v is None else comps(v), comps(free[0]), comps(free[1]), comps(F),
                         comps(O) if is_last else comps(F), p[k: k + S], p[0], self.c, mode, nbatch)
-                overlap = (self.overlap and self.world > 1 and v_out == 0 and not is_last and ro >= 4 * s
+                overlap = (self.overlap and self.multi and v_out == 0 and not is_last and ro >= 4 * s
                            and self.engine.multi_supported(S, nbatch))
                 if overlap:
                     # this launch uses up the ghost zone: advance the rows the neighbours need first, post the halo

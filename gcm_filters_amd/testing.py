@@ -204,3 +204,68 @@ def grid_dx_min(grid_type: str, grid_vars) -> float:
     if not spacing:
         return 1.0
     return float(min(np.min(s) for s in spacing))
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json workloads: one definition shared by bench.py, the full-size GPU tests and
+# tests/golden/make_golden.py (which feeds the very same arrays to the imported reference)
+# ------------------------------------------------------------------------------------------------
+BASELINE_SHAPE = (2400, 3600)
+BASELINE_GRID = {1: "REGULAR", 2: "REGULAR_WITH_LAND", 3: "IRREGULAR_WITH_LAND", 4: "TRIPOLAR_POP_WITH_LAND",
+                 5: "VECTOR_C_GRID", 6: "VECTOR_B_GRID"}
+
+
+def baseline_workload(cfg: int, shape=BASELINE_SHAPE, nlev: int = 0, f32: bool = False, f64: bool = False,
+                      scale: float = 0.0, levels=None):
+    """Synthetic inputs of BASELINE.json config `cfg` (6 = the B-grid extra) on `shape`.
+
+    Returns dict(grid, fields, grid_vars, fk) with fk = dict(filter_scale, dx_min, filter_shape name).
+    `scale` overrides the filter scale in units of dx_min (config 2: 10 => n_steps 11, 50 => 56).
+    `levels` selects which vertical levels of configs 5 / 6 to build (default range(nlev)); a level's
+    fields depend only on its own index, so a subset equals the same levels of the full workload."""
+    shape = tuple(shape)
+    if cfg in (1, 2):
+        grid = BASELINE_GRID[cfg]
+        gv = {} if cfg == 1 else {"wet_mask": land_mask(shape)}
+        fields = [random_field(shape, 100)]
+        fk = dict(filter_scale=float(scale or 50.0), dx_min=1.0, filter_shape="GAUSSIAN")
+    elif cfg in (3, 4):
+        grid = BASELINE_GRID[cfg]
+        gv = scalar_grid_vars(grid, shape)
+        fields = [random_field(shape, 100)]
+        dx = grid_dx_min(grid, gv)
+        if cfg == 3:
+            fk = dict(filter_scale=(scale or 16) * dx, dx_min=dx, filter_shape="TAPER")
+        else:
+            fk = dict(filter_scale=(scale or 50) * dx, dx_min=dx, filter_shape="GAUSSIAN")
+    elif cfg == 5:
+        grid = "VECTOR_C_GRID"
+        cdt = np.float64 if f64 else np.float32   # BASELINE config 5 is f32; f64 is an extra measurement
+        gv = {k: v.astype(cdt) for k, v in vector_grid_vars(grid, shape).items()}
+        gv["kappa_aniso"] = np.zeros(shape, dtype=cdt)
+        lv = list(levels) if levels is not None else list(range(nlev or 50))
+        fields = [np.stack([random_field(shape, 42 + c + 2 * l).astype(cdt) for l in lv]) for c in range(2)]
+        dx = grid_dx_min(grid, gv)
+        fk = dict(filter_scale=(scale or 40) * dx, dx_min=dx, filter_shape="GAUSSIAN")
+    elif cfg == 6:  # not a BASELINE config: the POP B-grid vector Laplacian at the benchmark size
+        grid = "VECTOR_B_GRID"
+        gv = vector_grid_vars(grid, shape)
+        lv = list(levels) if levels is not None else list(range(nlev or 1))
+        if len(lv) <= 1 and levels is None:
+            fields = [random_field(shape, 42), random_field(shape, 43)]
+        else:
+            fields = [np.stack([random_field(shape, 42 + c + 2 * l) for l in lv]) for c in range(2)]
+        if f32:
+            gv = {k: v.astype(np.float32) for k, v in gv.items()}
+            fields = [f.astype(np.float32) for f in fields]
+        dx = grid_dx_min(grid, gv)
+        fk = dict(filter_scale=(scale or 40) * dx, dx_min=dx, filter_shape="GAUSSIAN")
+    else:
+        raise ValueError(f"unknown BASELINE config {cfg}")
+    return dict(grid=grid, fields=fields, grid_vars=gv, fk=fk)
+
+
+def probe_points(shape, n=300, seed=2024):
+    """Seeded (j, i) sample positions of the full-size golden probes (tests/golden/reference_fullsize.npz)."""
+    rng = Generator(PCG64(seed))
+    return rng.integers(0, shape[-2], n), rng.integers(0, shape[-1], n)

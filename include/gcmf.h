@@ -89,8 +89,12 @@ typedef struct gcmf_plan_desc {
   int32_t halo;       /* ghost rows kept on each slab edge that has a neighbour (0: one GPU)   */
   int32_t device;     /* HIP device ordinal                                                    */
   int32_t planes_on_device; /* grid planes are device pointers on `device`                     */
-  int32_t reserved;
+  int32_t flags;      /* GCMF_PLAN_* bits, 0 by default                                        */
 } gcmf_plan_desc;
+
+/* A plan that covers the whole (periodic, non-tripolar) grid but keeps `halo` ghost rows per edge like a slab whose
+ * two neighbours are itself: the one-rank form of the row-slab driver (tests of the exchange path on a single GPU). */
+#define GCMF_PLAN_SELF_RING 0x1
 
 /*
  * Build a plan = the reference's `Laplacian(**grid_vars)` (kernels.py __post_init__ methods):
@@ -208,6 +212,25 @@ int gcmf_zero_land(gcmf_plan *plan, void *const *a, void *const *b, int64_t nbat
 int gcmf_land_fix(gcmf_plan *plan, const double *p, int n_steps, double c, const void *const *in,
                   void *const *out, int64_t nbatch, uint32_t flags, void *stream);
 
+/* ---- halo exchange of the row-slab driver, issued from C++ (RCCL send / recv over xGMI on a side stream) --------- */
+/*
+ * The reference has no spatial decomposition (filter.py:478-486 parallelises over non-core dims only); SURVEY 8e.
+ * gcmf_comm_unique_id: 128 bytes (ncclUniqueId) generated on one rank and handed to every rank by the caller's own
+ * channel (torch.distributed / MPI broadcast).  gcmf_comm_create: collective over `world` processes, one GPU each.
+ * gcmf_halo_start: after everything enqueued on `stream` so far, send the `halo` owned edge rows of every block of the
+ * `nstate` state arrays ((nblocks, rows_alloc, nx), nblocks = ncomp * nbatch, gcmf_dtype `dtype`) to the `south` / `north`
+ * peer ranks (-1: physical boundary, nothing is exchanged there) and receive this slab's ghost rows; returns at once,
+ * work enqueued on `stream` afterwards overlaps with the transfer.  gcmf_halo_finish: `stream` waits for the
+ * exchange.  Between the two calls the caller may update any row except the 2 x halo sent and the ghost rows.
+ */
+typedef struct gcmf_comm gcmf_comm;
+int gcmf_comm_unique_id(void *id128);
+int gcmf_comm_create(const void *id128, int world, int rank, int device, gcmf_comm **out);
+void gcmf_comm_destroy(gcmf_comm *comm);
+int gcmf_halo_start(gcmf_comm *comm, void *const *states, int nstate, int64_t nblocks, int64_t rows_alloc, int64_t nx,
+                    int64_t first_owned, int64_t rows_owned, int halo, int dtype, int south, int north, void *stream);
+int gcmf_halo_finish(gcmf_comm *comm, void *stream);
+
 /* T_0 = prepare(field) = field * area for the AREA_WEIGHTED grid types (kernels.py:100-101),
  * a copy otherwise; rows [row_lo,row_hi) of the slab allocation. */
 int gcmf_prepare(gcmf_plan *plan, const void *const *in, void *const *out, int64_t nbatch,
@@ -218,6 +241,10 @@ int gcmf_prepare(gcmf_plan *plan, const void *const *in, void *const *out, int64
 int gcmf_last_timing(const gcmf_plan *plan, float *ms_total, int *n_launches);
 /* Enable/disable event timing inside gcmf_apply (adds two hipEventRecord per call). */
 int gcmf_set_timing(gcmf_plan *plan, int enabled);
+/* Name (as rocprofv3 prints it, without "void " and the argument list) of the recurrence kernel that advanced the most
+ * steps per launch since this was last called; "" if none ran.  Reading resets it.  Instrumentation only: bench.py
+ * refuses to quote profiled HBM traffic for a kernel other than the one that ran. */
+int gcmf_last_kernel(gcmf_plan *plan, char *buf, int n);
 
 /* Tunables: rows marched per wave of the single-step kernel (0 keeps the default); XCD-aware tile order
  * (1 on, 0 off, <0 keep); temporal blocking: low byte = recurrence steps fused per HBM pass (1 = off,

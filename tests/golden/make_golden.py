@@ -11,6 +11,12 @@ Outputs (committed):
                            from the same seeds.  The case list is `CASES` below; its keys are the npz keys.
   reference_spec.npz       n_steps defaults and Chebyshev coefficients p[] from the reference for a table
                            of (shape, scale, dx_min, transition_width, ndim, n_steps).
+  reference_fullsize.npz   (`--fullsize`, ~6 min of reference time) BASELINE configs 2-5 at 2400 x 3600 run through the
+                           imported reference with their full polynomials: 300 seeded (j, i) probes of the output +
+                           sum / sum of squares / max-abs per case (the planes themselves are too big to
+                           store).  Inputs come from gcm_filters_amd.testing.baseline_workload, like bench.py's.
+
+`--out DIR` writes into DIR instead of this directory (to check that the committed files regenerate).
 
 No reference source text is copied anywhere: only numbers leave this script.
 """
@@ -194,12 +200,62 @@ SPEC_TABLE = [
 ]
 
 
+# full-size cases: key -> (BASELINE config, filter scale in dx_min units (0 = the config's own), NaN on land?)
+FULLSIZE_CASES = {
+    "cfg2_n11": (2, 10.0, False), "cfg2_n56": (2, 50.0, False), "cfg2_n11_nanland": (2, 10.0, True),
+    "cfg3_n63": (3, 0.0, False), "cfg4_n56": (4, 0.0, False), "cfg5_lev0_n44": (5, 0.0, False),
+}
+
+
+def make_fullsize(rf, rk, outdir):
+    """BASELINE configs 2-5 at full size through the imported reference -> probes + checksums."""
+    import time
+    from gcm_filters_amd import testing as T
+
+    out = {}
+    for key, (cfg, scale, nanland) in FULLSIZE_CASES.items():
+        wl = T.baseline_workload(cfg, T.BASELINE_SHAPE, scale=scale, levels=[0] if cfg == 5 else None)
+        grid, gv, fk = wl["grid"], wl["grid_vars"], wl["fk"]
+        fields = [f[0] if f.ndim == 3 else f for f in wl["fields"]]
+        if nanland:
+            fields = [np.where(gv["wet_mask"] == 0, np.nan, f) for f in fields]
+        cls = rk.ALL_KERNELS[rk.GridType[grid]]
+        args = [gv[k] for k in cls.required_grid_args()]
+        shape = rf.FilterShape[fk["filter_shape"]]
+        n = rf._compute_n_steps_default(2, shape, fk["filter_scale"], fk["dx_min"], np.pi)
+        spec = rf._compute_filter_spec(fk["filter_scale"], fk["dx_min"], shape, np.pi, 2, n)
+        assert key.endswith(f"n{int(n)}") or f"_n{int(n)}_" in key, (key, n)
+        t0 = time.time()
+        with np.errstate(all="ignore"):
+            if len(fields) == 2:
+                res = np.stack(rf._create_filter_func_vec(spec, cls)(*fields, *args))
+            else:
+                res = np.asarray(rf._create_filter_func(spec, cls)(*fields, *args))
+        jj, ii = T.probe_points(T.BASELINE_SHAPE)
+        out[key + "/probe"] = res[..., jj, ii].copy()
+        fin = np.isfinite(res)
+        r0 = np.where(fin, res, 0.0)
+        out[key + "/sums"] = np.array([r0.sum(), (r0 * r0).sum(), np.abs(r0).max(), float((~fin).sum())])
+        out[key + "/meta"] = np.array([n, spec.s_max, spec.dx_min_sq])
+        out[key + "/p"] = np.asarray(spec.p)
+        print(f"{key}: n_steps {int(n)} dtype {res.dtype} {time.time() - t0:.1f} s", flush=True)
+    np.savez_compressed(os.path.join(outdir, "reference_fullsize.npz"), **out)
+    print("reference_fullsize.npz:", len(out), "arrays")
+
+
 def main():
     if not os.path.isdir(REF):
         print("reference not mounted: nothing to do")
         return 0
     sys.path.insert(0, REPO)
     rf, rk = import_reference()
+    global HERE
+    if "--out" in sys.argv:
+        HERE = sys.argv[sys.argv.index("--out") + 1]
+        os.makedirs(HERE, exist_ok=True)
+    if "--fullsize" in sys.argv:
+        make_fullsize(rf, rk, HERE)
+        return 0
 
     # 1. the reference's own goldens
     z = {}

@@ -1,0 +1,57 @@
+"""bench.py started WITHOUT a launcher: `--gpus N` must bring up its own N ranks (or fail loudly), never print n_gpus 1
+for a multi-GPU request.  The ranks share the box's one GPU over gloo here (GCMF_BENCH_SHARE_GPU=1)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, timeout=600):
+    env = dict(os.environ, **(env_extra or {}))
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *args], env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def _json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_gpus_8_without_devices_fails_loudly():
+    r = _run(["--gpus", "8", "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0
+    assert "only" in (r.stderr + r.stdout) and "HIP device" in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.parametrize("cfg,extra", [(3, []), (4, ["--scaling", "weak"]), (5, ["--nlev", "5"])])
+def test_self_launch_two_ranks_sharing_the_gpu(cfg, extra):
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--config", str(cfg), "--ny", "256", "--nx", "256",
+              "--no-weak", *extra], {"GCMF_BENCH_SHARE_GPU": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert line["scaling"] == ("weak" if "weak" in extra else "strong")
+    assert line["config"]["global_grid"] == [512 if "weak" in extra else 256, 256]
+
+
+def test_single_gpu_line_carries_parity_and_roofline():
+    r = _run(["--steps", "2", "--warmup", "1", "--no-extra", "--cpu-steps", "3"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 1 and line["config"]["n_steps"] == 63
+    par = line["parity"]
+    assert par["rel_err"] <= 1e-6 and par["nan_pattern_equal"] is True
+    assert par["reference_probes"]["rel_err"] <= 1e-6 and par["reference_probes"]["n_probes"] == 300
+    rf = line["roofline"]
+    assert rf["kernel"].startswith("gcmf::k_") and rf["min_bytes_per_launch"] > 0 and 0 < rf["min_bytes_frac"] < 1
+    assert rf["traffic"] is None or rf["traffic_source"].startswith("profiles/")
+    assert line["cpu_baseline"]["cores"] == 1

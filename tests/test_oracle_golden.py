@@ -116,3 +116,20 @@ def test_oracle_error_contract():
         bad[nm][-1, 3] = 10
         with pytest.raises(AssertionError, match=rf"Northernmost row of {nm} .*"):
             O.make_laplacian("TRIPOLAR_POP_WITH_LAND", bad)
+
+
+def test_oracle_vs_reference_fullsize_fixture():
+    """BASELINE config 2 (REGULAR_WITH_LAND 2400 x 3600, n_steps 11) through the oracle against the probes and checksums
+    the imported reference produced at full size (make_golden.py --fullsize); ~10 s.  The longer cases of that fixture
+    are checked against the GPU path in tests/test_gpu_fullsize.py."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_fullsize.npz")
+    with np.load(path) as z:
+        probe, sums, meta, p = (z["cfg2_n11/" + k] for k in ("probe", "sums", "meta", "p"))
+    wl = T.baseline_workload(2, T.BASELINE_SHAPE, scale=10.0)
+    spec = O.make_spec(wl["fk"]["filter_scale"], wl["fk"]["dx_min"], wl["fk"]["filter_shape"])
+    assert spec.n_steps == int(meta[0]) == 11 and np.array_equal(np.asarray(spec.p), p)
+    res = O.filter_func(spec, wl["grid"], wl["fields"][0], wl["grid_vars"])
+    jj, ii = T.probe_points(T.BASELINE_SHAPE)
+    assert np.array_equal(res[jj, ii], probe.reshape(-1))
+    assert np.array_equal(np.array([res.sum(), (res * res).sum(), np.abs(res).max(), 0.0]), sums)

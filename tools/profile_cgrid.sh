@@ -2,7 +2,7 @@
 set -u
 OUT=$PWD/gpurun_out/prof_cgrid
 mkdir -p "$OUT"; export TMPDIR=/tmp; REPO=$PWD; cd /tmp
-ARGS="--steps 1 --warmup 0 --no-cpu --config 5 --nlev 12"
+ARGS="--steps 1 --warmup 0 --no-cpu --no-extra --config 5 --nlev 12"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- python3 $REPO/bench.py $ARGS > "$OUT/b0.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o pmc -- python3 $REPO/bench.py $ARGS > "$OUT/b1.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write" -o pmc -- python3 $REPO/bench.py $ARGS > "$OUT/b2.log" 2>&1
