@@ -239,24 +239,36 @@ def run_single(cfg, args, dev, steps, warmup, scale=0.0, levels=None, tuned=Fals
         launches += nl
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    return dict(wl=wl, grid=grid, fk=fk, itemsize=itemsize, nbatch=nbatch, n_steps=n_steps, elapsed=elapsed,
+    # the dominant kernel's own launch durations: a second, untimed pass with an event pair around every blocked launch
+    # (on the stream the kernel runs on); kept out of the timed region so that `value` is not perturbed
+    plan.set_timing(2)
+    dom_ms, dom_n, dom_min, dom_max = 0.0, 0, 1e30, 0.0
+    for _ in range(max(1, min(steps, 3))):
+        run()
+        ms, nl, lo, hi = plan.last_kernel_timing()
+        dom_ms, dom_n, dom_min, dom_max = dom_ms + ms, dom_n + nl, min(dom_min, lo), max(dom_max, hi)
+    dom_reps = max(1, min(steps, 3))
+    plan.set_timing(1)
+    return dict(dom_ms=dom_ms, dom_n=dom_n, dom_min=dom_min, dom_max=dom_max, dom_reps=dom_reps, wl=wl, grid=grid, fk=fk, itemsize=itemsize, nbatch=nbatch, n_steps=n_steps, elapsed=elapsed,
                 kernel_ms=kernel_ms, launches=launches, outs=list(outs), kernel=plan.last_kernel(), flt=flt, d_in=d_in,
                 cells=args.ny * args.nx * nbatch)
 
 
 def roofline_of(cfg, r, steps, default_tuning):
     w, nb, grid = r["itemsize"], r["nbatch"], r["grid"]
-    if not (r["launches"] and r["kernel_ms"] > 0):
+    if not (r["dom_n"] and r["dom_ms"] > 0):
         return None
     balg = b_alg(grid, w, 8, nb)
-    avg_ms = r["kernel_ms"] / r["launches"]
-    steps_per_launch = r["n_steps"] * steps / r["launches"]
+    avg_ms = r["dom_ms"] / r["dom_n"]                       # HIP events around each launch of the dominant kernel
+    steps_per_launch = r["n_steps"] * r["dom_reps"] / r["dom_n"]
     achieved = balg * r["cells"] * steps_per_launch / (avg_ms * 1e-3) / 1e9
     minb = min_bytes_per_cell_launch(grid, w, 8, nb) * r["cells"]
     rec, src = load_traffic(cfg, r["kernel"]) if default_tuning else (None, "non-default tuning: traffic withheld")
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "traffic": rec.get("bytes_per_launch") if rec else None, "traffic_source": src,
-           "kernel": r["kernel"], "avg_launch_ms": avg_ms, "steps_per_launch": steps_per_launch,
+           "kernel": r["kernel"], "avg_launch_ms": avg_ms, "min_launch_ms": r["dom_min"], "max_launch_ms": r["dom_max"],
+           "launches_per_application": r["dom_n"] / r["dom_reps"], "steps_per_launch": steps_per_launch,
+           "recurrence_ms_per_application": r["kernel_ms"] / steps,
            "alg_bytes_per_launch": balg * r["cells"] * steps_per_launch, "alg_bytes_per_cell_step": balg,
            "frac_note": "achieved/frac price every Laplacian step with SURVEY 8d's one-pass-per-step byte count; a blocked "
                         "launch advances steps_per_launch steps per pass over HBM, so frac > 1 is possible and is NOT a "
@@ -408,8 +420,8 @@ def main_single(args):
                 continue
             r = None
             free_gpu()
-            r = run_single(cfg, args, dev, steps=3, warmup=1)
-            rec = {"config": workload_name(cfg, r, args), "n_steps": r["n_steps"], "steps": 3, "warmup": 1,
+            r = run_single(cfg, args, dev, steps=3, warmup=2)
+            rec = {"config": workload_name(cfg, r, args), "n_steps": r["n_steps"], "steps": 3, "warmup": 2,
                    "value": r["cells"] * r["n_steps"] * 3 / r["elapsed"], "unit": "cell-steps/s",
                    "ms_per_step": 1e3 * r["elapsed"] / 3, "dtype": "f64" if r["itemsize"] == 8 else "f32",
                    "roofline": roofline_of(cfg, r, 3, True)}

@@ -29,7 +29,7 @@ EXPORTS = [
     "gcmf_grid_is_tripolar", "gcmf_plan_rows", "gcmf_apply", "gcmf_laplacian", "gcmf_cheb_step", "gcmf_prepare",
     "gcmf_last_timing", "gcmf_set_timing", "gcmf_set_tuning", "gcmf_last_error", "gcmf_version",
     "gcmf_multi_supported", "gcmf_cheb_multi", "gcmf_multi_supported_vec", "gcmf_cheb_multi_vec",
-    "gcmf_has_land", "gcmf_zero_land", "gcmf_land_fix", "gcmf_last_kernel",
+    "gcmf_has_land", "gcmf_zero_land", "gcmf_land_fix", "gcmf_last_kernel", "gcmf_last_kernel_timing",
     "gcmf_comm_unique_id", "gcmf_comm_create", "gcmf_comm_destroy", "gcmf_halo_start", "gcmf_halo_finish",
 ]
 PLAN_SELF_RING = 0x1
@@ -112,6 +112,9 @@ def load() -> C.CDLL:
         lib.gcmf_halo_start.restype = C.c_int
         lib.gcmf_halo_finish.argtypes = [vp, vp]
         lib.gcmf_halo_finish.restype = C.c_int
+        lib.gcmf_last_kernel_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float),
+                                                C.POINTER(C.c_float)]
+        lib.gcmf_last_kernel_timing.restype = C.c_int
         lib.gcmf_last_kernel.argtypes = [vp, C.c_char_p, C.c_int]
         lib.gcmf_last_kernel.restype = C.c_int
         lib.gcmf_set_timing.argtypes = [vp, C.c_int]
@@ -263,8 +266,15 @@ class Plan:
                                   C.c_void_p(stream or None)))
 
     # -- instrumentation -----------------------------------------------------------------------
-    def set_timing(self, enabled: bool):
-        check(load().gcmf_set_timing(self._h, 1 if enabled else 0))
+    def set_timing(self, enabled):
+        """False / True: event pair around the whole recurrence; 2: also one pair per temporally blocked launch."""
+        check(load().gcmf_set_timing(self._h, int(enabled)))
+
+    def last_kernel_timing(self):
+        """(sum ms, launches, shortest ms, longest ms) of the blocked launches of the last apply (set_timing(2))."""
+        ms, n, lo, hi = C.c_float(), C.c_int(), C.c_float(), C.c_float()
+        check(load().gcmf_last_kernel_timing(self._h, C.byref(ms), C.byref(n), C.byref(lo), C.byref(hi)))
+        return ms.value, n.value, lo.value, hi.value
 
     def last_timing(self):
         ms, n = C.c_float(), C.c_int()

@@ -109,6 +109,40 @@ static int ensure_dev_p(gcmf_plan *pl, const double *p, int n_steps, hipStream_t
   return GCMF_OK;
 }
 
+// gcmf_set_timing(plan, 2): bracket a blocked launch with its own event pair on the stream it runs on
+static int dom_begin(gcmf_plan *pl, hipStream_t s) {
+  if (!pl->timing_detail) return GCMF_OK;
+  if ((size_t)pl->dom_used + 2 > pl->dom_ev.size())
+    for (int q = 0; q < 2; ++q) {
+      hipEvent_t e;
+      GCMF_HIP(hipEventCreate(&e));
+      pl->dom_ev.push_back(e);
+    }
+  GCMF_HIP(hipEventRecord(pl->dom_ev[pl->dom_used], s));
+  return GCMF_OK;
+}
+static int dom_end(gcmf_plan *pl, hipStream_t s) {
+  if (!pl->timing_detail) return GCMF_OK;
+  GCMF_HIP(hipEventRecord(pl->dom_ev[pl->dom_used + 1], s));
+  pl->dom_used += 2;
+  return GCMF_OK;
+}
+static int dom_collect(gcmf_plan *pl) {
+  pl->dom_ms = pl->dom_min = pl->dom_max = 0.f;
+  pl->dom_n = 0;
+  for (int q = 0; q + 1 < pl->dom_used; q += 2) {
+    float ms = 0.f;
+    GCMF_HIP(hipEventSynchronize(pl->dom_ev[q + 1]));
+    GCMF_HIP(hipEventElapsedTime(&ms, pl->dom_ev[q], pl->dom_ev[q + 1]));
+    pl->dom_ms += ms;
+    pl->dom_min = pl->dom_n ? std::min(pl->dom_min, ms) : ms;
+    pl->dom_max = std::max(pl->dom_max, ms);
+    ++pl->dom_n;
+  }
+  pl->dom_used = 0;
+  return GCMF_OK;
+}
+
 // One temporally blocked advance of S steps on rows [row_lo, row_hi) of a scalar plan.
 //
 // Tripolar grids: the fold couples column i of the top row with column nx-1-i, i.e. with a DIFFERENT wave of the
@@ -121,7 +155,9 @@ int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launche
   const bool band = g.fold && m.row_hi == rows;
   int rc;
   if (!band) {
+    if ((rc = dom_begin(pl, s))) return rc;
     if ((rc = launch_scalar_multi(pl, m, s))) return rc;
+    if ((rc = dom_end(pl, s))) return rc;
     if (launches) ++*launches;
     return GCMF_OK;
   }
@@ -173,7 +209,9 @@ int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launche
     if ((rc = launch_prepare(pl, pin, pout, m.nbatch, rows - 2 * S, rows, n_early >= 1 ? pl->side : s))) return rc;
     if (launches) ++*launches;
   }
+  if ((rc = dom_begin(pl, s))) return rc;
   if ((rc = launch_scalar_multi(pl, mm, s))) return rc;
+  if ((rc = dom_end(pl, s))) return rc;
   if (launches) ++*launches;
   for (int t = 1; t <= S; ++t) {
     hipStream_t ts_ = pl->side;
@@ -237,6 +275,7 @@ void gcmf_plan_destroy(gcmf_plan *pl) {
   (void)hipSetDevice(pl->d.device);
   if (pl->stream) (void)hipStreamSynchronize(pl->stream);
   for (void *p : pl->owned) (void)hipFree(p);
+  for (hipEvent_t e : pl->dom_ev) (void)hipEventDestroy(e);
   if (pl->work) (void)hipFree(pl->work);
   if (pl->band) (void)hipFree(pl->band);
   if (pl->side) { (void)hipStreamSynchronize(pl->side); (void)hipStreamDestroy(pl->side); }
@@ -351,6 +390,7 @@ int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int 
   if (const char *e = getenv("GCMF_HOST_CHUNK_MB")) pl->host_chunk_bytes = (size_t)(atof(e) * 1048576.0);
   if (const char *e = getenv("GCMF_HOST_REGISTER")) pl->host_register = atoi(e);
   if (const char *e = getenv("GCMF_ZERO_LAND")) pl->zero_land = atoi(e);
+  if (const char *e = getenv("GCMF_RING")) pl->ring = atoi(e);
   pl->band_rpw = (pl->d.dtype == GCMF_F32) ? 1 : 0;  // f32: one row per wave shortens the chain (+8 %); f64: no difference
   if (const char *e = getenv("GCMF_BAND_RPW")) pl->band_rpw = atoi(e);
   PLAN_HIP(hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking));
@@ -388,6 +428,16 @@ int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int 
     dplanes[k] = p;
   }
   if (rc == GCMF_OK) rc = precompute(pl, dplanes.data(), desc->planes_on_device ? nullptr : planes);
+  if (rc == GCMF_OK && pl->ncomp == 1) {  // a row of zeros for k_ring
+    void *z = nullptr;
+    const size_t zb = ((size_t)desc->nx + 64) * 8;
+    if (hipMalloc(&z, zb) == hipSuccess && hipMemsetAsync(z, 0, zb, pl->stream) == hipSuccess) {
+      pl->owned.push_back(z);
+      pl->zero_row = z;
+    } else if (z) {
+      (void)hipFree(z);
+    }
+  }
   (void)hipStreamSynchronize(pl->stream);
   for (void *p : staged) (void)hipFree(p);
   if (rc != GCMF_OK) return fail(rc);
@@ -406,7 +456,18 @@ int gcmf_plan_rows(const gcmf_plan *pl, int64_t *rows_alloc, int64_t *first_owne
 
 int gcmf_set_timing(gcmf_plan *pl, int enabled) {
   if (!pl) return GCMF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(pl->mu);
   pl->timing = enabled != 0;
+  pl->timing_detail = enabled == 2;
+  pl->dom_used = 0;
+  return GCMF_OK;
+}
+int gcmf_last_kernel_timing(const gcmf_plan *pl, float *ms_sum, int *n_launches, float *ms_min, float *ms_max) {
+  if (!pl) return GCMF_ERR_INVALID_ARG;
+  if (ms_sum) *ms_sum = pl->dom_ms;
+  if (n_launches) *n_launches = pl->dom_n;
+  if (ms_min) *ms_min = pl->dom_min;
+  if (ms_max) *ms_max = pl->dom_max;
   return GCMF_OK;
 }
 int gcmf_last_timing(const gcmf_plan *pl, float *ms_total, int *n_launches) {
@@ -614,6 +675,9 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
   const size_t oC = per; if (use_multi || use_vmulti) per += szT;
   const size_t oD = per; if (use_multi || use_vmulti) per += szT;
   const size_t oF = per; per += szF;
+  // second fbar plane (scalar blocked schedule): k_flux_ring re-does a strip from its inputs when it meets a NaN / inf,
+  // so a launch must not accumulate fbar in place
+  const size_t oF2 = per; if (use_multi) per += szF;
   // flux kinds only: the land-mask kernels have a NaN-only mode that already makes NaN on land free, there the two
   // extra passes would only cost (measured -6 %)
   const bool zero_land = use_multi && land_ok(pl, n_steps);  // n_steps < 4096: k_land_fix keeps p in LDS
@@ -665,6 +729,7 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
       // once.  prepare/finalize are fused into the first / last launch.  State buffers rotate through a pool
       // of four because a launch may not overwrite the planes its neighbours' halos are still reading.
       void *pool[4] = {A[0], B[0], Cb[0], Db[0]};
+      void *Fcur = F[0], *Fnext = w + oF2;   // fbar ping-pongs between two planes (see oF2)
       const void *u = x0[0], *v = nullptr;
       int k = 1;
       bool land_zeroed = false;  // the first blocked launch kept the isolated cells out of the state
@@ -685,7 +750,8 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
         if (S >= 2) {
           MultiArgs m{};
           m.u0 = u; m.v0 = v; m.uo = fr[0]; m.vo = fr[1];
-          m.fb_in = F[0]; m.fb_out = is_last ? dout[0] : F[0];
+          m.fb_in = Fcur; m.fb_out = is_last ? dout[0] : Fnext;
+          std::swap(Fcur, Fnext);
           m.first = (k == 1); m.last = is_last; m.S = S; m.fb_is_f32 = fb32;
           m.land_zero = land_zeroed ? 1 : 0;
 
@@ -709,7 +775,7 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
             ++launches;
             src = Pp[0];
           }
-          a1.t1[0] = src; a1.t2[0] = v; a1.t0[0] = fr[0]; a1.fb_in[0] = F[0]; a1.fb_out[0] = is_last ? dout[0] : F[0];
+          a1.t1[0] = src; a1.t2[0] = v; a1.t0[0] = fr[0]; a1.fb_in[0] = Fcur; a1.fb_out[0] = is_last ? dout[0] : Fcur;
           if ((rc = step_dispatch(pl, a1, s))) return rc;
           v = src; u = fr[0];
         }
@@ -751,7 +817,9 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
           for (int t = 0; t < S; ++t) m.pk[t] = p[k + t];
           m.p0 = p[0]; m.c = c; m.S = S;
           m.first = (k == 1); m.last = is_last; m.fb_is_f32 = fb32; m.nbatch = nbatch; m.row_lo = 0; m.row_hi = rows;
+          if ((rc = dom_begin(pl, s))) return rc;
           if ((rc = launch_vec_multi(pl, m, s))) return rc;
+          if ((rc = dom_end(pl, s))) return rc;
           for (int q = 0; q < 2; ++q) { u[q] = fr[1][q]; v[q] = fr[0][q]; }
           k += S;
         } else {
@@ -811,6 +879,7 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
     GCMF_HIP(hipEventSynchronize(pl->ev1));
     GCMF_HIP(hipEventElapsedTime(&pl->last_ms, pl->ev0, pl->ev1));
   }
+  if (pl->timing_detail && timed && (rc = dom_collect(pl))) return rc;
   return GCMF_OK;
 }
 

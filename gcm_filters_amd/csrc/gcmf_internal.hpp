@@ -129,6 +129,12 @@ struct gcmf_plan {
   hipEvent_t ev_busy = nullptr;  // end of the last gcmf_apply that used the plan's work buffers
   bool busy_valid = false;
   bool timing = false;
+  // gcmf_set_timing(plan, 2): an event pair around every temporally blocked launch of gcmf_apply (the dominant kernel)
+  bool timing_detail = false;
+  std::vector<hipEvent_t> dom_ev;  // pairs
+  int dom_used = 0;
+  float dom_ms = 0.f, dom_min = 0.f, dom_max = 0.f;
+  int dom_n = 0;
   // the recurrence kernel with the most steps per launch since gcmf_last_kernel was last read (instrumentation:
   // bench.py ties its HBM-traffic figures to the kernel that actually ran)
   std::string last_kernel;
@@ -149,6 +155,8 @@ struct gcmf_plan {
   const uint8_t *lbits = nullptr;
   int64_t n_land = 0;
   int zero_land = 1;      // env GCMF_ZERO_LAND=0 turns it off
+  int ring = 1;           // env GCMF_RING=0: deep launches stay with k_flux_multi2 / k_scalar_multi
+  const void *zero_row = nullptr;  // nx zeros: what rows beyond a closed boundary read as coefficients / mask bits (k_ring)
   int band_rpw = 0;       // rows per wave of the tripole band steps (0 = default)
   double *dev_p = nullptr;   // p[0..n_steps] of the last filter, for k_land_fix
   size_t dev_p_n = 0;
@@ -171,6 +179,7 @@ int launch_scalar_step(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 int launch_vector_step(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 int launch_scalar_multi(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 bool flux_multi2_supported(const gcmf_plan *pl, int S);
+bool ring_supported(const gcmf_plan *pl, const MultiArgs &a);
 int launch_flux_multi2(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_cgrid_stream(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 bool cgrid_stream_supported(const gcmf_plan *pl, const StepArgs &a);

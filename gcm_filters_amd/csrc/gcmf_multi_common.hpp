@@ -73,6 +73,19 @@ template <> __device__ __forceinline__ float unsan<float>(float g, unsigned f) {
   return (f & 1u) ? __builtin_nanf("") : r;
 }
 
+// The same hops with zero fill: the outermost lane receives 0 instead of keeping its own value.  `old` is dead then, so the
+// move needs no preceding copy of the source (one VALU instruction less per dword); margin lanes only.
+__device__ __forceinline__ int dpp_up0_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ int dpp_down0_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }
+__device__ __forceinline__ double from_lower_lane0(double v) {
+  return __hiloint2double(dpp_up0_i(__double2hiint(v)), dpp_up0_i(__double2loint(v)));
+}
+__device__ __forceinline__ double from_upper_lane0(double v) {
+  return __hiloint2double(dpp_down0_i(__double2hiint(v)), dpp_down0_i(__double2loint(v)));
+}
+__device__ __forceinline__ float from_lower_lane0(float v) { return __int_as_float(dpp_up0_i(__float_as_int(v))); }
+__device__ __forceinline__ float from_upper_lane0(float v) { return __int_as_float(dpp_down0_i(__float_as_int(v))); }
+
 __device__ __forceinline__ double mabs(double x) { return __builtin_fabs(x); }
 __device__ __forceinline__ float mabs(float x) { return __builtin_fabsf(x); }
 
@@ -86,6 +99,7 @@ template <typename T, typename FB> struct MultiP {
   const FB *fb_in;  // running sum in     (unused when first)
   FB *fb_out;       // running sum out / finalised result when last
   const T *cE, *cN, *ra;
+  const T *zrow;    // nx zeros (k_flux_ring: coefficient rows beyond a closed boundary)
   const uint8_t *mbits;
   const T *area;
   int nx, rows, out_lo, out_hi;

@@ -1,0 +1,357 @@
+// Deep temporal blocking (S = 5..8 recurrence steps per pass over HBM) with STATIC register rings: k_ring<T, FB, KIND, S>.
+//
+// Same algorithm, wave mapping, operands and arithmetic as k_scalar_multi<T, FB, KIND, S> / k_flux_multi2 (reference
+// gcm_filters/kernels.py:113-121 (K_REG), 163-187 (K_MASKZ = the land-mask stencil on states whose land cells are zero),
+// 259-315, 345-372, 402-429, 517-585 (K_FLUX) inside the recurrence of filter.py:162-212) -- results are bit-identical --
+// rebuilt around what the SQ counters of those kernels showed (profiles/r02/cfg3_flux_multi2_sq_counters.txt,
+// cfg2_maskz_sq_counters.txt: VALU-issue bound, only 28-38 % of the VALU instructions are arithmetic):
+//
+//   * NO WINDOW SHIFTING.  The per-level row windows (3 rows), the input rows (6), the T_{k-2} rows (4) and the lag lines of
+//     the coefficient / mask rows and of fbar (12) are rings whose slot is (row index) mod the ring size; the row loop is
+//     unrolled over the common period 12, so every slot index is a compile-time constant and nothing is ever moved.
+//     Operands are loaded straight into the ring slot they are consumed from, THREE rows ahead (18 KB in flight per
+//     wave): with the shifting gone the first version of this kernel (one row ahead) spent 46 % of its time in s_waitcnt
+//     (profiles/r02/cfg3_flux_ring_v1_sq_counters.txt).
+//   * K_FLUX: the south-face flux of a row IS the north-face flux of the row below (same operands, same rounding): it is
+//     carried in a register per level instead of being recomputed (2 of 13 f64 operations per cell and level, and the
+//     second lag of the north-face coefficients).
+//   * NO NaN / inf BOOKKEEPING on this path.  nan_to_num is the identity on finite data, so the fast march only
+//     watches for a non-finite value (one compare per produced value, OR-ed into a wave mask, tested once per unrolled
+//     body); a wave that sees one abandons its strip and redoes it with the general march of k_flux_multi2 /
+//     k_scalar_multi, whose results then overwrite whatever the fast march stored (so fbar must not be accumulated in
+//     place).  gcmf_apply keeps land out of the state after its first launch (k_zero_land), so ocean fields with NaN
+//     on land stay on the fast path.  K_REG has no nan_to_num in the reference (NaN spreads): no check, no fallback.
+//   * the wave index goes through readfirstlane: row indices, pointers and loop bounds are scalar; neighbours by DPP
+//     with zero fill (no copy of the source); rows beyond a closed boundary read their coefficients from a row of zeros.
+//
+// Not the first launch of a filter (no T_{k-2} / fbar yet, prepare() to fuse, NaN on land still in the field): that one
+// stays with the general kernels.  One wave per SIMD (up to 446 registers at S = 8 in f64).
+#pragma once
+#include "gcmf_flux_multi2_body.hpp"
+#include "gcmf_scalar_multi_impl.hpp"
+
+namespace gcmf {
+
+template <int N> using ic = std::integral_constant<int, N>;
+constexpr int pmod(int a, int m) { return ((a % m) + m) % m; }
+
+struct RingGeom {
+  static constexpr int D = 3;   // rows of operands in flight
+  static constexpr int R = 12;  // lag-ring slots (>= S + D) == unroll factor of the row loop == common period of all rings
+  static constexpr int RU = 6;  // ring of the input rows T_{k-1}: 3 live (levels 1, 2) + D in flight
+  static constexpr int RV = 4;  // ring of the T_{k-2} rows: 1 live (level 1) + D in flight
+};
+
+template <typename T, typename FB, int KIND, int S>
+__global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int W = 64 * VEC;
+  constexpr int M = (S + VEC - 1) / VEC * VEC;
+  constexpr int WI = W - 2 * M;
+  constexpr int R = RingGeom::R, D = RingGeom::D, RU = RingGeom::RU, RV = RingGeom::RV;
+  static_assert(R >= S + D && R % 3 == 0 && R % RU == 0 && R % RV == 0 && RU >= 3 + D && RV >= 1 + D, "ring periods");
+  static_assert(KIND == K_REG || KIND == K_MASKZ || KIND == K_FLUX, "stencil kind");
+  constexpr bool FLUX = (KIND == K_FLUX), MASK = (KIND == K_MASKZ);
+  constexpr bool SAN = (KIND != K_REG);  // the reference sanitises with nan_to_num (kernels.py:165, 298): watch for non-finite values
+  constexpr bool FUSED = FLUX;           // gcmf_recurrence.hpp
+
+  const int lane = threadIdx.x & 63;
+  // the wave index is uniform, but the compiler cannot prove it of threadIdx.x >> 6: without the readfirstlane every row
+  // index, pointer and loop bound derived from it lives in vector registers and is recomputed with vector instructions
+  const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wid >= P.nwaves) return;
+  const int wx = wid % P.nwx, st = wid / P.nwx;
+  const int nx = P.nx, rows = P.rows;
+  const int a = P.out_lo + st * P.H;
+  const int b = min(a + P.H, P.out_hi);
+  const long long boff = (long long)blockIdx.y * P.bstride;
+  const int pos = wx * WI - M + lane * VEC;
+  int col = pos % nx;
+  if (col < 0) col += nx;
+  const bool keep = (lane * VEC >= M) && (lane * VEC < W - M) && (pos < nx);
+  const T c = (T)P.c;
+  const bool last = P.last;
+
+  // ---- register-resident state: rings indexed by compile-time slots ----
+  T G0[RU][VEC];     // rows of the input T_{k-1}, slot = (row - r_begin) mod RU
+  T G[S][3][VEC];    // G[t], t = 1..S-1: rows of T_{k-1+t}, slot = (row - r_begin) mod 3   (G[0] unused)
+  T FN[S + 1][VEC];  // K_FLUX: FN[t] = north-face flux of the row level t worked on in the previous iteration
+  T cE[R][VEC], cN[R][VEC], ra[R][VEC];  // K_FLUX: coefficient rows, slot = (row + 1 - r_begin) mod R
+  unsigned B[R];     // K_MASKZ: mask bytes of the lane's cells (bit 0 wet, bits 5-7 wet-neighbour count), same slots
+  FB F[R][VEC];      // fbar rows, same slots
+  T V[RV][VEC];      // T_{k-2} rows, slot = (row + 1 - r_begin) mod RV
+#pragma unroll
+  for (int t = 0; t < S; ++t) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) G[t][0][k] = G[t][1][k] = G[t][2][k] = FN[t + 1][k] = T(0);
+  }
+#pragma unroll
+  for (int l = 0; l < RU; ++l) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) G0[l][k] = T(0);
+  }
+
+  // periodic wrap (|r| never leaves (-rows, 2 rows)) or clamp at a closed boundary; written as selects: a branch per row
+  // index costs this single-wave kernel more than the scalar arithmetic it would skip
+  const bool wrap = P.wrap;
+  auto row_index = [&](int r, bool &outside) {
+    const bool lo = r < 0, hi = r >= rows;
+    const int jw = r + (lo ? rows : 0) - (hi ? rows : 0);
+    const int jc = lo ? 0 : (hi ? rows - 1 : r);
+    outside = !wrap && (lo || hi);
+    return wrap ? jw : jc;
+  };
+  const int r_begin = a - S, r_last = b + S - 1;  // rows of T_{k-1} this strip needs: [a-S, b+S)
+  // addresses = a wave-uniform row pointer (scalar arithmetic) + this lane's column
+  auto load_u = [&](auto slot_c, int r) {  // row r of T_{k-1}
+    constexpr int sl = decltype(slot_c)::value;
+    bool out_u;
+    const T *rowp = P.u0 + boff + (long long)row_index(min(r, r_last), out_u) * nx;
+    mload<T, VEC>(G0[sl], rowp + col);
+  };
+  // the centre-only operands that travel with row r of T_{k-1}: T_{k-2}, fbar, coefficients / mask bits of row r-1
+  auto load_centre = [&](auto slot_c, auto vslot_c, int r) {
+    constexpr int sl = decltype(slot_c)::value;
+    constexpr int vs = decltype(vslot_c)::value;
+    bool out_c;
+    const long long rc = (long long)row_index(min(r, r_last) - 1, out_c) * nx;
+    if constexpr (FLUX) {  // beyond a closed boundary: no flux -- the coefficients come from a row of zeros
+      const T *pE = out_c ? P.zrow : P.cE + rc;
+      const T *pN = out_c ? P.zrow : P.cN + rc;
+      const T *pA = out_c ? P.zrow : P.ra + rc;
+      mload<T, VEC>(cE[sl], pE + col);
+      mload<T, VEC>(cN[sl], pN + col);
+      mload<T, VEC>(ra[sl], pA + col);
+    }
+    if constexpr (MASK) {  // beyond a closed boundary: land (bits 0)
+      const uint8_t *mp = (out_c ? (const uint8_t *)P.zrow : P.mbits + rc) + col;
+      if (VEC == 2) B[sl] = *reinterpret_cast<const unsigned short *>(mp);
+      else B[sl] = *reinterpret_cast<const unsigned *>(mp);
+    }
+    const FB *pF = P.fb_in + boff + rc;
+    const T *pV = P.v0 + boff + rc;
+    mload<FB, VEC>(F[sl], pF + col);
+    mload<T, VEC>(V[vs], pV + col);
+  };
+
+  bool bad = false;         // this lane met a non-finite value (input row or a produced level)
+  T out_v[VEC], out_u[VEC]; // outputs of levels S-1 and S of the current iteration
+
+  // level t of the iteration with phase ph: row r - t of T_{k-1+t} from rows r-t-1 .. r-t+1 of level t-1
+  auto level = [&](auto tt, auto ph_c) {
+    constexpr int t = decltype(tt)::value;
+    constexpr int ph = decltype(ph_c)::value;
+    constexpr int sS = pmod(ph - t - 1, 3), sC = pmod(ph - t, 3), sN = pmod(ph - t + 1, 3);
+    constexpr int sl = pmod(ph - t + 1, R);
+    const T(&gS)[VEC] = (t == 1) ? G0[pmod(ph - 2, RU)] : G[t >= 2 ? t - 1 : 1][sS];
+    const T(&gC)[VEC] = (t == 1) ? G0[pmod(ph - 1, RU)] : G[t >= 2 ? t - 1 : 1][sC];
+    const T(&gN)[VEC] = (t == 1) ? G0[pmod(ph, RU)] : G[t >= 2 ? t - 1 : 1][sN];
+    const T ev = from_upper_lane0(gC[0]);
+    T fev[VEC], few = T(0), wv = T(0);
+    if constexpr (FLUX) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const T xE = (k == VEC - 1) ? ev : gC[k < VEC - 1 ? k + 1 : k];
+        fev[k] = (xE - gC[k]) * cE[sl][k];
+      }
+      few = from_lower_lane0(fev[VEC - 1]);
+    } else {
+      wv = from_lower_lane0(gC[VEC - 1]);
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const T xC = gC[k];
+      T L;
+      if constexpr (FLUX) {
+        const T fe = fev[k];
+        const T fw = (k == 0) ? few : fev[k > 0 ? k - 1 : 0];
+        const T fn = (gN[k] - xC) * cN[sl][k];
+        L = (fe - fw + fn - FN[t][k]) * ra[sl][k];
+        FN[t][k] = fn;
+      } else {
+        const T xW = (k == 0) ? wv : gC[k > 0 ? k - 1 : 0];
+        const T xE = (k == VEC - 1) ? ev : gC[k < VEC - 1 ? k + 1 : k];
+        if constexpr (MASK) {
+          const unsigned bb = (B[sl] >> (8 * k)) & 0xFFu;
+          const T wf = (T)(bb >> 5);  // wet-neighbour count, precomputed in bits 5-7
+          L = -wf * xC + xE;
+          L = L + xW;
+          L = L + gN[k];
+          L = L + gS[k];
+          L = (bb & 1u) ? L : T(0);
+        } else {
+          L = T(-4) * xC + xE;
+          L = L + xW;
+          L = L + gN[k];
+          L = L + gS[k];
+        }
+      }
+      const T av = cheb_a<FUSED>(xC, c, L);
+      const T x2 = (t == 1) ? V[ph % RV][k] : (t == 2 ? G0[pmod(ph - 2, RU)][k] : G[t >= 3 ? t - 2 : 1][sC][k]);
+      const T tk = cheb_t<FUSED>(av, x2);
+      F[sl][k] = cheb_acc<FUSED, T, FB>(F[sl][k], P.pk[t - 1], tk);
+      if (t < S) {
+        G[t < S ? t : 0][sC][k] = tk;
+        if (SAN) bad = bad || !(mabs(tk) <= MLim<T>::big());
+      }
+      if (t == S - 1) out_v[k] = tk;
+      if (t == S) out_u[k] = tk;
+    }
+  };
+
+  // one row iteration: row r of T_{k-1} has been delivered into G0[ph % RU], its centre operands into ring slots ph
+  auto phase = [&](auto ph_c, int r) {
+    constexpr int ph = decltype(ph_c)::value;
+    // the operands of iteration + D; every slot they land in was released in the previous iteration at the latest
+    load_centre(ic<(ph + D) % R>{}, ic<(ph + D) % RV>{}, r + D);
+    load_u(ic<(ph + D) % RU>{}, r + D);
+    if (SAN) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) bad = bad || !(mabs(G0[ph % RU][k]) <= MLim<T>::big());
+    }
+    level(ic<1>{}, ph_c);
+    if constexpr (S >= 2) level(ic<2>{}, ph_c);
+    if constexpr (S >= 3) level(ic<3>{}, ph_c);
+    if constexpr (S >= 4) level(ic<4>{}, ph_c);
+    if constexpr (S >= 5) level(ic<5>{}, ph_c);
+    if constexpr (S >= 6) level(ic<6>{}, ph_c);
+    if constexpr (S >= 7) level(ic<7>{}, ph_c);
+    if constexpr (S >= 8) level(ic<8>{}, ph_c);
+    // stores: T_{k-1+S} row r-S, fbar row r-S (its ring slot is complete), T_{k-2+S} row r-S+1
+    const int ju = r - S;
+    if (ju >= a && ju < b) {  // wave-uniform
+      const long long off = boff + (long long)ju * nx;
+      if (keep) {
+        constexpr int fs = pmod(ph - S + 1, R);
+        if (!last) {
+          mstore<T, VEC>(P.uo + off + col, out_u);
+        } else if (!FLUX && P.area_weighted) {  // finalize(): / area (kernels.py:103-104)
+          T ar[VEC];
+          mload<T, VEC>(ar, P.area + (long long)ju * nx + col);
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) F[fs][k] = F[fs][k] / (FB)ar[k];
+        }
+        mstore<FB, VEC>(P.fb_out + off + col, F[fs]);
+      }
+    }
+    const int jv = r - S + 1;
+    if (!last && jv >= a && jv < b) {
+      T *rowp = P.vo + boff + (long long)jv * nx;
+      if (keep) mstore<T, VEC>(rowp + col, out_v);
+    }
+  };
+
+  // ---- march north; the body covers one full period of every ring ----
+  load_centre(ic<0>{}, ic<0>{}, r_begin);
+  load_u(ic<0>{}, r_begin);
+  load_centre(ic<1>{}, ic<1>{}, r_begin + 1);
+  load_u(ic<1>{}, r_begin + 1);
+  load_centre(ic<2>{}, ic<2>{}, r_begin + 2);
+  load_u(ic<2>{}, r_begin + 2);
+  static_assert(D == 3, "prologue");
+  const int niter = (r_last - r_begin + 1 + R - 1) / R * R;  // padded to whole periods: the extra rows store nothing
+  bool dirty = false;
+  for (int i0 = 0; i0 < niter; i0 += R) {
+    const int r0 = r_begin + i0;
+    phase(ic<0>{}, r0);
+    phase(ic<1>{}, r0 + 1);
+    phase(ic<2>{}, r0 + 2);
+    phase(ic<3>{}, r0 + 3);
+    phase(ic<4>{}, r0 + 4);
+    phase(ic<5>{}, r0 + 5);
+    phase(ic<6>{}, r0 + 6);
+    phase(ic<7>{}, r0 + 7);
+    phase(ic<8>{}, r0 + 8);
+    phase(ic<9>{}, r0 + 9);
+    phase(ic<10>{}, r0 + 10);
+    phase(ic<11>{}, r0 + 11);
+    if (SAN && __any(bad)) {  // wave-uniform: a NaN / inf somewhere in this strip -> the general march redoes the strip
+      dirty = true;
+      break;
+    }
+  }
+  if constexpr (SAN) {
+    if (dirty) {
+      if constexpr (FLUX) flux_multi2_march<T, FB, S>(P);
+      else scalar_multi_march<T, FB, KIND, S, 1>(P);
+    }
+  }
+}
+
+template <typename T, typename FB, int KIND, int S> static int launch_ring_s(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int W = 64 * VEC;
+  constexpr int M = (S + VEC - 1) / VEC * VEC;
+  constexpr int WI = W - 2 * M;
+  constexpr int R = RingGeom::R;
+  const Geom &g = pl->g;
+  MultiP<T, FB> P;
+  P.u0 = (const T *)a.u0;
+  P.v0 = (const T *)a.v0;
+  P.uo = (T *)a.uo;
+  P.vo = (T *)a.vo;
+  P.fb_in = (const FB *)a.fb_in;
+  P.fb_out = (FB *)a.fb_out;
+  P.cE = (const T *)g.coef[0];
+  P.cN = (const T *)g.coef[1];
+  P.ra = (const T *)g.coef[2];
+  P.zrow = (const T *)pl->zero_row;
+  P.mbits = g.mbits;
+  P.area = (const T *)g.area;
+  P.nx = g.nx;
+  P.rows = g.rows;
+  P.out_lo = a.row_lo;
+  P.out_hi = a.row_hi;
+  const int nrows = a.row_hi - a.row_lo;
+  if (nrows <= 0 || a.nbatch <= 0) return GCMF_OK;
+  P.nwx = (g.nx + WI - 1) / WI;
+  int H = pl->strip_rows;
+  if (H <= 0) {  // one resident round of waves at one wave per SIMD (all strips march in lock-step)
+    // tripolar plans: the single steps of the fold band run beside this launch on a side stream (advance_multi).  Their
+    // waves (94 registers) do not fit next to a 446-register wave on a SIMD, so 16 of the 256 CUs are left to them
+    const long long slots = g.fold ? 960 : 1024;
+    long long want = slots / ((long long)P.nwx * a.nbatch);
+    if (want < 1) want = 1;
+    H = (int)((nrows + want - 1) / want);
+    if (H < 2 * S) H = 2 * S;
+    // the march is padded to whole ring periods: make the padding carry real rows (never more strips than before)
+    H += (R - (H + 2 * S) % R) % R;
+  }
+  if (H > nrows) H = nrows;
+  P.H = H;
+  P.nstrips = (nrows + H - 1) / H;
+  P.nwaves = P.nwx * P.nstrips;
+  P.wrap = g.south_wrap && g.north_wrap;
+  P.first = 0;
+  P.last = a.last;
+  P.area_weighted = (KIND == K_FLUX) ? 0 : g.area_weighted;
+  P.bstride = (long long)g.rows * g.nx;
+  for (int t = 0; t < MAX_S; ++t) P.pk[t] = t < S ? a.pk[t] : 0.0;
+  P.p0 = a.p0;
+  P.c = a.c;
+  dim3 block(256), grid((P.nwaves + 3) / 4, (unsigned)a.nbatch);
+  hipLaunchKernelGGL((k_ring<T, FB, KIND, S>), grid, block, 0, s, P);
+  GCMF_HIP(hipGetLastError());
+  note_kernel(pl, std::string("gcmf::k_ring<") + tyname<T>() + ", " + tyname<FB>() + ", " + std::to_string(KIND) + ", " +
+                      std::to_string(S) + ">", S);
+  return GCMF_OK;
+}
+
+template <typename T, typename FB, int KIND> static int launch_ring_k(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
+  switch (a.S) {
+    case 5: return launch_ring_s<T, FB, KIND, 5>(pl, a, s);
+    case 6: return launch_ring_s<T, FB, KIND, 6>(pl, a, s);
+    case 7: return launch_ring_s<T, FB, KIND, 7>(pl, a, s);
+    case 8: return launch_ring_s<T, FB, KIND, 8>(pl, a, s);
+  }
+  return GCMF_ERR_INVALID_ARG;
+}
+
+// one translation unit per stencil kind (compile time): the dtype dispatch
+template <int KIND> static int launch_ring_kind(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
+  if (pl->d.dtype == GCMF_F64) return launch_ring_k<double, double, KIND>(pl, a, s);
+  if (a.fb_is_f32) return launch_ring_k<float, float, KIND>(pl, a, s);
+  return launch_ring_k<float, double, KIND>(pl, a, s);
+}
+
+}  // namespace gcmf

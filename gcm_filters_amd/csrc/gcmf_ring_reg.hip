@@ -1,0 +1,6 @@
+// k_ring instantiations for K_REG (see gcmf_ring_impl.hpp); one translation unit per stencil kind so that they compile in parallel
+#include "gcmf_ring_impl.hpp"
+
+namespace gcmf {
+int launch_ring_reg(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) { return launch_ring_kind<K_REG>(pl, a, s); }
+}  // namespace gcmf

@@ -11,6 +11,9 @@ int launch_multi_reg(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_multi_mask(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_multi_maskz(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_multi_flux(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
+int launch_ring_reg(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
+int launch_ring_maskz(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
+int launch_ring_flux(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 
 bool multi_supported(const gcmf_plan *pl, int S) {
   if (pl->ncomp != 1) return false;
@@ -23,9 +26,26 @@ bool multi_supported(const gcmf_plan *pl, int S) {
   return true;
 }
 
+// S in 5..8, not the first launch of a filter (prepare() / p0 T0 + p1 T1 to fuse), land-mask kinds only once land is kept out of
+// the state, a row of zeros at hand for closed boundaries, and fbar NOT accumulated in place: a strip that meets a NaN /
+// inf is redone from its inputs, which its own stores must not have touched
+bool ring_supported(const gcmf_plan *pl, const MultiArgs &a) {
+  if (!pl->ring || !pl->zero_row || a.first || a.S < 5 || a.S > 8 || a.fb_in == a.fb_out) return false;
+  if (pl->kind == K_MASK) return a.land_zero != 0;
+  return pl->kind == K_REG || pl->kind == K_FLUX;
+}
+
 int launch_scalar_multi(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   // deep flux launches: the two-rows-per-iteration kernel (gcmf_flux_multi2.hip); GCMF_FLUX2=0 keeps the one-row form
   static const bool flux2 = !(getenv("GCMF_FLUX2") && atoi(getenv("GCMF_FLUX2")) == 0);
+  // deep launches after the first: the static-ring kernels (gcmf_ring_impl.hpp); GCMF_RING=0 keeps the general ones
+  if (ring_supported(pl, a)) {
+    switch (pl->kind) {
+      case K_REG: return launch_ring_reg(pl, a, s);
+      case K_MASK: return launch_ring_maskz(pl, a, s);
+      case K_FLUX: return launch_ring_flux(pl, a, s);
+    }
+  }
   if (flux2 && flux_multi2_supported(pl, a.S)) return launch_flux_multi2(pl, a, s);
   switch (pl->kind) {
     case K_REG: return launch_multi_reg(pl, a, s);

@@ -46,8 +46,10 @@ template <typename T, int KIND, int S> struct WavesPerSimd {
                                : ((IsMask<KIND>::value && S > 5 && sizeof(T) == 4) ? 1 : 2);
 };
 
+// the march itself as a device function: k_scalar_multi is just this; the static-ring kernels (gcmf_ring_impl.hpp) fall
+// back to it for a strip in which a non-finite value turned up
 template <typename T, typename FB, int KIND, int S, int D>
-__global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scalar_multi(const MultiP<T, FB> P) {
+__device__ __forceinline__ void scalar_multi_march(const MultiP<T, FB> &P) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int W = 64 * VEC;
   constexpr int M = (S + VEC - 1) / VEC * VEC;  // x margin, multiple of VEC so that windows stay 16-byte aligned
@@ -433,6 +435,11 @@ __global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scal
 #undef GCMF_SLOT
 }
 
+template <typename T, typename FB, int KIND, int S, int D>
+__global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scalar_multi(const MultiP<T, FB> P) {
+  scalar_multi_march<T, FB, KIND, S, D>(P);
+}
+
 // ------------------------------------------------------------------------------------------------------
 template <typename T, typename FB, int KIND, int S, int D>
 static int launch_multi_s(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
@@ -451,6 +458,7 @@ static int launch_multi_s(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   P.cE = (const T *)g.coef[0];
   P.cN = (const T *)g.coef[1];
   P.ra = (const T *)g.coef[2];
+  P.zrow = nullptr;
   P.mbits = g.mbits;
   P.area = (const T *)g.area;
   P.nx = g.nx;

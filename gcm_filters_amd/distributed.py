@@ -224,7 +224,7 @@ class SlabFilter:
             shape = (self.ncomp, nbatch, self.rows_alloc, self.nx)
             mk = lambda dt: t.zeros(shape, dtype=dt, device=self.device)
             self._bufs[key] = dict(X=mk(self.tdtype), A=mk(self.tdtype), B=mk(self.tdtype), C=mk(self.tdtype),
-                                   D=mk(self.tdtype), F=mk(t.float64), O=mk(t.float64))
+                                   D=mk(self.tdtype), F=mk(t.float64), F2=mk(t.float64), O=mk(t.float64))
         return self._bufs[key]
 
     # -- halo exchange -------------------------------------------------------------------------
@@ -335,6 +335,8 @@ class SlabFilter:
         nbatch = int(local[0].shape[0])
         st = self._state(nbatch)
         X, F, O = st["X"], st["F"], st["O"]
+        Fn = st["F2"]  # fbar ping-pongs between two planes: the static-ring kernels redo a strip from its inputs when they
+        #                meet a NaN / inf, so a blocked launch must not accumulate fbar in place (gcmf_ring_impl.hpp)
         pool = [st["A"], st["B"], st["C"], st["D"]]
         fo, ro, s = self.first_owned, self.rows_owned, self.halo
         for k in range(self.ncomp):
@@ -380,7 +382,7 @@ class SlabFilter:
                 e0.record()
             if S >= 2:
                 args = (comps(u), None if v is None else comps(v), comps(free[0]), comps(free[1]), comps(F),
-                        comps(O) if is_last else comps(F), p[k: k + S], p[0], self.c, mode, nbatch)
+                        comps(O) if is_last else comps(Fn), p[k: k + S], p[0], self.c, mode, nbatch)
                 overlap = (self.overlap and self.multi and v_out == 0 and not is_last and ro >= 4 * s
                            and self.engine.multi_supported(S, nbatch))
                 if overlap:
@@ -397,6 +399,7 @@ class SlabFilter:
                 else:
                     self.engine.multi(*args, lo, hi)
                 u, v = free[0], free[1]
+                F, Fn = Fn, F
                 if k == 1 and not is_last and keep_land_out:
                     # flux kinds: land (cells with four closed faces) leaves the state here; its own polynomial is
                     # written into the result by land_fix below (what gcmf_apply does internally)
