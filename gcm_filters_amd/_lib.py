@@ -32,7 +32,7 @@ EXPORTS = [
     "gcmf_has_land", "gcmf_zero_land", "gcmf_land_fix", "gcmf_last_kernel", "gcmf_last_kernel_timing",
     "gcmf_comm_unique_id", "gcmf_comm_create", "gcmf_comm_destroy", "gcmf_halo_start", "gcmf_halo_finish",
 ]
-PLAN_SELF_RING = 0x1
+PLAN_SELF_RING, PLAN_SKIP_KAPPA_ONE = 0x1, 0x2
 
 
 class PlanDesc(C.Structure):
@@ -163,14 +163,15 @@ class Plan:
 
     def __init__(self, grid_type: int, dtype: int, ny: int, nx: int, planes: Sequence, *, device: int = 0,
                  row_begin: int = 0, row_end: Optional[int] = None, halo: int = 0, planes_on_device: bool = False,
-                 self_ring: bool = False):
+                 self_ring: bool = False, skip_kappa_one: bool = False):
         lib = load()
         self._h = None
         self.grid_type, self.dtype, self.ny, self.nx, self.device = int(grid_type), int(dtype), int(ny), int(nx), int(device)
         self.ncomp = lib.gcmf_grid_ncomp(self.grid_type)
         desc = PlanDesc(self.grid_type, self.dtype, self.ny, self.nx, int(row_begin),
                         int(self.ny if row_end is None else row_end), int(halo), self.device,
-                        1 if planes_on_device else 0, PLAN_SELF_RING if self_ring else 0)
+                        1 if planes_on_device else 0,
+                        (PLAN_SELF_RING if self_ring else 0) | (PLAN_SKIP_KAPPA_ONE if skip_kappa_one else 0))
         if planes_on_device:
             ptrs = [int(p) for p in planes]
             keep = None

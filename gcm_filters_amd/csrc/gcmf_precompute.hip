@@ -426,7 +426,7 @@ template <typename T> static int precompute_t(gcmf_plan *pl, const void *const *
       set_error("There are kappa_s values > 1 and this can cause the filter to blow up.Please make sure all kappa_s are <=1.");
       return GCMF_ERR_KAPPA_S_GT1;
     }
-    if (!(flags & F_K_NEAR1)) {
+    if (!(flags & F_K_NEAR1) && !(pl->d.flags & GCMF_PLAN_SKIP_KAPPA_ONE)) {
       set_error("At least one place in the domain must have either kappa_w = 1 or kappa_s = 1. Otherwise the filter's "
                 "scale will not be equal to filter_scale anywhere in the domain.");
       return GCMF_ERR_KAPPA_NONE_ONE;

@@ -223,7 +223,7 @@ class Filter:
     grid_type : GridType
     grid_vars : dict
         Grid variables required by ``grid_type`` (see ``required_grid_vars``); xarray DataArrays, numpy
-        arrays or torch tensors (host or MI355X-resident)
+        arrays or torch tensors (host or MI355X-resident); planes (y, x) or with leading level / time dims
 
     Attributes
     ----------
@@ -239,158 +239,139 @@ class Filter:
     grid_type: GridType = GridType.REGULAR
     grid_vars: dict = field(default_factory=dict, repr=False)
 
+    # Same fields, defaults, attribute names (Laplacian, filter_spec, n_steps, grid_ds) and exception / warning texts as
+    # the reference class (gcm_filters/filter.py:294-393): they are the contract its users and tests rely on.  The
+    # bodies below are this package's own.
     def __post_init__(self):
         self.Laplacian = ALL_KERNELS[self.grid_type]
+        self._reject_bad_arguments()
+        self.n_steps = self._choose_n_steps()
+        self.filter_spec = _compute_filter_spec(self.filter_scale, self.dx_min, self.filter_shape, self.transition_width,
+                                                self.ndim, self.n_steps)
+        wanted, given = self.Laplacian.required_grid_args(), list(self.grid_vars)
+        if set(wanted) != set(given):
+            raise ValueError(f"Provided `grid_vars` {given} do not match expected {wanted}")
+        self.grid_ds = self._bundle_grid_vars()
 
-        if issubclass(self.Laplacian, AreaWeightedMixin) and self.dx_min != 1:
-            raise ValueError(
-                "Provided Laplacian is for simple fixed factor filtering, "
-                "where transformed field is filtered on a regular grid with dx = dy = 1. "
-                "dx_min must be set to 1."
-            )
-        if self.transition_width <= 1:
+    def _reject_bad_arguments(self):
+        fixed_factor = issubclass(self.Laplacian, AreaWeightedMixin)
+        if fixed_factor and self.dx_min != 1:
+            raise ValueError("Provided Laplacian is for simple fixed factor filtering, "
+                             "where transformed field is filtered on a regular grid with dx = dy = 1. "
+                             "dx_min must be set to 1.")
+        if not self.transition_width > 1:
             raise ValueError("Transition width must be > 1.")
+        if self.ndim > 2 and self.n_steps < 3:
+            raise ValueError("When ndim > 2, you must set n_steps manually")
 
+    def _choose_n_steps(self):
+        """The caller's n_steps when it asks for at least 3 steps, else the default rule (1-D / 2-D only)."""
+        asked = self.n_steps
         if self.ndim > 2:
-            if self.n_steps < 3:
-                raise ValueError("When ndim > 2, you must set n_steps manually")
-            n_steps_default = self.n_steps
-        else:
-            n_steps_default = _compute_n_steps_default(
-                self.ndim, self.filter_shape, self.filter_scale, self.dx_min, self.transition_width
-            )
-        if self.n_steps < 3:
-            self.n_steps = n_steps_default
-        if self.n_steps < n_steps_default:
-            warnings.warn("You have set n_steps below the default. Results might not be accurate.", stacklevel=2)
+            return asked
+        default = _compute_n_steps_default(self.ndim, self.filter_shape, self.filter_scale, self.dx_min,
+                                           self.transition_width)
+        if asked < 3:
+            return default
+        if asked < default:
+            warnings.warn("You have set n_steps below the default. Results might not be accurate.", stacklevel=4)
+        return asked
 
-        self.filter_spec = _compute_filter_spec(
-            self.filter_scale, self.dx_min, self.filter_shape, self.transition_width, self.ndim, self.n_steps
-        )
-
-        if not set(self.Laplacian.required_grid_args()) == set(self.grid_vars):
-            raise ValueError(
-                f"Provided `grid_vars` {list(self.grid_vars)} do not match expected "
-                f"{list(self.Laplacian.required_grid_args())}"
-            )
+    def _bundle_grid_vars(self):
+        """An ``xarray.Dataset`` when every grid variable is an xarray object (what ``apply`` feeds apply_ufunc from),
+        a plain dict otherwise (bare numpy / torch arrays)."""
         xr = _xarray()
-        if xr is not None and all(isinstance(v, (xr.DataArray, xr.Variable)) for v in self.grid_vars.values()):
-            self.grid_ds = xr.Dataset({name: da for name, da in self.grid_vars.items()})
-        else:
-            self.grid_ds = dict(self.grid_vars)
+        if xr is not None and self.grid_vars and all(isinstance(v, (xr.DataArray, xr.Variable)) for v in self.grid_vars.values()):
+            return xr.Dataset(dict(self.grid_vars))
+        return dict(self.grid_vars)
 
-    # -- cosmetics ----------------------------------------------------------------------------
+    # -- the target and its polynomial, for inspection -------------------------------------------
     def plot_shape(self, ax=None):
         """Plot the shape of the target filter and approximation."""
         import matplotlib.pyplot as plt
 
-        s_max = self.filter_spec.s_max
-        F = _target_function[self.filter_shape](TargetSpec(s_max, self.filter_scale, self.transition_width))
-        x = np.linspace(-1, 1, 10001)
-        k = np.sqrt(s_max * (x + 1) / 2)
+        spec = self.filter_spec
+        target = _target_function[self.filter_shape](TargetSpec(spec.s_max, self.filter_scale, self.transition_width))
+        t = np.linspace(-1.0, 1.0, 10001)
+        wavenumber = np.sqrt(0.5 * spec.s_max * (t + 1.0))
+        fitted = np.asarray(spec.p) @ _cheb_T(t, spec.n_steps)
+        cutoff = 2 * np.pi / self.filter_scale
         if ax is None:
-            _, ax = plt.subplots()
-        ax.plot(k, F(x), "g", label="target filter", linewidth=4)
-        approx = (np.asarray(self.filter_spec.p)[:, None] * _cheb_T(x, self.filter_spec.n_steps)).sum(axis=0)
-        ax.plot(k, approx, "m", label="approximation", linewidth=4)
-        ax.axvline(2 * np.pi / self.filter_scale, color="k", label="filter cutoff wavenumber", linewidth=2)
-        ax.set_xlim(left=0)
-        if self.filter_scale / self.dx_min > 10:
-            ax.set_xlim(right=4 * np.pi / self.filter_scale)
-        ax.set_ylim(bottom=-0.1)
-        ax.set_ylim(top=1.1)
+            ax = plt.subplots()[1]
+        for curve, style, label in ((target(t), "g", "target filter"), (fitted, "m", "approximation")):
+            ax.plot(wavenumber, curve, style, label=label, linewidth=4)
+        ax.axvline(cutoff, color="k", label="filter cutoff wavenumber", linewidth=2)
+        right = 2 * cutoff if self.filter_scale / self.dx_min > 10 else None   # zoom in on strong filters
+        ax.set_xlim(left=0, right=right)
+        ax.set_ylim(bottom=-0.1, top=1.1)
         ax.set_xlabel("Wavenumber k", fontsize=18)
         ax.grid(True)
         ax.legend()
+        return ax
 
-    # -- scalar fields ------------------------------------------------------------------------
+    # -- applying the filter ---------------------------------------------------------------------
+    def _grid_args(self, as_xarray: bool):
+        names = self.Laplacian.required_grid_args()
+        if not as_xarray:
+            return [self.grid_vars[n] for n in names]
+        if isinstance(self.grid_ds, dict):
+            bare = [n for n in names if not hasattr(self.grid_ds[n], "dims")]
+            if bare:
+                raise TypeError(f"grid_vars {bare} must be xarray DataArrays to filter xarray objects")
+        return [self.grid_ds[n] for n in names]
+
+    def _through_apply_ufunc(self, func, fields, dims):
+        """The one call into ``xarray.apply_ufunc`` (reference filter.py:478-486, 518-527): every field and grid
+        variable has ``dims`` as core dims (moved last), one output per field, same keywords as upstream so that lazy
+        (dask) inputs keep working: ``dask="parallelized"`` then calls ``func`` from worker threads, block by block."""
+        xr = _xarray()
+        if xr is None:
+            raise ImportError("xarray is required to filter xarray objects; pass numpy arrays or torch tensors instead")
+        assert len(dims) == 2
+        operands = list(fields) + self._grid_args(as_xarray=True)
+        return xr.apply_ufunc(
+            func,
+            *operands,
+            input_core_dims=len(operands) * [dims],
+            output_core_dims=[dims] if len(fields) == 1 else len(fields) * [dims],
+            output_dtypes=[f.dtype for f in fields],
+            dask="parallelized",
+        )
+
     def apply(self, ds, dims=None):
         """Filter an ``xarray.DataArray`` / ``xarray.Dataset`` with a scalar Laplacian across ``dims``
         (two names, latitude-like dimension first).
 
         Extension: a bare ``numpy.ndarray`` or ``torch.Tensor`` (``dims`` omitted) is filtered over its
         last two axes (y, x), leading axes being independent batches -- exactly what ``apply_ufunc`` hands
-        to ``filter_func``; an MI355X-resident tensor is filtered in place in HBM and returned as a tensor.
+        to ``filter_func``; an MI355X-resident tensor is filtered in HBM and returned as a tensor.
         """
         if issubclass(self.Laplacian, BaseVectorLaplacian):
-            raise ValueError(
-                f"Provided Laplacian {self.Laplacian} is a vector Laplacian. "
-                f"The ``.apply`` method is only suitable for scalar Laplacians."
-            )
-        if _is_bare_array(ds):
-            return _create_filter_func(self.filter_spec, self.Laplacian)(ds, *self._grid_args_bare())
-        xr = _xarray()
-        if xr is not None and isinstance(ds, xr.Dataset):
-            filtered = ds.copy(deep=True)
-            any_filtered = False
-            for key, var in filtered.variables.items():
-                if all(dim in var.dims for dim in dims):
-                    filtered[key] = self._apply_to_dataarray(var, dims=dims)
-                    any_filtered = True
-            if not any_filtered:
-                warnings.warn(
-                    f"No variables in the dataset had all of the given "
-                    f"dimensions ({dims}), so nothing was filtered.",
-                    stacklevel=2,
-                )
-            return filtered
-        return self._apply_to_dataarray(ds, dims=dims)
-
-    def _grid_args_bare(self):
-        return [self.grid_vars[name] for name in self.Laplacian.required_grid_args()]
-
-    def _grid_args_xr(self):
-        xr = _xarray()
-        names = self.Laplacian.required_grid_args()
-        if isinstance(self.grid_ds, dict):
-            missing_dims = [n for n in names if not hasattr(self.grid_ds[n], "dims")]
-            if missing_dims:
-                raise TypeError(f"grid_vars {missing_dims} must be xarray DataArrays to filter xarray objects")
-        return [self.grid_ds[name] for name in names]
-
-    def _apply_to_dataarray(self, field, dims):
-        xr = _xarray()
-        if xr is None:
-            raise ImportError("xarray is required to filter xarray objects; pass a numpy array or torch tensor instead")
+            raise ValueError(f"Provided Laplacian {self.Laplacian} is a vector Laplacian. "
+                             f"The ``.apply`` method is only suitable for scalar Laplacians.")
         filter_func = _create_filter_func(self.filter_spec, self.Laplacian)
-        grid_args = self._grid_args_xr()
-        assert len(dims) == 2
-        n_args = 1 + len(grid_args)
-        return xr.apply_ufunc(
-            filter_func,
-            field,
-            *grid_args,
-            input_core_dims=n_args * [dims],
-            output_core_dims=[dims],
-            output_dtypes=[field.dtype],
-            dask="parallelized",
-        )
+        if _is_bare_array(ds):
+            return filter_func(ds, *self._grid_args(as_xarray=False))
+        xr = _xarray()
+        if xr is None or not isinstance(ds, xr.Dataset):
+            return self._through_apply_ufunc(filter_func, [ds], dims)
+        # a Dataset: every variable that has both dims is filtered, the others are carried along untouched
+        result = ds.copy(deep=True)
+        hits = [name for name, var in result.variables.items() if set(dims) <= set(var.dims)]
+        for name in hits:
+            result[name] = self._through_apply_ufunc(filter_func, [result.variables[name]], dims)
+        if not hits:
+            warnings.warn(f"No variables in the dataset had all of the given dimensions ({dims}), so nothing was filtered.",
+                          stacklevel=2)
+        return result
 
-    # -- vector fields ------------------------------------------------------------------------
     def apply_to_vector(self, ufield, vfield, dims=None):
         """Filter a vector field (u, v) with a vector Laplacian across ``dims``; bare arrays as in ``apply``."""
         if not issubclass(self.Laplacian, BaseVectorLaplacian):
-            raise ValueError(
-                f"Provided Laplacian {self.Laplacian} is a scalar Laplacian. "
-                f"The ``.apply_to_vector`` method is only suitable for vector Laplacians."
-            )
+            raise ValueError(f"Provided Laplacian {self.Laplacian} is a scalar Laplacian. "
+                             f"The ``.apply_to_vector`` method is only suitable for vector Laplacians.")
         filter_func_vec = _create_filter_func_vec(self.filter_spec, self.Laplacian)
         if _is_bare_array(ufield) and _is_bare_array(vfield):
-            return filter_func_vec(ufield, vfield, *self._grid_args_bare())
-        xr = _xarray()
-        if xr is None:
-            raise ImportError("xarray is required to filter xarray objects; pass numpy arrays or torch tensors instead")
-        grid_args = self._grid_args_xr()
-        assert len(dims) == 2
-        n_args = 2 + len(grid_args)
-        (ufield_smooth, vfield_smooth) = xr.apply_ufunc(
-            filter_func_vec,
-            ufield,
-            vfield,
-            *grid_args,
-            input_core_dims=n_args * [dims],
-            output_core_dims=2 * [dims],
-            output_dtypes=[ufield.dtype, vfield.dtype],
-            dask="parallelized",
-        )
-        return (ufield_smooth, vfield_smooth)
+            return filter_func_vec(ufield, vfield, *self._grid_args(as_xarray=False))
+        u_filtered, v_filtered = self._through_apply_ufunc(filter_func_vec, [ufield, vfield], dims)
+        return (u_filtered, v_filtered)

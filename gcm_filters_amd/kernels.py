@@ -85,15 +85,108 @@ def compute_dtype(arrays: Sequence) -> int:
     return _lib.F32 if (rt.kind == "f" and rt.itemsize <= 4) else _lib.F64
 
 
+# How a cached device plan is tied to the host grid planes it was folded from (the reference rebuilds and re-validates its
+# Laplacian on every call, gcm_filters/filter.py:183; a plan lives in HBM and is reused while the planes are unchanged):
+#   * the planes (and the arrays that own their buffers) are made READ-ONLY while a cached plan refers to them, so an
+#     in-place edit raises instead of silently filtering with stale coefficients; writability comes back when the plan
+#     leaves the cache (LRU eviction, clear_plan_cache()).  torch tensors carry a version counter instead;
+#   * the cache key holds the buffer address, layout and a 256-value strided sample, and an entry is only reused while the
+#     owner of the buffer is still alive (no false hit on a freed-and-reallocated buffer).  A writable view created BEFORE
+#     the plan was cached can still edit the buffer behind its back: GCMF_PLAN_CACHE_VERIFY=full hashes the whole plane on
+#     every call (~5 ms per 2400x3600 f64 plane), GCMF_PLAN_CACHE=0 rebuilds the plan on every call like the reference.
+_VERIFY_FULL = os.environ.get("GCMF_PLAN_CACHE_VERIFY", "sample") == "full"
+_CACHE_ON = os.environ.get("GCMF_PLAN_CACHE", "1") != "0"
+
+
+def _content_hash(a) -> int:
+    buf = np.ascontiguousarray(a)
+    try:
+        import xxhash
+        return xxhash.xxh3_64_intdigest(buf)
+    except ImportError:
+        import zlib
+        return zlib.crc32(buf)
+
+
 def _fingerprint(a) -> Tuple:
-    """Cheap identity of a grid plane: buffer address, layout, and a strided sample of its values (256 of them:
-    the check runs on every filter call, 8 planes of a 2400x3600 grid cost ~40 us; 2048 samples cost 280 us)."""
+    """Identity of a grid plane: buffer address, layout, and a strided sample of its values (256 of them: the check runs
+    on every filter call, 8 planes of a 2400x3600 grid cost ~40 us) -- or a hash of all of it (GCMF_PLAN_CACHE_VERIFY=full)."""
     if _is_torch(a):
         return ("t", a.data_ptr(), tuple(a.shape), tuple(a.stride()), str(a.dtype), a._version, str(a.device))
+    if _VERIFY_FULL:
+        return ("n", a.__array_interface__["data"][0], a.shape, a.strides, a.dtype.str, _content_hash(a))
     n = a.size
     flat = a.reshape(-1) if a.flags.c_contiguous else a.ravel()
     sample = flat[:: max(1, n // 256)]
     return ("n", a.__array_interface__["data"][0], a.shape, a.strides, a.dtype.str, hash(sample.tobytes()))
+
+
+def _owner(a: np.ndarray) -> np.ndarray:
+    """The ndarray at the bottom of a chain of views (it owns the buffer or wraps a foreign one)."""
+    while isinstance(a.base, np.ndarray):
+        a = a.base
+    return a
+
+
+class _HostLocks:
+    """Reference-counted write protection of host arrays that cached plans were folded from."""
+
+    def __init__(self):
+        self._mu = threading.Lock()
+        self._held: Dict[int, list] = {}   # id(array) -> [weakref, count]
+
+    def acquire(self, arrays) -> list:
+        """Make `arrays` and the owners of their buffers read-only; returns the tickets for ``release``."""
+        tickets = []
+        with self._mu:
+            for a in arrays:
+                if not isinstance(a, np.ndarray):
+                    continue
+                for x in {id(a): a, id(_owner(a)): _owner(a)}.values():
+                    ent = self._held.get(id(x))
+                    if ent is not None and ent[0]() is x:
+                        ent[1] += 1
+                        tickets.append(ent[0])
+                    elif x.flags.writeable:
+                        x.flags.writeable = False
+                        ref = weakref.ref(x)
+                        self._held[id(x)] = [ref, 1]
+                        tickets.append(ref)
+        return tickets
+
+    def release(self, tickets):
+        with self._mu:
+            for ref in reversed(tickets):   # owners of the buffers first: a view cannot be made writable before its base
+                x = ref()
+                if x is None:
+                    continue
+                ent = self._held.get(id(x))
+                if ent is None or ent[0] is not ref:
+                    continue
+                ent[1] -= 1
+                if ent[1] > 0:
+                    continue
+                del self._held[id(x)]
+                try:
+                    x.flags.writeable = True
+                except ValueError:
+                    # a view whose base is still protected on behalf of another plan: it gets its flag back with the base
+                    own = self._held.get(id(_owner(x)))
+                    if own is not None:
+                        own.append(ref)
+                    continue
+                for late in ent[2:]:
+                    v = late()
+                    if v is not None:
+                        try:
+                            v.flags.writeable = True
+                        except ValueError:
+                            pass
+            for k in [k for k, e in self._held.items() if e[0]() is None]:
+                del self._held[k]
+
+
+_HOST_LOCKS = _HostLocks()
 
 
 # Host outputs: a fresh pageable numpy array costs more than the transfer that fills it (69 MB: 2.5 ms of first-touch
@@ -139,29 +232,45 @@ class _PlanCache:
     (filter.py:183); here the equivalent state lives in HBM and is reused while the grid arrays are
     unchanged (same buffers, same sampled contents)."""
 
-    def __init__(self, capacity: int = 6):
+    def __init__(self, capacity: int = int(os.environ.get("GCMF_PLAN_CACHE_SIZE", "64"))):
         self.capacity = capacity
-        self._d: "OrderedDict[Tuple, _lib.Plan]" = OrderedDict()
+        self._d: "OrderedDict[Tuple, Tuple]" = OrderedDict()   # key -> (plan, owner weakrefs, lock tickets)
         self._lock = threading.Lock()
 
-    def get(self, key, factory):
+    @staticmethod
+    def _drop(entry):
+        plan, _, tickets = entry
+        plan.close()
+        _HOST_LOCKS.release(tickets)
+
+    def get(self, key, factory, host_planes=()):
+        """The plan for `key`, built by `factory` if absent.  `host_planes`: the numpy grid planes the plan is folded from
+        (write-protected while the plan is cached; the entry dies with the owners of their buffers)."""
         with self._lock:
-            p = self._d.get(key)
-            if p is not None:
-                self._d.move_to_end(key)
-                return p
+            ent = self._d.get(key)
+            if ent is not None:
+                if all(r() is not None for r in ent[1]):
+                    self._d.move_to_end(key)
+                    return ent[0]
+                self._drop(self._d.pop(key))   # a buffer was freed since: same address, unknown contents
         p = factory()
+        nps = [a for a in host_planes if isinstance(a, np.ndarray)]
+        owners = [weakref.ref(_owner(a)) for a in nps]
+        tickets = _HOST_LOCKS.acquire(nps)
         with self._lock:
-            self._d[key] = p
+            old = self._d.pop(key, None)
+            if old is not None:
+                self._drop(old)
+            self._d[key] = (p, owners, tickets)
             while len(self._d) > self.capacity:
-                _, old = self._d.popitem(last=False)
-                old.close()
+                _, ev = self._d.popitem(last=False)
+                self._drop(ev)
         return p
 
     def clear(self):
         with self._lock:
-            for p in self._d.values():
-                p.close()
+            for ent in self._d.values():
+                self._drop(ent)
             self._d.clear()
 
 
@@ -169,7 +278,7 @@ PLAN_CACHE = _PlanCache()
 
 
 def clear_plan_cache():
-    """Drop every cached device plan (frees their HBM)."""
+    """Drop every cached device plan (frees their HBM) and give the grid arrays they were built from back their writability."""
     PLAN_CACHE.clear()
 
 
@@ -208,6 +317,7 @@ class _DeviceLaplacian:
     is_dimensional = False
 
     def __init__(self, *args, **kwargs):
+        self._skip_kappa_one = bool(kwargs.pop("_skip_kappa_one", False))
         names = self._ARGS
         if len(args) > len(names):
             raise TypeError(f"{type(self).__name__}() takes {len(names)} grid arguments but {len(args)} were given")
@@ -224,14 +334,68 @@ class _DeviceLaplacian:
         for n in names:
             setattr(self, n, vals[n])
         self._planes = [_unwrap(vals[n]) for n in names]
-        for a in self._planes:
-            if a.ndim != 2:
-                raise NotImplementedError(
-                    "grid variables must be 2-D (y, x) planes shared by all batch entries; "
-                    f"got a grid variable of shape {tuple(a.shape)}")
+        for n, a in zip(names, self._planes):
+            if a.ndim < 2:
+                raise ValueError(f"grid variable {n!r} needs at least two (y, x) dimensions, got shape {tuple(a.shape)}")
+        self._levels = None
+        if any(a.ndim > 2 for a in self._planes):
+            self._init_levels()
+            return
         self._fp = tuple(_fingerprint(a) for a in self._planes)
         if self._planes:  # validation happens at construction, like the reference's __post_init__
             self._plan(compute_dtype(self._planes), tuple(self._planes[0].shape))
+
+    # -- grid variables with leading (level / time) dims ------------------------------------------
+    def _init_levels(self):
+        """Grid variables such as wet_mask(z, y, x) or kappa(z, y, x).  The reference's kernels roll along the last two
+        axes only (kernels.py:113-121, 163-187, 297-315) and xarray.apply_ufunc broadcasts the remaining dims of field
+        and grid variables against each other (filter.py:478-486), so every index of the grid variables' broadcast
+        leading shape is an independent 2-D problem: one device plan per index, each batch entry filtered with its own."""
+        leads = [tuple(a.shape[:-2]) for a in self._planes]
+        self._glead = tuple(np.broadcast_shapes(*leads))
+        if self.GRID_TYPE is GridType.IRREGULAR_WITH_LAND and not self._skip_kappa_one:
+            # the reference tests the WHOLE kappa arrays (kernels.py:262-281); the per-plane plans repeat the > 1 test
+            kw, ks = (np.asarray(x.detach().cpu() if _is_torch(x) else x) for x in (self.kappa_w, self.kappa_s))
+            if not (np.any(np.isclose(kw, 1.0, atol=1e-5)) or np.any(np.isclose(ks, 1.0, atol=1e-5))) \
+                    and not (np.any(kw > 1.0) or np.any(ks > 1.0)):
+                raise ValueError("At least one place in the domain must have either kappa_w = 1 or kappa_s = 1. "
+                                 "Otherwise the filter's scale will not be equal to filter_scale anywhere in the domain.")
+        self._levels = {}
+        for g in np.ndindex(*self._glead):
+            sub = []
+            for a, lead in zip(self._planes, leads):
+                if a.ndim == 2:
+                    sub.append(a)
+                else:  # align the plane's own leading dims with the tail of the broadcast shape
+                    gi = g[len(g) - len(lead):]
+                    sub.append(a[tuple(0 if n == 1 else i for i, n in zip(gi, lead))])
+            self._levels[g] = type(self)(*sub, _skip_kappa_one=True)
+
+    def _run_levels(self, fields, spec, out_f32):
+        fields = [_unwrap(f) for f in fields]
+        shape = tuple(fields[0].shape)
+        if len(shape) < 2:
+            raise ValueError("fields need at least two (y, x) dimensions")
+        core = shape[-2:]
+        out_lead = tuple(np.broadcast_shapes(shape[:-2], self._glead))
+        pad = len(out_lead) - len(self._glead)
+        outs = None
+        for g, lap in self._levels.items():
+            idx = tuple([slice(None)] * pad + [slice(None) if n == 1 else i for i, n in zip(g, self._glead)])
+            sub = []
+            for f in fields:
+                fb = f.expand(*out_lead, *core) if _is_torch(f) else np.broadcast_to(f, out_lead + core)
+                sub.append(fb[idx])
+            res = lap._run(sub, spec=spec, out_f32=out_f32)
+            if outs is None:
+                if _is_torch(res[0]):
+                    import torch
+                    outs = [torch.empty(out_lead + core, dtype=r.dtype, device=r.device) for r in res]
+                else:
+                    outs = [np.empty(out_lead + core, dtype=r.dtype) for r in res]
+            for o, r in zip(outs, res):
+                o[idx] = r
+        return outs
 
     # -- protocol ----------------------------------------------------------------------------
     @classmethod
@@ -245,7 +409,7 @@ class _DeviceLaplacian:
         on_gpu = bool(self._planes) and all(_on_gpu(a) for a in self._planes)
         if device is None:
             device = self._planes[0].device.index if on_gpu else current_device()
-        key = (self.GRID_TYPE.value, dtype, tuple(shape), device, self._fp)
+        key = (self.GRID_TYPE.value, dtype, tuple(shape), device, self._skip_kappa_one, self._fp)
 
         def factory():
             try:
@@ -255,18 +419,27 @@ class _DeviceLaplacian:
                     keep = [a.to(tdt).contiguous() for a in self._planes]
                     torch.cuda.synchronize(device)
                     plan = _lib.Plan(self.GRID_TYPE.value, dtype, shape[0], shape[1], [t.data_ptr() for t in keep],
-                                     device=device, planes_on_device=True)
+                                     device=device, planes_on_device=True, skip_kappa_one=self._skip_kappa_one)
                     del keep
                     return plan
                 host = [a.detach().cpu().numpy() if _is_torch(a) else a for a in self._planes]
-                return _lib.Plan(self.GRID_TYPE.value, dtype, shape[0], shape[1], host, device=device)
+                return _lib.Plan(self.GRID_TYPE.value, dtype, shape[0], shape[1], host, device=device,
+                                 skip_kappa_one=self._skip_kappa_one)
             except _lib.GcmfError as e:
                 raise _translate(e) from None
 
-        return PLAN_CACHE.get(key, factory)
+        if not _CACHE_ON:   # the reference's behaviour: a fresh Laplacian (validation + precompute) per call
+            old = getattr(self, "_own_plan", None)
+            if old is not None:
+                old.close()
+            self._own_plan = factory()
+            return self._own_plan
+        return PLAN_CACHE.get(key, factory, () if on_gpu else self._planes)
 
     def _run(self, fields: Sequence, spec=None, out_f32: bool = False):
         """Shared driver of __call__ (spec None: one Laplacian) and of filter_func (spec: whole polynomial)."""
+        if self._levels is not None:
+            return self._run_levels(fields, spec, out_f32)
         fields = [_unwrap(f) for f in fields]
         shape = tuple(fields[0].shape)
         if len(shape) < 2:

@@ -95,6 +95,10 @@ typedef struct gcmf_plan_desc {
 /* A plan that covers the whole (periodic, non-tripolar) grid but keeps `halo` ghost rows per edge like a slab whose
  * two neighbours are itself: the one-rank form of the row-slab driver (tests of the exchange path on a single GPU). */
 #define GCMF_PLAN_SELF_RING 0x1
+/* IRREGULAR_WITH_LAND: do not fail with GCMF_ERR_KAPPA_NONE_ONE.  For grid variables with leading (level / time) dims the
+ * reference applies that check to the whole array (kernels.py:274-281), not per (y, x) plane; the Python layer then does
+ * it itself and builds one plan per plane with this flag. */
+#define GCMF_PLAN_SKIP_KAPPA_ONE 0x2
 
 /*
  * Build a plan = the reference's `Laplacian(**grid_vars)` (kernels.py __post_init__ methods):

@@ -82,7 +82,44 @@ class Dataset:
             raise AttributeError(k)
 
 
+def chunked(da, dim, nchunks):
+    """Mark `da` as lazily chunked along the non-core dim `dim` (a stand-in for ``da.chunk({dim: ...})``): apply_ufunc with
+    dask="parallelized" then calls the function once per block, CONCURRENTLY from a pool of worker threads -- the way
+    dask's threaded scheduler drives ``filter_func`` (reference filter.py:485, docs/basic_filtering.rst:175-203)."""
+    out = DataArray(da.data, da.dims, name=da.name)
+    out._chunks = (dim, int(nchunks))
+    return out
+
+
+def _apply_blockwise(func, args, input_core_dims, output_core_dims, dim, nchunks):
+    from concurrent.futures import ThreadPoolExecutor
+
+    n = [a for a in args if dim in a.dims][0].data.shape[[a for a in args if dim in a.dims][0].dims.index(dim)]
+    edges = np.linspace(0, n, min(nchunks, n) + 1).astype(int)
+
+    def block(lo, hi):
+        sub = []
+        for a in args:
+            if dim in a.dims:
+                idx = [slice(None)] * a.data.ndim
+                idx[a.dims.index(dim)] = slice(lo, hi)
+                sub.append(DataArray(a.data[tuple(idx)], a.dims))
+            else:
+                sub.append(a)
+        return apply_ufunc(func, *sub, input_core_dims=input_core_dims, output_core_dims=output_core_dims)
+
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        parts = list(pool.map(lambda e: block(*e), zip(edges[:-1], edges[1:])))
+    multi = len(output_core_dims) > 1
+    cols = list(zip(*parts)) if multi else [parts]
+    outs = tuple(DataArray(np.concatenate([p.data for p in col], axis=col[0].dims.index(dim)), col[0].dims) for col in cols)
+    return outs if multi else outs[0]
+
+
 def apply_ufunc(func, *args, input_core_dims, output_core_dims, output_dtypes=None, dask=None):
+    lazy = [a._chunks for a in args if getattr(a, "_chunks", None)]
+    if lazy and dask == "parallelized":
+        return _apply_blockwise(func, args, input_core_dims, output_core_dims, *lazy[0])
     raw, lead_dims = [], ()
     for a, core in zip(args, input_core_dims):
         core = list(core)

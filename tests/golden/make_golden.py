@@ -16,6 +16,9 @@ Outputs (committed):
                            sum / sum of squares / max-abs per case (the planes themselves are too big to
                            store).  Inputs come from gcm_filters_amd.testing.baseline_workload, like bench.py's.
 
+  reference_gridbatched.npz (`--gridbatched`) grid variables with a leading level dim (wet_mask(z, y, x), kappa(z, y, x), ...)
+                           against fields of shape (2, z, y, x): L(f) and the Gaussian filter from the imported reference.
+
 `--out DIR` writes into DIR instead of this directory (to check that the committed files regenerate).
 
 No reference source text is copied anywhere: only numbers leave this script.
@@ -200,6 +203,72 @@ SPEC_TABLE = [
 ]
 
 
+# ------------------------------------------------------------------------------------------------
+# grid variables with leading (level) dims: reference_gridbatched.npz -- case builder shared with the tests
+# ------------------------------------------------------------------------------------------------
+GRIDBATCHED_GRIDS = ["REGULAR_WITH_LAND", "REGULAR_WITH_LAND_AREA_WEIGHTED", "IRREGULAR_WITH_LAND", "TRIPOLAR_POP_WITH_LAND",
+                     "TRIPOLAR_REGULAR_WITH_LAND_AREA_WEIGHTED", "VECTOR_C_GRID", "VECTOR_B_GRID"]
+
+
+def build_gridbatched_case(grid: str):
+    """(fields, grid_vars, filter kwargs): a 3-level problem whose wet mask (and kappa / a metric) differs per level while the
+    other grid variables stay 2-D; fields have shape (2, 3, ny, nx) -- the leading 2 broadcasts against the grid variables."""
+    sys.path.insert(0, REPO)
+    from gcm_filters_amd import testing as T
+
+    shape, nlev = SMALL, 3
+    ny, nx = shape
+    vec = grid in T.VECTOR_GRIDS
+    gv = T.vector_grid_vars(grid, shape) if vec else T.scalar_grid_vars(grid, shape)
+
+    def per_level(mask2d):
+        m = np.stack([mask2d.copy() for _ in range(nlev)])
+        for l in range(nlev):  # an island that grows with depth (never in the southernmost row)
+            m[l, ny // 2 + 2: ny // 2 + 4 + 2 * l, nx // 2 + 3: nx // 2 + 6 + 3 * l] = 0
+        return m
+
+    for k in list(gv):
+        if k.startswith("wet_mask"):
+            gv[k] = per_level(gv[k])
+    if grid == "IRREGULAR_WITH_LAND":  # kappa_w varies per level and reaches 1 only on level 0 (the reference tests the whole array)
+        kw = np.stack([T.smooth_kappa(shape, 21 + l) * (1.0 if l == 0 else 0.8) for l in range(nlev)])
+        gv["kappa_w"] = kw
+        gv["kappa_s"] = 0.9 * T.smooth_kappa(shape, 31)
+    if grid == "VECTOR_C_GRID":
+        gv["kappa_iso"] = np.stack([T.smooth_kappa(shape, 41 + l) for l in range(nlev)])
+    if grid == "VECTOR_B_GRID":  # no mask: let a metric depend on the level instead
+        gv["TAREA"] = np.stack([gv["TAREA"] * (1.0 + 0.05 * l) for l in range(nlev)])
+    ncomp = 2 if vec else 1
+    fields = tuple(np.stack([np.stack([T.random_field(shape, 500 + 100 * c + 10 * a + l) for l in range(nlev)])
+                             for a in range(2)]) for c in range(ncomp))
+    dimensional = grid in ("IRREGULAR_WITH_LAND", "TRIPOLAR_POP_WITH_LAND") or vec
+    dx_min = T.grid_dx_min(grid, gv) if dimensional else 1.0
+    fk = dict(filter_scale=6.0 * dx_min, dx_min=dx_min, filter_shape="GAUSSIAN", n_steps=0)
+    return fields, gv, fk
+
+
+def make_gridbatched(rf, rk, outdir):
+    out = {}
+    for grid in GRIDBATCHED_GRIDS:
+        fields, gv, fk = build_gridbatched_case(grid)
+        cls = rk.ALL_KERNELS[rk.GridType[grid]]
+        args = [gv[k] for k in cls.required_grid_args()]
+        with np.errstate(all="ignore"):
+            res = cls(**gv)(*fields)
+            out[f"{grid}/lap/gridbatched"] = np.stack(res) if isinstance(res, tuple) else np.asarray(res)
+            shape = rf.FilterShape[fk["filter_shape"]]
+            n = rf._compute_n_steps_default(2, shape, fk["filter_scale"], fk["dx_min"], np.pi)
+            spec = rf._compute_filter_spec(fk["filter_scale"], fk["dx_min"], shape, np.pi, 2, n)
+            if len(fields) == 2:
+                res = np.stack(rf._create_filter_func_vec(spec, cls)(*fields, *args))
+            else:
+                res = np.asarray(rf._create_filter_func(spec, cls)(*fields, *args))
+        out[f"{grid}/gauss/gridbatched"] = res
+        print(grid, "n_steps", int(n), res.shape, flush=True)
+    np.savez_compressed(os.path.join(outdir, "reference_gridbatched.npz"), **out)
+    print("reference_gridbatched.npz:", len(out), "arrays")
+
+
 # full-size cases: key -> (BASELINE config, filter scale in dx_min units (0 = the config's own), NaN on land?)
 FULLSIZE_CASES = {
     "cfg2_n11": (2, 10.0, False), "cfg2_n56": (2, 50.0, False), "cfg2_n11_nanland": (2, 10.0, True),
@@ -255,6 +324,9 @@ def main():
         os.makedirs(HERE, exist_ok=True)
     if "--fullsize" in sys.argv:
         make_fullsize(rf, rk, HERE)
+        return 0
+    if "--gridbatched" in sys.argv:
+        make_gridbatched(rf, rk, HERE)
         return 0
 
     # 1. the reference's own goldens

@@ -647,3 +647,96 @@ def test_in_place_is_rejected():
     with pytest.raises(_lib.GcmfError) as e:
         plan.apply(p, 0.25, [d.data_ptr()], [d.data_ptr()], 1, device_ptrs=True)
     assert "alias" in str(e.value)
+
+
+# ---------------------------------------------------------------------------------------------------
+# grid variables with leading (level) dims: one device plan per level (upstream kernels.py:163-187 roll along the last two
+# axes only; filter.py:478-486 broadcasts the other dims)
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def golden_gridbatched():
+    import os
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_gridbatched.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize("grid", MG.GRIDBATCHED_GRIDS)
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_grid_variables_with_leading_dims(grid, where, golden_gridbatched):
+    import torch
+    fields, gv, fk = MG.build_gridbatched_case(grid)
+    vec = grid in T.VECTOR_GRIDS
+    if where == "device":
+        gv = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in gv.items()}
+        fields = tuple(torch.from_numpy(f).cuda() for f in fields)
+    to_np = lambda x: x.cpu().numpy() if hasattr(x, "cpu") else x
+    lap = ALL_KERNELS[GridType[grid]](**gv)
+    L = lap(*fields)
+    L = np.stack([to_np(x) for x in L]) if vec else to_np(L)
+    assert rel_err(L, golden_gridbatched[f"{grid}/lap/gridbatched"]) <= 1e-11
+    flt = Filter(filter_scale=fk["filter_scale"], dx_min=fk["dx_min"], grid_type=GridType[grid], grid_vars=gv)
+    got = flt.apply_to_vector(*fields) if vec else flt.apply(fields[0])
+    got = np.stack([to_np(x) for x in got]) if vec else to_np(got)
+    want = golden_gridbatched[f"{grid}/gauss/gridbatched"]
+    assert got.shape == want.shape
+    assert rel_err(got, want) <= 1e-11
+    # a field WITHOUT the extra leading dim broadcasts the same way: (z, y, x) field, (z, y, x) grid variables
+    one = flt.apply_to_vector(*(f[1] for f in fields)) if vec else flt.apply(fields[0][1])
+    one = np.stack([to_np(x) for x in one]) if vec else to_np(one)
+    assert rel_err(one, want[:, 1] if vec else want[1]) <= 1e-11
+
+
+def test_kappa_check_spans_all_levels():
+    """kernels.py:274-281 tests the whole kappa arrays: a level whose kappa stays below 1 is fine as long as another level
+    reaches 1; nothing reaching 1 anywhere, or anything above 1 on any level, is an error."""
+    fields, gv, fk = MG.build_gridbatched_case("IRREGULAR_WITH_LAND")
+    assert gv["kappa_w"][1].max() < 0.9 and gv["kappa_w"][0].max() == 1.0
+    ALL_KERNELS[GridType.IRREGULAR_WITH_LAND](**gv)
+    bad = dict(gv, kappa_w=0.8 * gv["kappa_w"])
+    with pytest.raises(ValueError, match=r"At least one place in the domain must have either kappa_w = 1 or kappa_s = 1.*"):
+        ALL_KERNELS[GridType.IRREGULAR_WITH_LAND](**bad)
+    worse = dict(gv, kappa_w=gv["kappa_w"].copy())
+    worse["kappa_w"][2, 5, 5] = 1.5
+    with pytest.raises(ValueError, match=r"There are kappa_w values > 1.*"):
+        ALL_KERNELS[GridType.IRREGULAR_WITH_LAND](**worse)
+
+
+# ---------------------------------------------------------------------------------------------------
+# plan cache: a cached device plan must never serve stale coefficients (the reference rebuilds its Laplacian per call,
+# upstream filter.py:183)
+# ---------------------------------------------------------------------------------------------------
+def test_plan_cache_never_serves_stale_coefficients(monkeypatch):
+    from gcm_filters_amd import kernels as K
+    shape = (600, 700)                                    # 420 000 cells: the 256-value sample sees 1 cell in 1640
+    f, gv = T.scalar_case("REGULAR_WITH_LAND", shape)
+    mask = gv["wet_mask"]
+    flt = Filter(filter_scale=4.0, dx_min=1.0, grid_type=GridType.REGULAR_WITH_LAND, grid_vars=gv)
+    before = flt.apply(f)
+    j, i = 411, 333                                       # an unsampled, wet cell
+    assert mask[j, i] == 1 and (j * shape[1] + i) % max(1, mask.size // 256) != 0
+    # 1. an in-place edit of a plane a cached plan was folded from is refused
+    assert not mask.flags.writeable
+    with pytest.raises(ValueError, match="read-only"):
+        mask[j, i] = 0
+    # 2. once the plan leaves the cache the array is writable again, and the edit changes the result
+    K.clear_plan_cache()
+    assert mask.flags.writeable
+    mask[j, i] = 0
+    after = flt.apply(f)
+    assert after[j, i] != before[j, i] and not np.array_equal(after, before)
+    want = O.filter_func(O.make_spec(4.0, 1.0), "REGULAR_WITH_LAND", f, gv)
+    assert rel_err(after, want) <= 1e-12
+    # 3. a writable view that existed before the plan was cached can still reach the buffer: whole-plane hashing catches it
+    K.clear_plan_cache()
+    base = np.ones(shape)
+    base[0, :] = 0
+    alias = base[:]                                       # created before any plan exists
+    monkeypatch.setattr(K, "_VERIFY_FULL", True)
+    flt2 = Filter(filter_scale=4.0, dx_min=1.0, grid_type=GridType.REGULAR_WITH_LAND, grid_vars={"wet_mask": base})
+    r1 = flt2.apply(f)
+    alias[j, i] = 0                                       # `alias` kept its flag; `base` is protected
+    r2 = flt2.apply(f)
+    assert not np.array_equal(r1, r2)
+    assert rel_err(r2, O.filter_func(O.make_spec(4.0, 1.0), "REGULAR_WITH_LAND", f, {"wet_mask": base})) <= 1e-12
+    K.clear_plan_cache()
+    assert base.flags.writeable

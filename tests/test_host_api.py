@@ -246,3 +246,27 @@ def test_plan_cache_fingerprint_and_host_outputs():
     assert out.shape == (3, 40, 64) and out.dtype == np.float64 and out.flags.c_contiguous and out.flags.writeable
     small = K._host_output((4, 4), np.float32)
     assert small.dtype == np.float32 and K._pinned_out >= 0
+
+
+def test_host_planes_are_write_protected_while_a_plan_refers_to_them():
+    """The plan cache's guard against stale coefficients (kernels._HostLocks; no device needed): arrays and the owners of
+    their buffers become read-only, nested holders are reference counted, views get their flag back with their base."""
+    from gcm_filters_amd import kernels as K
+    a = np.zeros((6, 8))
+    v = a[1:]
+    t1 = K._HOST_LOCKS.acquire([v])              # plan 1 was folded from a view
+    assert not v.flags.writeable and not a.flags.writeable
+    with pytest.raises(ValueError, match="read-only"):
+        a[0, 0] = 1.0
+    assert not a[2:].flags.writeable             # views made from now on inherit the protection
+    t2 = K._HOST_LOCKS.acquire([a])              # plan 2 from the owner itself
+    K._HOST_LOCKS.release(t1)
+    assert not a.flags.writeable and not v.flags.writeable
+    K._HOST_LOCKS.release(t2)
+    assert a.flags.writeable and v.flags.writeable
+    a[0, 0] = 1.0
+    ro = np.zeros(4)
+    ro.flags.writeable = False                   # the user's own read-only array is left alone
+    K._HOST_LOCKS.release(K._HOST_LOCKS.acquire([ro]))
+    assert not ro.flags.writeable
+    assert K._owner(v) is a and K._fingerprint(a) == K._fingerprint(a)

@@ -133,3 +133,22 @@ def test_oracle_vs_reference_fullsize_fixture():
     jj, ii = T.probe_points(T.BASELINE_SHAPE)
     assert np.array_equal(res[jj, ii], probe.reshape(-1))
     assert np.array_equal(np.array([res.sum(), (res * res).sum(), np.abs(res).max(), 0.0]), sums)
+
+
+@pytest.mark.parametrize("grid", MG.GRIDBATCHED_GRIDS)
+def test_oracle_grid_variables_with_leading_dims(grid):
+    """wet_mask(z, y, x) / kappa(z, y, x) against fields (2, z, y, x): the reference's kernels roll along the last two
+    axes only and numpy broadcasts the rest (upstream kernels.py:163-187 under filter.py:478-486); fixture from the
+    imported reference (make_golden.py --gridbatched)."""
+    import os
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_gridbatched.npz")) as z:
+        want_l, want_f = z[f"{grid}/lap/gridbatched"], z[f"{grid}/gauss/gridbatched"]
+    fields, gv, fk = MG.build_gridbatched_case(grid)
+    with np.errstate(all="ignore"):
+        assert np.array_equal(_stack(O.make_laplacian(grid, gv)(*fields)), want_l)
+        spec = O.make_spec(fk["filter_scale"], fk["dx_min"], "GAUSSIAN")
+        if len(fields) == 2:
+            got = np.stack(O.filter_func_vec(spec, grid, *fields, gv))
+        else:
+            got = O.filter_func(spec, grid, fields[0], gv)
+    assert np.array_equal(got, want_f)
