@@ -14,7 +14,7 @@ __device__ __forceinline__ void flux_multi2_march(const MultiP<T, FB> &P) {
   constexpr int WI = W - 2 * M;
 
   const int lane = threadIdx.x & 63;
-  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: scalar row / pointer arithmetic
   if (wid >= P.nwaves) return;
   const int wx = wid % P.nwx, st = wid / P.nwx;
   const int nx = P.nx, rows = P.rows;
@@ -121,14 +121,14 @@ __device__ __forceinline__ void flux_multi2_march(const MultiP<T, FB> &P) {
     const T(&gS)[VEC] = G[t - 1][q];
     const T(&gC)[VEC] = G[t - 1][q + 1];
     const T(&gN)[VEC] = G[t - 1][q + 2];
-    const T ev = from_upper_lane(gC[0]);
+    const T ev = from_upper_lane0(gC[0]);
     T fev[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       const T xE = (k == VEC - 1) ? ev : gC[k < VEC - 1 ? k + 1 : k];
       fev[k] = (xE - gC[k]) * cEq[e][k];
     }
-    const T few = from_lower_lane(fev[VEC - 1]);
+    const T few = from_lower_lane0(fev[VEC - 1]);
     const unsigned fmid = (q == 0) ? (Rf[t - 1] >> (2 * VEC)) : nf[0][t - 1];
     const unsigned fold2 = (t >= 2) ? ((q == 0) ? (Rf[t >= 2 ? t - 2 : 0] & OLD_MASK) : (Rf[t >= 2 ? t - 2 : 0] >> (2 * VEC))) : 0u;
     T tkv[VEC];

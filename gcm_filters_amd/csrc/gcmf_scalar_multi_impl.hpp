@@ -57,7 +57,7 @@ __device__ __forceinline__ void scalar_multi_march(const MultiP<T, FB> &P) {
   constexpr bool SAN = (KIND != K_REG);
 
   const int lane = threadIdx.x & 63;
-  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: scalar row / pointer arithmetic
   if (wid >= P.nwaves) return;
   const int wx = wid % P.nwx, st = wid / P.nwx;
   const int nx = P.nx, rows = P.rows;
@@ -215,7 +215,7 @@ __device__ __forceinline__ void scalar_multi_march(const MultiP<T, FB> &P) {
     const T(&gS)[VEC] = G[t - 1][0];
     const T(&gC)[VEC] = G[t - 1][1];
     const T(&gN)[VEC] = G[t - 1][2];
-    const T ev = from_upper_lane(gC[0]);
+    const T ev = from_upper_lane0(gC[0]);
     // flux form: the west-face flux of a cell IS the east-face flux of its western neighbour (same operands, same
     // rounding), so every east flux is computed once and the lane's first cell takes its west flux from the
     // lower lane -- one DPP hop of the flux instead of hops of the value and of the coefficient
@@ -226,9 +226,9 @@ __device__ __forceinline__ void scalar_multi_march(const MultiP<T, FB> &P) {
         const T xE = (k == VEC - 1) ? ev : gC[k < VEC - 1 ? k + 1 : k];
         fev[k] = (xE - gC[k]) * cEq[t][k];
       }
-      few = from_lower_lane(fev[VEC - 1]);
+      few = from_lower_lane0(fev[VEC - 1]);
     } else {
-      wv = from_lower_lane(gC[VEC - 1]);
+      wv = from_lower_lane0(gC[VEC - 1]);
     }
     T tkv[VEC];
 #pragma unroll

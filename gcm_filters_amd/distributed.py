@@ -136,10 +136,11 @@ class SlabFilter:
         if not self.multi:
             self.halo = 0
         else:
-            # default: 8 ghost rows (one blocked launch) per ~300 owned rows, at most 64: an exchange costs a few
-            # hundred microseconds of host + RCCL latency, a blocked 8-step launch on a 2400-row slab ~200 us, and
-            # the redundant ghost-zone work of a 64-row halo is still ~2 % there
-            auto = 8 * max(1, min(8, min_rows // 300))
+            # default: 8 ghost rows (one blocked launch) per ~300 owned rows, at least 16, at most 64: an exchange costs
+            # tens of microseconds of host + RCCL latency -- as much as a whole blocked 8-step launch on a 300-row slab
+            # (~50 us) -- while the redundant ghost-zone work of a 16-row halo is ~10 % there and ~2 % for 64 rows on a
+            # 2400-row slab
+            auto = max(16, 8 * min(8, min_rows // 300))
             self.halo = int(halo) if halo else auto
             self.halo = max(1, min(self.halo, min_rows))
         planes = [np.ascontiguousarray(np.asarray(grid_vars[k]), dtype=self.np_dtype)
@@ -174,10 +175,28 @@ class SlabFilter:
         self.exchange_kind = "native" if (self.multi and on_gpu and rccl_group and exchange != "torch") else "torch"
         self.comm = None
         if self.exchange_kind == "native" and self.multi:
-            uid = [_lib.Comm.unique_id() if self.rank == 0 else None]
+            # "auto" falls back to torch.distributed P2P if libgcmf cannot bring up its own communicator (all ranks agree)
+            err = None
+            try:
+                uid = [_lib.Comm.unique_id() if self.rank == 0 else None]
+            except _lib.GcmfError as e:
+                uid, err = [None], e
             if self.world > 1:
                 dist.broadcast_object_list(uid, src=self._global_rank(0), group=group)
-            self.comm = _lib.Comm(uid[0], self.world, self.rank, device)
+            if uid[0] is not None:
+                try:
+                    self.comm = _lib.Comm(uid[0], self.world, self.rank, device)
+                except _lib.GcmfError as e:
+                    err = e
+            ok = torch.tensor([0 if self.comm is None else 1], device=self.device)
+            if self.world > 1:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 0:
+                if exchange == "native":
+                    raise err if err is not None else RuntimeError("another rank could not create its gcmf_comm")
+                if self.comm is not None:
+                    self.comm.close()
+                self.comm, self.exchange_kind = None, "torch"
         self.tdtype = torch.float64 if self.np_dtype == np.float64 else torch.float32
         self._bufs = {}
         self.kernel_ms = 0.0
@@ -186,7 +205,10 @@ class SlabFilter:
         self.exchanges = 0
         self.time_kernels = False  # bench.py: bracket every step launch with events on the launch stream
         self.multi_depth = 8       # most recurrence steps fused per HBM pass (1 = single steps only)
-        self.overlap = True        # overlap the halo exchange with the interior rows of the last launch of a cycle
+        # overlap the halo exchange with the interior rows of the last launch of a cycle: splitting that launch into two
+        # edge strips + interior costs two small launches that march 2S warm-up rows for `halo` useful ones (~35 us
+        # each); worth it only when the interior is long enough to hide an exchange behind (tall slabs)
+        self.overlap = self.rows_owned >= 1000
 
     # -- data movement helpers -----------------------------------------------------------------
     def scatter_from_global(self, fields: Sequence[np.ndarray]):

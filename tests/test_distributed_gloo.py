@@ -67,6 +67,7 @@ def _worker(rank, world, port, q):
         for grid, shape, halo, nbatch in CASES:
             gv, fields, fk = _problem(grid, shape, nbatch)
             sf = SlabFilter(grid, gv, fk, shape[0], shape[1], halo=halo, engine_factory=OracleSlabEngine, device=-1)
+            sf.overlap = True   # small test slabs: force the overlapped (edge strips first) exchange where it fits
             local = sf.scatter_from_global(fields)
             out = sf.apply_local(local)
             got = sf.gather_to_global(out)

@@ -69,6 +69,7 @@ def _worker(rank, world, port, q):
             dx = T.grid_dx_min(grid, gv) if O.DIMENSIONAL[grid] else 1.0
             fk = dict(filter_scale=5.0 * dx, dx_min=dx, filter_shape="GAUSSIAN")
             sf = SlabFilter(grid, gv, fk, shape[0], shape[1], halo=halo, dtype=np.dtype(dt), device=0)
+            sf.overlap = True   # small test slabs: force the overlapped (edge strips first) exchange where it fits
             sf.time_kernels = True
             got = sf.gather_to_global(sf.apply_local(sf.scatter_from_global(fields)))
             sf.collect_kernel_times()

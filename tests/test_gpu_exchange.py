@@ -58,6 +58,7 @@ def test_self_ring_native_exchange_equals_single_domain(grid, shape, halo, nbatc
     fk = dict(filter_scale=6.0 * dx, dx_min=dx, filter_shape="GAUSSIAN")
     sf = SlabFilter(grid, gv, fk, shape[0], shape[1], halo=halo, dtype=np.dtype(dt), device=0, rank=0, world=1,
                     self_ring=True, exchange="native")
+    sf.overlap = True
     assert sf.exchange_kind == "native" and sf.halo == halo and sf.rows_alloc == shape[0] + 2 * halo
     got = [t.cpu().numpy() for t in sf.apply_local(sf.scatter_from_global(fields))]
     assert sf.exchanges >= (sf.n_steps - 1) // halo

@@ -56,6 +56,7 @@ def worker(rank, world, port, cases, q):
             fk = dict(filter_scale=3.0 * dx, dx_min=dx, filter_shape="TAPER", n_steps=nsteps)
             try:
                 sf = SlabFilter(grid, gv, fk, shape[0], shape[1], halo=halo, dtype=np.dtype(dt), device=0)
+                sf.overlap = True   # small test slabs: force the overlapped (edge strips first) exchange where it fits
                 sf.multi_depth, sf.overlap = depth, overlap
                 got = sf.gather_to_global(sf.apply_local(sf.scatter_from_global(fields)))
             except Exception as e:
