@@ -288,6 +288,41 @@ def roofline_of(cfg, r, steps, default_tuning):
     return out
 
 
+def run_config1(dev):
+    """BASELINE config 1 (REGULAR 512x512 fp64, Gaussian filter_scale 4, n_steps 16): the reference's CPU-runnable case.  On the
+    GPU it is a latency measurement (two launches); output checked against the probe the imported reference produced
+    (tests/golden/reference_generated.npz: REGULAR/config1)."""
+    import torch
+
+    from gcm_filters_amd import Filter, GridType, testing as T
+
+    f = T.random_field((512, 512), 100)
+    flt = Filter(filter_scale=4.0, dx_min=1.0, n_steps=16, grid_type=GridType.REGULAR)
+    d = torch.from_numpy(f).to(dev)
+    for _ in range(5):
+        out = flt.apply(d)
+    torch.cuda.synchronize()
+    reps = 200
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = flt.apply(d)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    rec = {"config": "BASELINE config 1: REGULAR 512x512, Gaussian filter_scale=4, n_steps=16 (HBM-resident, back-to-back calls)",
+           "n_steps": 16, "steps": reps, "value": 512 * 512 * 16 * reps / el, "unit": "cell-steps/s",
+           "us_per_application": 1e6 * el / reps, "dtype": "f64"}
+    gp = os.path.join(REPO, "tests", "golden", "reference_generated.npz")
+    if os.path.exists(gp):
+        with np.load(gp) as z:
+            probe, sums = z["REGULAR/config1/probe"], z["REGULAR/config1/sums"]
+        got = out.cpu().numpy()
+        rec["parity"] = {"fixture": "tests/golden/reference_generated.npz:REGULAR/config1", "n_probes": int(probe.size),
+                         "rel_err": float(np.abs(got[::8, ::8] - probe).max() / np.abs(probe).max()),
+                         "sum_rel_err": float(abs(got.sum() - sums[0]) / abs(sums[0])), "tolerance": 1e-6,
+                         "source": "imported reference (tests/golden/make_golden.py)"}
+    return rec
+
+
 def free_gpu():
     import gc
 
@@ -414,7 +449,9 @@ def main_single(args):
     out["parity"] = parity
     # ---- the other BASELINE configs, briefly ---------------------------------------------------------------------
     if not args.no_extra:
-        extras = []
+        extras = [run_config1(dev)]
+        if not extras[0].get("parity", {"rel_err": 0})["rel_err"] <= 1e-6:
+            failed.append(f"config 1 reference probe: rel_err {extras[0]['parity']['rel_err']:.3e}")
         for cfg in (2, 4, 5):
             if cfg == args.config:
                 continue

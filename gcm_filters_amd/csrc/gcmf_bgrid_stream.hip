@@ -95,8 +95,8 @@ template <typename T, typename FB> __global__ __launch_bounds__(256, 2) void k_b
     T uN[VEC], vN[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) { uN[k] = bsan(x.u[k]); vN[k] = bsan(x.v[k]); }
-    const T uw_ = from_lower_lane(uC[VEC - 1]), ue_ = from_upper_lane(uC[0]);
-    const T vw_ = from_lower_lane(vC[VEC - 1]), ve_ = from_upper_lane(vC[0]);
+    const T uw_ = from_lower_lane0(uC[VEC - 1]), ue_ = from_upper_lane0(uC[0]);
+    const T vw_ = from_lower_lane0(vC[VEC - 1]), ve_ = from_upper_lane0(vC[0]);
     const int j = r - 1;
     T tu[VEC], tv[VEC];
     FB fu[VEC], fv[VEC];

@@ -44,8 +44,8 @@ template <typename T, int VEC> struct BgLevel {
   }
   __device__ __forceinline__ void feed(const T (&uN)[VEC], const T (&vN)[VEC], const T (&K)[8][VEC], T (&lu)[VEC],
                                        T (&lv)[VEC]) {
-    const T uw_ = from_lower_lane(uC[VEC - 1]), ue_ = from_upper_lane(uC[0]);
-    const T vw_ = from_lower_lane(vC[VEC - 1]), ve_ = from_upper_lane(vC[0]);
+    const T uw_ = from_lower_lane0(uC[VEC - 1]), ue_ = from_upper_lane0(uC[0]);
+    const T vw_ = from_lower_lane0(vC[VEC - 1]), ve_ = from_upper_lane0(vC[0]);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       const T uc = uC[k], vc = vC[k];

@@ -185,8 +185,8 @@ __global__ __launch_bounds__(256, 2) void k_cgrid_stream(const CStreamP<T, FB> P
       vt[k] = sv * x.rdxCv[k];
       vh[k] = sv * x.rdyCv[k];
     }
-    const T ut_w = from_lower_lane(ut[VEC - 1]);   // W u~(r)
-    const T vh_e = from_upper_lane(vh_p[0]);       // E v^(r-1)
+    const T ut_w = from_lower_lane0(ut[VEC - 1]);   // W u~(r)
+    const T vh_e = from_upper_lane0(vh_p[0]);       // E v^(r-1)
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       const T utw = (k == 0) ? ut_w : ut[k > 0 ? k - 1 : 0];
@@ -196,8 +196,8 @@ __global__ __launch_bounds__(256, 2) void k_cgrid_stream(const CStreamP<T, FB> P
       Rm[k] = x.b1[k] * (vhe - vh_p[k]) + x.b2[k] * (uh[k] - uh_p[k]);
       Sm[k] = x.rq[k] * Rm[k];
     }
-    const T P_e = from_upper_lane(P_p[0]);         // E P(r-1)
-    const T S_w = from_lower_lane(Sm[VEC - 1]);    // W S(r-1)
+    const T P_e = from_upper_lane0(P_p[0]);         // E P(r-1)
+    const T S_w = from_lower_lane0(Sm[VEC - 1]);    // W S(r-1)
     const int j = r - 1;
     T tu[VEC], tv[VEC];
     FB fu[VEC], fv[VEC];

@@ -54,8 +54,8 @@ template <typename T, int VEC> struct CgLevel {
       vt[k] = sv[k] * cA[2][k];
       vh[k] = sv[k] * cA[3][k];
     }
-    const T ut_w = from_lower_lane(ut[VEC - 1]);
-    const T vh_e = from_upper_lane(vh_p[0]);
+    const T ut_w = from_lower_lane0(ut[VEC - 1]);
+    const T vh_e = from_upper_lane0(vh_p[0]);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       const T utw = (k == 0) ? ut_w : ut[k > 0 ? k - 1 : 0];
@@ -65,8 +65,8 @@ template <typename T, int VEC> struct CgLevel {
       Rm[k] = cB[0][k] * (vhe - vh_p[k]) + cB[1][k] * (uh[k] - uh_p[k]);
       Sm[k] = cB[2][k] * Rm[k];
     }
-    const T P_e = from_upper_lane(P_p[0]);
-    const T S_w = from_lower_lane(Sm[VEC - 1]);
+    const T P_e = from_upper_lane0(P_p[0]);
+    const T S_w = from_lower_lane0(Sm[VEC - 1]);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       const T pe = (k == VEC - 1) ? P_e : P_p[k < VEC - 1 ? k + 1 : k];
