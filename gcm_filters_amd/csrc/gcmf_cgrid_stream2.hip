@@ -13,6 +13,13 @@
 #include "gcmf_multi_common.hpp"
 #include <cstdlib>
 
+// Row-loop unroll factor: the per-level state of one iteration (previous-row stresses, the last two output rows, the fbar
+// pipeline) is handed to the next iteration by renaming inside an unrolled body instead of by register moves -- a third
+// of the rolled loop's VALU instructions were `v_mov` (792 VALU per row at S = 5, 283 of them moves).
+#ifndef GCMF_CG_UNROLL
+#define GCMF_CG_UNROLL 1
+#endif
+
 namespace gcmf {
 
 template <typename T, typename FB> struct CStream2P {
@@ -292,10 +299,17 @@ __global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) == 8 && (PRIV || S > 
   if (D == 1) {  // one row of operands in flight per wave; the other waves of the SIMD hide the rest of the latency
     Row nxt;
     load_row(nxt, r_begin);
-    for (int r = r_begin; r < r_end; ++r) {
-      Row now = nxt;
-      load_row(nxt, min(r + 1, r_end - 1));
-      step(now, r);
+    // unrolled by hand (a loop with a barrier is not unrolled by the compiler when its trip count is unknown); the march
+    // is padded to a whole number of bodies: the extra iterations re-load the last row and store nothing
+    constexpr int U = GCMF_CG_UNROLL;
+    const int r_pad = r_begin + (r_end - r_begin + U - 1) / U * U;
+    for (int r = r_begin; r < r_pad; r += U) {
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        Row now = nxt;
+        load_row(nxt, min(r + q + 1, r_end - 1));
+        step(now, r + q);
+      }
     }
   } else {  // two rows in flight
     Row q0, q1;
