@@ -91,30 +91,44 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
     for (int k = 0; k < VEC; ++k) G0[l][k] = T(0);
   }
 
-  // periodic wrap (|r| never leaves (-rows, 2 rows)) or clamp at a closed boundary; written as selects: a branch per row
-  // index costs this single-wave kernel more than the scalar arithmetic it would skip
+  // Row cursor: the rows are visited in sequence, so the (wrapped / clamped) row index of the row being loaded is kept
+  // incrementally in scalar registers -- periodic wrap, or clamp beyond a closed boundary (such rows are `outside`: no
+  // flux, no wet cells).  Written as selects: a branch per row costs this single-wave kernel more than the arithmetic.
   const bool wrap = P.wrap;
-  auto row_index = [&](int r, bool &outside) {
-    const bool lo = r < 0, hi = r >= rows;
-    const int jw = r + (lo ? rows : 0) - (hi ? rows : 0);
-    const int jc = lo ? 0 : (hi ? rows - 1 : r);
-    outside = !wrap && (lo || hi);
-    return wrap ? jw : jc;
-  };
   const int r_begin = a - S, r_last = b + S - 1;  // rows of T_{k-1} this strip needs: [a-S, b+S)
-  // addresses = a wave-uniform row pointer (scalar arithmetic) + this lane's column
-  auto load_u = [&](auto slot_c, int r) {  // row r of T_{k-1}
+  int cj, cj_prev;          // row index (in [0, rows)) of the next T_{k-1} row to load, and of the one before it
+  bool cout_, cout_prev;    // ... lies beyond a closed boundary
+  {
+    const int r = r_begin - 1;  // the centre operands of the first iteration belong to row r_begin - 1
+    const bool lo = r < 0, hi = r >= rows;
+    cj = wrap ? (r + (lo ? rows : 0) - (hi ? rows : 0)) : (lo ? 0 : (hi ? rows - 1 : r));
+    cout_ = !wrap && (lo || hi);
+    cj_prev = cj;
+    cout_prev = cout_;
+  }
+  int cr = r_begin - 1;     // unwrapped row of the cursor
+  auto advance = [&]() {    // cursor -> next row
+    cj_prev = cj;
+    cout_prev = cout_;
+    ++cr;
+    const int jn = cj + ((wrap || cr > 0) ? 1 : 0);
+    const bool hit = (jn >= rows);
+    cj = hit ? (wrap ? 0 : rows - 1) : jn;
+    cout_ = !wrap && (cr < 0 || cr >= rows);
+  };
+  // addresses = a wave-uniform row pointer (scalar arithmetic) + this lane's column.  Loads past the strip's last row are
+  // harmless (a valid row of the plane; what they feed is never stored), so the march needs no clamp of its own.
+  auto load_u = [&](auto slot_c) {  // the cursor's row of T_{k-1}
     constexpr int sl = decltype(slot_c)::value;
-    bool out_u;
-    const T *rowp = P.u0 + boff + (long long)row_index(min(r, r_last), out_u) * nx;
+    const T *rowp = P.u0 + boff + (long long)(cj * nx);
     mload<T, VEC>(G0[sl], rowp + col);
   };
-  // the centre-only operands that travel with row r of T_{k-1}: T_{k-2}, fbar, coefficients / mask bits of row r-1
-  auto load_centre = [&](auto slot_c, auto vslot_c, int r) {
+  // the centre-only operands that travel with that row: T_{k-2}, fbar, coefficients / mask bits of the row before it
+  auto load_centre = [&](auto slot_c, auto vslot_c) {
     constexpr int sl = decltype(slot_c)::value;
     constexpr int vs = decltype(vslot_c)::value;
-    bool out_c;
-    const long long rc = (long long)row_index(min(r, r_last) - 1, out_c) * nx;
+    const bool out_c = cout_prev;
+    const long long rc = (long long)(cj_prev * nx);
     if constexpr (FLUX) {  // beyond a closed boundary: no flux -- the coefficients come from a row of zeros
       const T *pE = out_c ? P.zrow : P.cE + rc;
       const T *pN = out_c ? P.zrow : P.cN + rc;
@@ -203,8 +217,9 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
   auto phase = [&](auto ph_c, int r) {
     constexpr int ph = decltype(ph_c)::value;
     // the operands of iteration + D; every slot they land in was released in the previous iteration at the latest
-    load_centre(ic<(ph + D) % R>{}, ic<(ph + D) % RV>{}, r + D);
-    load_u(ic<(ph + D) % RU>{}, r + D);
+    advance();
+    load_centre(ic<(ph + D) % R>{}, ic<(ph + D) % RV>{});
+    load_u(ic<(ph + D) % RU>{});
     if (SAN) {
 #pragma unroll
       for (int k = 0; k < VEC; ++k) bad = bad || !(mabs(G0[ph % RU][k]) <= MLim<T>::big());
@@ -242,12 +257,15 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
   };
 
   // ---- march north; the body covers one full period of every ring ----
-  load_centre(ic<0>{}, ic<0>{}, r_begin);
-  load_u(ic<0>{}, r_begin);
-  load_centre(ic<1>{}, ic<1>{}, r_begin + 1);
-  load_u(ic<1>{}, r_begin + 1);
-  load_centre(ic<2>{}, ic<2>{}, r_begin + 2);
-  load_u(ic<2>{}, r_begin + 2);
+  advance();  // cursor on r_begin
+  load_centre(ic<0>{}, ic<0>{});
+  load_u(ic<0>{});
+  advance();
+  load_centre(ic<1>{}, ic<1>{});
+  load_u(ic<1>{});
+  advance();
+  load_centre(ic<2>{}, ic<2>{});
+  load_u(ic<2>{});
   static_assert(D == 3, "prologue");
   const int niter = (r_last - r_begin + 1 + R - 1) / R * R;  // padded to whole periods: the extra rows store nothing
   bool dirty = false;
