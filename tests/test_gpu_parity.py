@@ -740,3 +740,32 @@ def test_plan_cache_never_serves_stale_coefficients(monkeypatch):
     assert rel_err(r2, O.filter_func(O.make_spec(4.0, 1.0), "REGULAR_WITH_LAND", f, {"wet_mask": base})) <= 1e-12
     K.clear_plan_cache()
     assert base.flags.writeable
+
+
+def test_regular_spreads_nan_like_the_reference():
+    """RegularLaplacian has no nan_to_num (upstream kernels.py:113-121): a NaN in the input spreads one cell per step in
+    the 5-point pattern (181 cells after 9 steps).  Blocked (k_ring / general) and single-step schedules."""
+    from gcm_filters_amd import _lib
+    shape = (96, 160)
+    f = T.random_field(shape, 3)
+    f[40, 70] = np.nan
+    flt9 = Filter(filter_scale=8.0, dx_min=1.0, grid_type=GridType.REGULAR)
+    assert flt9.n_steps == 9
+    fs = flt9.filter_spec
+    want = O.filter_func(O.FilterSpec(fs.n_steps, fs.s_max, np.asarray(fs.p), fs.dx_min_sq), "REGULAR", f, {})
+    assert np.isnan(want).sum() == 181
+    plan = ALL_KERNELS[GridType.REGULAR]()._plan(_lib.F64, shape)
+    try:
+        for ms in (1, 4, 8):
+            plan.set_tuning(multi_s=ms)
+            got = flt9.apply(f)
+            assert np.array_equal(np.isnan(got), np.isnan(want)), ms
+            assert np.array_equal(got, want, equal_nan=True), ms                  # REGULAR is bit-exact
+    finally:
+        plan.set_tuning(multi_s=8)
+    flt = Filter(filter_scale=8.0, dx_min=1.0, n_steps=21, grid_type=GridType.REGULAR)   # 8 + 8 (k_ring) + 5
+    fs = flt.filter_spec
+    want = O.filter_func(O.FilterSpec(fs.n_steps, fs.s_max, np.asarray(fs.p), fs.dx_min_sq), "REGULAR", f, {})
+    got = flt.apply(f)
+    assert "k_ring<double, double, 0, 8>" in plan.last_kernel() or "k_scalar_multi" in plan.last_kernel()
+    assert np.array_equal(got, want, equal_nan=True) and np.isnan(got).sum() == 2 * 21 * 22 + 1
