@@ -368,8 +368,15 @@ template <typename T, typename FB, int KIND> static int launch_ring_k(gcmf_plan 
 // one translation unit per stencil kind (compile time): the dtype dispatch
 template <int KIND> static int launch_ring_kind(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   if (pl->d.dtype == GCMF_F64) return launch_ring_k<double, double, KIND>(pl, a, s);
-  if (a.fb_is_f32) return launch_ring_k<float, float, KIND>(pl, a, s);
-  return launch_ring_k<float, double, KIND>(pl, a, s);
+  if constexpr (KIND == K_FLUX) {
+    // f32 state (four cells per lane, f64 fbar): the rings need 510 registers and the AGPR traffic of the f64 fbar ring
+    // makes the kernel slower than k_flux_multi2 (IRREGULAR 2400x3600 f32: 405 against 485 G) -- not instantiated
+    set_error("k_ring: the flux kinds run in f64 only");
+    return GCMF_ERR_UNSUPPORTED;
+  } else {
+    if (a.fb_is_f32) return launch_ring_k<float, float, KIND>(pl, a, s);
+    return launch_ring_k<float, double, KIND>(pl, a, s);
+  }
 }
 
 }  // namespace gcmf

@@ -32,7 +32,8 @@ bool multi_supported(const gcmf_plan *pl, int S) {
 bool ring_supported(const gcmf_plan *pl, const MultiArgs &a) {
   if (!pl->ring || !pl->zero_row || a.first || a.S < 5 || a.S > 8 || a.fb_in == a.fb_out) return false;
   if (pl->kind == K_MASK) return a.land_zero != 0;
-  return pl->kind == K_REG || pl->kind == K_FLUX;
+  if (pl->kind == K_FLUX) return pl->d.dtype == GCMF_F64;  // f32 flux: k_flux_multi2 is faster (see gcmf_ring_impl.hpp)
+  return pl->kind == K_REG;
 }
 
 int launch_scalar_multi(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {

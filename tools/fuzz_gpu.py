@@ -38,6 +38,15 @@ for it in range(ncase):
         fields = [np.where(gv["wet_mask"] == 0, np.nan, f) for f in fields]
     if grid == "IRREGULAR_WITH_LAND" and rng.random() < 0.5:
         gv["kappa_w"] = T.smooth_kappa(shape, int(rng.integers(100))) if min(shape) > 1 else gv["kappa_w"]
+    if ("--nanwet" in sys.argv or "--infwet" in sys.argv) and rng.random() < 0.6:
+        # a few NaN (--nanwet) / +-inf (--infwet) anywhere: the static-ring kernels' per-strip fallback.  nan_to_num turns inf
+        # into +-DBL_MAX and the stencil then overflows: where it does depends on the order of operations, so on the grid
+        # types whose coefficients are folded at plan time only the land-mask / regular kinds can be held to the NaN pattern
+        vals = [np.nan] if "--infwet" not in sys.argv else [np.nan, np.inf, -np.inf]
+        for f in fields:
+            flat = f.reshape(-1)
+            for _ in range(int(rng.integers(1, 4))):
+                flat[int(rng.integers(flat.size))] = rng.choice(vals)
     fields = [f.astype(dt) for f in fields]
     gv = {k: v.astype(dt) for k, v in gv.items()}
     dim = O.DIMENSIONAL[grid]
