@@ -260,14 +260,17 @@ def roofline_of(cfg, r, steps, default_tuning):
         return None
     balg = b_alg(grid, w, 8, nb)
     avg_ms = r["dom_ms"] / r["dom_n"]                       # HIP events around each launch of the dominant kernel
-    steps_per_launch = r["n_steps"] * r["dom_reps"] / r["dom_n"]
+    # recurrence steps one launch of that kernel advances: its last (vector kernels: fourth) template argument
+    targs = r["kernel"][r["kernel"].index("<") + 1: r["kernel"].rindex(">")].split(", ")
+    steps_per_launch = float(targs[3] if "stream2" in r["kernel"] or "k_scalar_multi" in r["kernel"] else
+                             (targs[-1] if ("k_ring" in r["kernel"] or "k_flux_multi2" in r["kernel"]) else 1))
     achieved = balg * r["cells"] * steps_per_launch / (avg_ms * 1e-3) / 1e9
     minb = min_bytes_per_cell_launch(grid, w, 8, nb) * r["cells"]
     rec, src = load_traffic(cfg, r["kernel"]) if default_tuning else (None, "non-default tuning: traffic withheld")
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "traffic": rec.get("bytes_per_launch") if rec else None, "traffic_source": src,
            "kernel": r["kernel"], "avg_launch_ms": avg_ms, "min_launch_ms": r["dom_min"], "max_launch_ms": r["dom_max"],
-           "launches_per_application": r["dom_n"] / r["dom_reps"], "steps_per_launch": steps_per_launch,
+           "launches_of_it_per_application": r["dom_n"] / r["dom_reps"], "steps_per_launch": steps_per_launch,
            "recurrence_ms_per_application": r["kernel_ms"] / steps,
            "alg_bytes_per_launch": balg * r["cells"] * steps_per_launch, "alg_bytes_per_cell_step": balg,
            "frac_note": "achieved/frac price every Laplacian step with SURVEY 8d's one-pass-per-step byte count; a blocked "

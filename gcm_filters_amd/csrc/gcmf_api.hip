@@ -124,15 +124,20 @@ static int dom_begin(gcmf_plan *pl, hipStream_t s) {
 static int dom_end(gcmf_plan *pl, hipStream_t s) {
   if (!pl->timing_detail) return GCMF_OK;
   GCMF_HIP(hipEventRecord(pl->dom_ev[pl->dom_used + 1], s));
+  pl->dom_name.resize(pl->dom_ev.size() / 2);
+  pl->dom_name[pl->dom_used / 2] = pl->last_launched;
   pl->dom_used += 2;
   return GCMF_OK;
 }
 static int dom_collect(gcmf_plan *pl) {
   pl->dom_ms = pl->dom_min = pl->dom_max = 0.f;
   pl->dom_n = 0;
+  // only the launches of the dominant kernel (the one gcmf_last_kernel reports): the first launch of a filter and the
+  // remainder launch run other instantiations
   for (int q = 0; q + 1 < pl->dom_used; q += 2) {
     float ms = 0.f;
     GCMF_HIP(hipEventSynchronize(pl->dom_ev[q + 1]));
+    if (!pl->last_kernel.empty() && pl->dom_name[q / 2] != pl->last_kernel) continue;
     GCMF_HIP(hipEventElapsedTime(&ms, pl->dom_ev[q], pl->dom_ev[q + 1]));
     pl->dom_ms += ms;
     pl->dom_min = pl->dom_n ? std::min(pl->dom_min, ms) : ms;

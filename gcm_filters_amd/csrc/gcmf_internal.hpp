@@ -132,6 +132,8 @@ struct gcmf_plan {
   // gcmf_set_timing(plan, 2): an event pair around every temporally blocked launch of gcmf_apply (the dominant kernel)
   bool timing_detail = false;
   std::vector<hipEvent_t> dom_ev;  // pairs
+  std::vector<std::string> dom_name;  // kernel each pair bracketed
+  std::string last_launched;          // name of the most recent recurrence kernel launch
   int dom_used = 0;
   float dom_ms = 0.f, dom_min = 0.f, dom_max = 0.f;
   int dom_n = 0;
@@ -168,6 +170,7 @@ namespace gcmf {
 template <typename T> inline const char *tyname() { return sizeof(T) == 8 ? "double" : "float"; }
 // name as rocprofv3 prints it (without "void " and the argument list); weight = recurrence steps per launch
 inline void note_kernel(gcmf_plan *pl, const std::string &name, int weight) {
+  pl->last_launched = name;
   if (weight >= pl->last_kernel_weight) {
     pl->last_kernel = name;
     pl->last_kernel_weight = weight;

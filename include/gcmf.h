@@ -245,7 +245,7 @@ int gcmf_prepare(gcmf_plan *plan, const void *const *in, void *const *out, int64
 int gcmf_last_timing(const gcmf_plan *plan, float *ms_total, int *n_launches);
 /* Enable/disable event timing inside gcmf_apply (adds two hipEventRecord per call).  enabled = 2: additionally one event
  * pair around every temporally blocked launch (the dominant kernel), read back with gcmf_last_kernel_timing: sum, count,
- * shortest and longest of those launches in the last gcmf_apply (device-resident calls, up to 32768 batch entries). */
+ * shortest and longest of the launches of the dominant kernel (gcmf_last_kernel) in the last gcmf_apply (device-resident calls, up to 32768 batch entries). */
 int gcmf_set_timing(gcmf_plan *plan, int enabled);
 int gcmf_last_kernel_timing(const gcmf_plan *plan, float *ms_sum, int *n_launches, float *ms_min, float *ms_max);
 /* Name (as rocprofv3 prints it, without "void " and the argument list) of the recurrence kernel that advanced the most
