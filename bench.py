@@ -407,7 +407,8 @@ def main_single(args):
     out = {
         "metric": "grid-cells*Laplacian-steps/sec", "value": value, "unit": "cell-steps/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * r["elapsed"] / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        # N = 1 is the first point of the strong-scaling curve `--gpus N` reports (same global grid at every N)
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f64" if r["itemsize"] == 8 else "f32", "data": "synthetic",
         "config": {"workload": workload_name(args.config, r, args),
                    "filter": f"{fk['filter_shape']} filter_scale={fk['filter_scale']:.6g} dx_min={fk['dx_min']:.6g}",
