@@ -222,7 +222,7 @@ def run_single(cfg, args, dev, steps, warmup, scale=0.0, levels=None, tuned=Fals
     plan = lap._plan(_lib.F64 if itemsize == 8 else _lib.F32, (args.ny, args.nx), dev.index)
     if tuned:
         plan.set_tuning(args.rows_per_wave, args.xcd_remap, args.multi or 8, args.strip, args.prefetch)
-    plan.set_timing(True)
+    plan.set_timing(False)
     d_in = [torch.from_numpy(f).to(dev) for f in wl["fields"]]
     run = (lambda: flt.apply_to_vector(d_in[0], d_in[1])) if len(d_in) == 2 else (lambda: (flt.apply(d_in[0]),))
     outs = None
@@ -230,25 +230,26 @@ def run_single(cfg, args, dev, steps, warmup, scale=0.0, levels=None, tuned=Fals
         outs = run()
     plan.last_kernel()  # reset
     torch.cuda.synchronize()
+    # the timed region: K applications enqueued back to back, no host synchronisation inside (event timing is OFF: reading
+    # an event back after every application would idle the GPU while the host prepares the next one)
     t0 = time.perf_counter()
-    kernel_ms, launches = 0.0, 0
     for _ in range(steps):
         outs = run()
-        ms, nl = plan.last_timing()  # hipEvents recorded inside gcmf_apply on the stream the kernels ran on
-        kernel_ms += ms
-        launches += nl
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    # the dominant kernel's own launch durations: a second, untimed pass with an event pair around every blocked launch
-    # (on the stream the kernel runs on); kept out of the timed region so that `value` is not perturbed
+    # kernel-level timing in a second, untimed pass: an event pair around the whole recurrence and one around every
+    # launch of the dominant kernel, recorded on the stream the kernels run on
     plan.set_timing(2)
     dom_ms, dom_n, dom_min, dom_max = 0.0, 0, 1e30, 0.0
-    for _ in range(max(1, min(steps, 3))):
+    kernel_ms, launches = 0.0, 0
+    dom_reps = max(1, min(steps, 3))
+    for _ in range(dom_reps):
         run()
+        ms, nl = plan.last_timing()
+        kernel_ms, launches = kernel_ms + ms, launches + nl
         ms, nl, lo, hi = plan.last_kernel_timing()
         dom_ms, dom_n, dom_min, dom_max = dom_ms + ms, dom_n + nl, min(dom_min, lo), max(dom_max, hi)
-    dom_reps = max(1, min(steps, 3))
-    plan.set_timing(1)
+    plan.set_timing(False)
     return dict(dom_ms=dom_ms, dom_n=dom_n, dom_min=dom_min, dom_max=dom_max, dom_reps=dom_reps, wl=wl, grid=grid, fk=fk, itemsize=itemsize, nbatch=nbatch, n_steps=n_steps, elapsed=elapsed,
                 kernel_ms=kernel_ms, launches=launches, outs=list(outs), kernel=plan.last_kernel(), flt=flt, d_in=d_in,
                 cells=args.ny * args.nx * nbatch)
@@ -271,7 +272,7 @@ def roofline_of(cfg, r, steps, default_tuning):
            "traffic": rec.get("bytes_per_launch") if rec else None, "traffic_source": src,
            "kernel": r["kernel"], "avg_launch_ms": avg_ms, "min_launch_ms": r["dom_min"], "max_launch_ms": r["dom_max"],
            "launches_of_it_per_application": r["dom_n"] / r["dom_reps"], "steps_per_launch": steps_per_launch,
-           "recurrence_ms_per_application": r["kernel_ms"] / steps,
+           "recurrence_ms_per_application": r["kernel_ms"] / r["dom_reps"],
            "alg_bytes_per_launch": balg * r["cells"] * steps_per_launch, "alg_bytes_per_cell_step": balg,
            "frac_note": "achieved/frac price every Laplacian step with SURVEY 8d's one-pass-per-step byte count; a blocked "
                         "launch advances steps_per_launch steps per pass over HBM, so frac > 1 is possible and is NOT a "
@@ -360,8 +361,8 @@ def self_launch(args):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config number (2..5), default 3")
     ap.add_argument("--ny", type=int, default=2400)
     ap.add_argument("--nx", type=int, default=3600)
