@@ -16,8 +16,9 @@
 //     carried in a register per level instead of being recomputed (2 of 13 f64 operations per cell and level, and the
 //     second lag of the north-face coefficients).
 //   * NO NaN / inf BOOKKEEPING on this path.  nan_to_num is the identity on finite data, so the fast march only
-//     watches for a non-finite value (one compare per produced value, OR-ed into a wave mask, tested once per unrolled
-//     body); a wave that sees one abandons its strip and redoes it with the general march of k_flux_multi2 /
+//     watches for a non-finite value (one compare per cell of the LAST level -- a NaN / inf never becomes finite again on
+//     this path, so every one that could reach a stored cell ends up there -- OR-ed into a wave mask, tested once per
+//     unrolled body); a wave that sees one abandons its strip and redoes it with the general march of k_flux_multi2 /
 //     k_scalar_multi, whose results then overwrite whatever the fast march stored (so fbar must not be accumulated in
 //     place).  gcmf_apply keeps land out of the state after its first launch (k_zero_land), so ocean fields with NaN
 //     on land stay on the fast path.  K_REG has no nan_to_num in the reference (NaN spreads): no check, no fallback.
@@ -204,12 +205,16 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
       const T x2 = (t == 1) ? V[ph % RV][k] : (t == 2 ? G0[pmod(ph - 2, RU)][k] : G[t >= 3 ? t - 2 : 1][sC][k]);
       const T tk = cheb_t<FUSED>(av, x2);
       F[sl][k] = cheb_acc<FUSED, T, FB>(F[sl][k], P.pk[t - 1], tk);
-      if (t < S) {
-        G[t < S ? t : 0][sC][k] = tk;
+      if (t < S) G[t < S ? t : 0][sC][k] = tk;
+      if (t == S - 1) out_v[k] = tk;
+      if (t == S) {
+        out_u[k] = tk;
+        // A non-finite value never becomes finite again on this path: "-x" carries it to the same cell of the next level
+        // (and T_{k-2} to the one after), the stencil spreads it to the neighbours.  So whatever NaN / inf could reach a
+        // stored cell -- from T_{k-1}, T_{k-2} or any level -- shows up in level S of that cell: one test per cell
+        // and row instead of one per cell, row and level.
         if (SAN) bad = bad || !(mabs(tk) <= MLim<T>::big());
       }
-      if (t == S - 1) out_v[k] = tk;
-      if (t == S) out_u[k] = tk;
     }
   };
 
@@ -220,10 +225,6 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
     advance();
     load_centre(ic<(ph + D) % R>{}, ic<(ph + D) % RV>{});
     load_u(ic<(ph + D) % RU>{});
-    if (SAN) {
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) bad = bad || !(mabs(G0[ph % RU][k]) <= MLim<T>::big());
-    }
     level(ic<1>{}, ph_c);
     if constexpr (S >= 2) level(ic<2>{}, ph_c);
     if constexpr (S >= 3) level(ic<3>{}, ph_c);
