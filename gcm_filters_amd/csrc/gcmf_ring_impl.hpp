@@ -43,6 +43,14 @@ struct RingGeom {
   static constexpr int RV = 4;  // ring of the T_{k-2} rows: 1 live (level 1) + D in flight
 };
 
+// (scalar row pointer) + (32-bit byte offset of the lane): the form the global_load `saddr` addressing mode takes
+template <typename X> __device__ __forceinline__ const X *lane_ptr(const X *rowp, unsigned bytes) {
+  return reinterpret_cast<const X *>(reinterpret_cast<const char *>(rowp) + bytes);
+}
+template <typename X> __device__ __forceinline__ X *lane_ptr(X *rowp, unsigned bytes) {
+  return reinterpret_cast<X *>(reinterpret_cast<char *>(rowp) + bytes);
+}
+
 template <typename T, typename FB, int KIND, int S>
 __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
   constexpr int VEC = 16 / sizeof(T);
@@ -67,8 +75,11 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
   const int b = min(a + P.H, P.out_hi);
   const long long boff = (long long)blockIdx.y * P.bstride;
   const int pos = wx * WI - M + lane * VEC;
-  int col = pos % nx;
-  if (col < 0) col += nx;
+  int col_s = pos % nx;
+  if (col_s < 0) col_s += nx;
+  // unsigned: a zero-extended 32-bit lane offset lets the loads take (scalar row pointer + vector offset) addressing
+  const unsigned col = (unsigned)col_s;
+  const unsigned colT = col * (unsigned)sizeof(T), colF = col * (unsigned)sizeof(FB);  // byte offsets of the lane's first cell
   const bool keep = (lane * VEC >= M) && (lane * VEC < W - M) && (pos < nx);
   const T c = (T)P.c;
   const bool last = P.last;
@@ -122,7 +133,7 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
   auto load_u = [&](auto slot_c) {  // the cursor's row of T_{k-1}
     constexpr int sl = decltype(slot_c)::value;
     const T *rowp = P.u0 + boff + (long long)(cj * nx);
-    mload<T, VEC>(G0[sl], rowp + col);
+    mload<T, VEC>(G0[sl], lane_ptr(rowp, colT));
   };
   // the centre-only operands that travel with that row: T_{k-2}, fbar, coefficients / mask bits of the row before it
   auto load_centre = [&](auto slot_c, auto vslot_c) {
@@ -134,19 +145,19 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
       const T *pE = out_c ? P.zrow : P.cE + rc;
       const T *pN = out_c ? P.zrow : P.cN + rc;
       const T *pA = out_c ? P.zrow : P.ra + rc;
-      mload<T, VEC>(cE[sl], pE + col);
-      mload<T, VEC>(cN[sl], pN + col);
-      mload<T, VEC>(ra[sl], pA + col);
+      mload<T, VEC>(cE[sl], lane_ptr(pE, colT));
+      mload<T, VEC>(cN[sl], lane_ptr(pN, colT));
+      mload<T, VEC>(ra[sl], lane_ptr(pA, colT));
     }
     if constexpr (MASK) {  // beyond a closed boundary: land (bits 0)
-      const uint8_t *mp = (out_c ? (const uint8_t *)P.zrow : P.mbits + rc) + col;
+      const uint8_t *mp = lane_ptr(out_c ? (const uint8_t *)P.zrow : P.mbits + rc, col);
       if (VEC == 2) B[sl] = *reinterpret_cast<const unsigned short *>(mp);
       else B[sl] = *reinterpret_cast<const unsigned *>(mp);
     }
     const FB *pF = P.fb_in + boff + rc;
     const T *pV = P.v0 + boff + rc;
-    mload<FB, VEC>(F[sl], pF + col);
-    mload<T, VEC>(V[vs], pV + col);
+    mload<FB, VEC>(F[sl], lane_ptr(pF, colF));
+    mload<T, VEC>(V[vs], lane_ptr(pV, colT));
   };
 
   bool bad = false;         // this lane met a non-finite value (input row or a produced level)
@@ -240,20 +251,20 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
       if (keep) {
         constexpr int fs = pmod(ph - S + 1, R);
         if (!last) {
-          mstore<T, VEC>(P.uo + off + col, out_u);
+          mstore<T, VEC>(lane_ptr(P.uo + off, colT), out_u);
         } else if (!FLUX && P.area_weighted) {  // finalize(): / area (kernels.py:103-104)
           T ar[VEC];
-          mload<T, VEC>(ar, P.area + (long long)ju * nx + col);
+          mload<T, VEC>(ar, lane_ptr(P.area + (long long)ju * nx, colT));
 #pragma unroll
           for (int k = 0; k < VEC; ++k) F[fs][k] = F[fs][k] / (FB)ar[k];
         }
-        mstore<FB, VEC>(P.fb_out + off + col, F[fs]);
+        mstore<FB, VEC>(lane_ptr(P.fb_out + off, colF), F[fs]);
       }
     }
     const int jv = r - S + 1;
     if (!last && jv >= a && jv < b) {
       T *rowp = P.vo + boff + (long long)jv * nx;
-      if (keep) mstore<T, VEC>(rowp + col, out_v);
+      if (keep) mstore<T, VEC>(lane_ptr(rowp, colT), out_v);
     }
   };
 
