@@ -286,9 +286,11 @@ def roofline_of(cfg, r, steps, default_tuning):
         out["hbm_frac"] = gbs / HBM_PEAK_GBS                      # counter bytes / this run's launch time / 8 TB/s
         out["hbm_frac_of_copy_ceiling"] = gbs / HBM_COPY_GBS
         out["traffic_over_min_bytes"] = rec["bytes_per_launch"] / minb
-        for k in ("bound", "valu_active_frac", "valu_arith_share", "counters_source"):
+        # SQ-counter view of the same kernel (profiles/): how the wave cycles split; `bound` stays the contract's enum
+        for k in ("bound", "valu_active_frac", "salu_active_frac", "wait_memory_frac", "wait_issue_frac", "valu_arith_share",
+                  "counters_source"):
             if k in rec:
-                out["bound" if k == "bound" else k] = rec[k]
+                out["bound_detail" if k == "bound" else k] = rec[k]
     return out
 
 
