@@ -22,14 +22,14 @@ ERR_KAPPA_W_GT1, ERR_KAPPA_S_GT1, ERR_KAPPA_NONE_ONE = 16, 17, 18
 ERR_WET_SOUTH_ROW, ERR_DXN_FOLD, ERR_DYN_FOLD = 19, 20, 21
 F32, F64 = 0, 1
 DEVICE_PTRS, OUT_F32 = 0x1, 0x2
-STEP_FIRST, STEP_LAST, STEP_LAND_ZERO = 0x1, 0x2, 0x4
+STEP_FIRST, STEP_LAST, STEP_LAND_ZERO, STEP_LAND_FIXED = 0x1, 0x2, 0x4, 0x8
 
 EXPORTS = [
     "gcmf_plan_create", "gcmf_plan_destroy", "gcmf_grid_nplanes", "gcmf_grid_ncomp", "gcmf_grid_is_dimensional",
     "gcmf_grid_is_tripolar", "gcmf_plan_rows", "gcmf_apply", "gcmf_laplacian", "gcmf_cheb_step", "gcmf_prepare",
     "gcmf_last_timing", "gcmf_set_timing", "gcmf_set_tuning", "gcmf_last_error", "gcmf_version",
     "gcmf_multi_supported", "gcmf_cheb_multi", "gcmf_multi_supported_vec", "gcmf_cheb_multi_vec",
-    "gcmf_has_land", "gcmf_zero_land", "gcmf_land_fix", "gcmf_last_kernel", "gcmf_last_kernel_timing",
+    "gcmf_has_land", "gcmf_zero_land", "gcmf_land_fix", "gcmf_last_kernel", "gcmf_last_kernel_timing", "gcmf_ring_fallbacks",
     "gcmf_comm_unique_id", "gcmf_comm_create", "gcmf_comm_destroy", "gcmf_halo_start", "gcmf_halo_finish",
 ]
 PLAN_SELF_RING, PLAN_SKIP_KAPPA_ONE = 0x1, 0x2
@@ -115,6 +115,8 @@ def load() -> C.CDLL:
         lib.gcmf_last_kernel_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float),
                                                 C.POINTER(C.c_float)]
         lib.gcmf_last_kernel_timing.restype = C.c_int
+        lib.gcmf_ring_fallbacks.argtypes = [vp, C.POINTER(C.c_int64)]
+        lib.gcmf_ring_fallbacks.restype = C.c_int
         lib.gcmf_last_kernel.argtypes = [vp, C.c_char_p, C.c_int]
         lib.gcmf_last_kernel.restype = C.c_int
         lib.gcmf_set_timing.argtypes = [vp, C.c_int]
@@ -281,6 +283,12 @@ class Plan:
         ms, n = C.c_float(), C.c_int()
         check(load().gcmf_last_timing(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def ring_fallbacks(self) -> int:
+        """Wave strips the k_ring kernels handed to the general kernel (NaN / inf met) since the last call; synchronises."""
+        n = C.c_int64()
+        check(load().gcmf_ring_fallbacks(self._h, C.byref(n)))
+        return n.value
 
     def last_kernel(self) -> str:
         buf = C.create_string_buffer(256)

@@ -435,10 +435,11 @@ int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int 
   if (rc == GCMF_OK) rc = precompute(pl, dplanes.data(), desc->planes_on_device ? nullptr : planes);
   if (rc == GCMF_OK && pl->ncomp == 1) {  // a row of zeros for k_ring
     void *z = nullptr;
-    const size_t zb = ((size_t)desc->nx + 64) * 8;
+    const size_t zb = ((size_t)desc->nx + 64) * 8 + 256;
     if (hipMalloc(&z, zb) == hipSuccess && hipMemsetAsync(z, 0, zb, pl->stream) == hipSuccess) {
       pl->owned.push_back(z);
       pl->zero_row = z;
+      pl->ring_nfb = reinterpret_cast<unsigned *>((char *)z + zb - 8);  // beyond anything a (padded) row read touches
     } else if (z) {
       (void)hipFree(z);
     }
@@ -487,6 +488,17 @@ int gcmf_last_kernel(gcmf_plan *pl, char *buf, int n) {
   snprintf(buf, (size_t)n, "%s", pl->last_kernel.c_str());
   pl->last_kernel.clear();
   pl->last_kernel_weight = 0;
+  return GCMF_OK;
+}
+int gcmf_ring_fallbacks(gcmf_plan *pl, int64_t *count) {
+  if (!pl || !count) return GCMF_ERR_INVALID_ARG;
+  *count = 0;
+  if (!pl->ring_nfb) return GCMF_OK;
+  unsigned n = 0;
+  GCMF_HIP(hipDeviceSynchronize());
+  GCMF_HIP(hipMemcpy(&n, pl->ring_nfb, sizeof n, hipMemcpyDeviceToHost));
+  GCMF_HIP(hipMemset(pl->ring_nfb, 0, sizeof n));
+  *count = n;
   return GCMF_OK;
 }
 int gcmf_set_tuning(gcmf_plan *pl, int rows_per_wave, int xcd_remap, int multi_s) {
@@ -566,6 +578,7 @@ int gcmf_cheb_multi(gcmf_plan *pl, const void *u, const void *v, void *uo, void 
   m.fb_is_f32 = (pl->d.dtype == GCMF_F32) && (flags & GCMF_OUT_F32);
   m.nbatch = nbatch; m.row_lo = (int)row_lo; m.row_hi = (int)row_hi;
   m.land_zero = (mode & GCMF_STEP_LAND_ZERO) ? 1 : 0;
+  m.ring_first = (first && !last && (mode & GCMF_STEP_LAND_FIXED)) ? 1 : 0;
   return advance_multi(pl, m, (hipStream_t)stream, nullptr);
 }
 
@@ -759,6 +772,8 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
           std::swap(Fcur, Fnext);
           m.first = (k == 1); m.last = is_last; m.S = S; m.fb_is_f32 = fb32;
           m.land_zero = land_zeroed ? 1 : 0;
+          // the first launch may drop land on load if k_land_fix restores it at the end (not for a one-launch filter)
+          m.ring_first = (k == 1 && !is_last && (zero_land || pl->n_land == 0)) ? 1 : 0;
 
           for (int t = 0; t < S; ++t) m.pk[t] = p[k + t];
           m.p0 = p[0]; m.c = c; m.nbatch = nbatch; m.row_lo = 0; m.row_hi = rows;
@@ -766,7 +781,9 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
           --launches;  // counted once more below
           u = fr[0]; v = fr[1];
           if (k == 1 && zero_land && !is_last) {  // keep the isolated cells out of the state from here on
-            if ((rc = launch_zero_land(pl, fr[0], fr[1], nbatch, s))) return rc;
+            // (a first launch by k_ring already took them as zero while it loaded the field -- except in the rows of a tripole
+            // band, which single steps advance from the raw field)
+            if ((!ring_supported(pl, m) || pl->g.fold) && (rc = launch_zero_land(pl, fr[0], fr[1], nbatch, s))) return rc;
             land_zeroed = true;
           }
         } else {

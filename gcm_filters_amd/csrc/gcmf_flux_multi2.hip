@@ -33,6 +33,8 @@ template <typename T, typename FB, int S> static int launch_f2(gcmf_plan *pl, co
   P.cN = (const T *)g.coef[1];
   P.ra = (const T *)g.coef[2];
   P.zrow = nullptr;
+  P.lbits = nullptr;
+  P.nfb = nullptr;
   P.mbits = nullptr;
   P.area = nullptr;
   P.nx = g.nx;

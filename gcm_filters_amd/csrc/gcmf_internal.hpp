@@ -80,6 +80,8 @@ struct MultiArgs {
   int64_t nbatch;
   int row_lo, row_hi;
   int land_zero;  // the caller guarantees that isolated (land) cells of u0 and v0 are zero: GCMF_STEP_LAND_ZERO
+  int ring_first; // first launch: the caller will overwrite the result of the isolated (land) cells (k_land_fix) or there are
+                  // none, so the launch may take them as zero while it loads the field (k_ring<..., FIRST>)
 };
 
 // Arguments of one S-step vector launch (gcmf_cgrid_stream2.hip / gcmf_bgrid_stream2.hip): T_{k-1}, T_{k-2} -> T_{k+S-2}, T_{k+S-1}.
@@ -158,6 +160,7 @@ struct gcmf_plan {
   int64_t n_land = 0;
   int zero_land = 1;      // env GCMF_ZERO_LAND=0 turns it off
   int ring = 1;           // env GCMF_RING=0: deep launches stay with k_flux_multi2 / k_scalar_multi
+  unsigned *ring_nfb = nullptr;    // device counter behind gcmf_ring_fallbacks (lives behind zero_row)
   const void *zero_row = nullptr;  // nx zeros: what rows beyond a closed boundary read as coefficients / mask bits (k_ring)
   int band_rpw = 0;       // rows per wave of the tripole band steps (0 = default)
   double *dev_p = nullptr;   // p[0..n_steps] of the last filter, for k_land_fix

@@ -51,7 +51,7 @@ template <typename X> __device__ __forceinline__ X *lane_ptr(X *rowp, unsigned b
   return reinterpret_cast<X *>(reinterpret_cast<char *>(rowp) + bytes);
 }
 
-template <typename T, typename FB, int KIND, int S>
+template <typename T, typename FB, int KIND, int S, bool FIRST>
 __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int W = 64 * VEC;
@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
   unsigned B[R];     // K_MASKZ: mask bytes of the lane's cells (bit 0 wet, bits 5-7 wet-neighbour count), same slots
   FB F[R][VEC];      // fbar rows, same slots
   T V[RV][VEC];      // T_{k-2} rows, slot = (row + 1 - r_begin) mod RV
+  unsigned Z[RU];    // FIRST: the "exchanges with a neighbour" bytes of the input rows (same slots as G0)
 #pragma unroll
   for (int t = 0; t < S; ++t) {
 #pragma unroll
@@ -101,6 +102,25 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
   for (int l = 0; l < RU; ++l) {
 #pragma unroll
     for (int k = 0; k < VEC; ++k) G0[l][k] = T(0);
+    Z[l] = 0u;
+  }
+  // The first S iterations run their upper levels on ring slots no load has filled yet.  What they produce is never stored,
+  // but the NaN watch sees it: registers start with whatever the previous kernel on this SIMD left in them, and 0 x (a stale
+  // NaN taken as a coefficient) would send a clean strip to the general march.  (Measured: every strip of the first launch
+  // after a kernel that had NaNs in flight.)  Zeros cost ~100 moves per wave, once.
+#pragma unroll
+  for (int l = 0; l < R; ++l) {
+    B[l] = 0u;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      cE[l][k] = cN[l][k] = ra[l][k] = T(0);
+      F[l][k] = FB(0);
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < RV; ++l) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) V[l][k] = T(0);
   }
 
   // Row cursor: the rows are visited in sequence, so the (wrapped / clamped) row index of the row being loaded is kept
@@ -128,12 +148,21 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
     cj = hit ? (wrap ? 0 : rows - 1) : jn;
     cout_ = !wrap && (cr < 0 || cr >= rows);
   };
+  const bool has_land = FIRST && P.lbits != nullptr;
+  const uint8_t *zbase = has_land ? P.lbits : reinterpret_cast<const uint8_t *>(P.u0);  // (bytes of a valid plane, ignored)
   // addresses = a wave-uniform row pointer (scalar arithmetic) + this lane's column.  Loads past the strip's last row are
   // harmless (a valid row of the plane; what they feed is never stored), so the march needs no clamp of its own.
   auto load_u = [&](auto slot_c) {  // the cursor's row of T_{k-1}
     constexpr int sl = decltype(slot_c)::value;
     const T *rowp = P.u0 + boff + (long long)(cj * nx);
     mload<T, VEC>(G0[sl], lane_ptr(rowp, colT));
+    if constexpr (FIRST) {  // the caller's field: land leaves the state as it is loaded (see `phase`)
+      // unconditional load (a plan without land reads the field's own bytes and ignores them): a load under a wave-uniform
+      // `if` has produced mis-timed waits in this code base before (compiler notes)
+      const uint8_t *zp = lane_ptr(zbase + (long long)(cj * nx), col);
+      if (VEC == 2) Z[sl] = *reinterpret_cast<const unsigned short *>(zp);
+      else Z[sl] = *reinterpret_cast<const unsigned *>(zp);
+    }
   };
   // the centre-only operands that travel with that row: T_{k-2}, fbar, coefficients / mask bits of the row before it
   auto load_centre = [&](auto slot_c, auto vslot_c) {
@@ -154,10 +183,12 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
       if (VEC == 2) B[sl] = *reinterpret_cast<const unsigned short *>(mp);
       else B[sl] = *reinterpret_cast<const unsigned *>(mp);
     }
-    const FB *pF = P.fb_in + boff + rc;
-    const T *pV = P.v0 + boff + rc;
-    mload<FB, VEC>(F[sl], lane_ptr(pF, colF));
-    mload<T, VEC>(V[vs], lane_ptr(pV, colT));
+    if constexpr (!FIRST) {  // the first launch of a filter has no T_{k-2} and no fbar yet
+      const FB *pF = P.fb_in + boff + rc;
+      const T *pV = P.v0 + boff + rc;
+      mload<FB, VEC>(F[sl], lane_ptr(pF, colF));
+      mload<T, VEC>(V[vs], lane_ptr(pV, colT));
+    }
   };
 
   bool bad = false;         // this lane met a non-finite value (input row or a produced level)
@@ -213,9 +244,15 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
         }
       }
       const T av = cheb_a<FUSED>(xC, c, L);
-      const T x2 = (t == 1) ? V[ph % RV][k] : (t == 2 ? G0[pmod(ph - 2, RU)][k] : G[t >= 3 ? t - 2 : 1][sC][k]);
-      const T tk = cheb_t<FUSED>(av, x2);
-      F[sl][k] = cheb_acc<FUSED, T, FB>(F[sl][k], P.pk[t - 1], tk);
+      T tk;
+      if constexpr (FIRST && t == 1) {  // T_1 = A(T_0), fbar = p_0 T_0 + p_1 T_1 (filter.py:192-199)
+        tk = av;
+        F[sl][k] = cheb_acc_first<FUSED, T, FB>(P.p0, P.pk[0], xC, av);
+      } else {
+        const T x2 = (t == 1) ? V[ph % RV][k] : (t == 2 ? G0[pmod(ph - 2, RU)][k] : G[t >= 3 ? t - 2 : 1][sC][k]);
+        tk = cheb_t<FUSED>(av, x2);
+        F[sl][k] = cheb_acc<FUSED, T, FB>(F[sl][k], P.pk[t - 1], tk);
+      }
       if (t < S) G[t < S ? t : 0][sC][k] = tk;
       if (t == S - 1) out_v[k] = tk;
       if (t == S) {
@@ -236,6 +273,14 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
     advance();
     load_centre(ic<(ph + D) % R>{}, ic<(ph + D) % RV>{});
     load_u(ic<(ph + D) % RU>{});
+    if constexpr (FIRST) {
+      // Land out of the state from the start: a cell that exchanges nothing with its neighbours (land under a wet mask, a
+      // flux-form cell with four closed faces) is taken as zero -- it has L = 0 and evolves on its own; k_land_fix writes
+      // its polynomial into the result at the end.  NaN on land therefore never enters this kernel.
+#pragma unroll
+      for (int k = 0; k < VEC; ++k)
+        G0[ph % RU][k] = (!has_land || ((Z[ph % RU] >> (8 * k)) & 1u)) ? G0[ph % RU][k] : T(0);
+    }
     level(ic<1>{}, ph_c);
     if constexpr (S >= 2) level(ic<2>{}, ph_c);
     if constexpr (S >= 3) level(ic<3>{}, ph_c);
@@ -302,13 +347,35 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
   }
   if constexpr (SAN) {
     if (dirty) {
+      if (P.nfb && (threadIdx.x & 63) == 0) atomicAdd(P.nfb, 1u);  // instrumentation: gcmf_ring_fallbacks
+      // the general march reads P.first itself; a first launch still has land in its input: K_MASK, not K_MASKZ
       if constexpr (FLUX) flux_multi2_march<T, FB, S>(P);
-      else scalar_multi_march<T, FB, KIND, S, 1>(P);
+      else scalar_multi_march<T, FB, (FIRST ? K_MASK : KIND), S, 1>(P);
+      if constexpr (FIRST) {
+        // the general march carries land through the recurrence; the launches that follow were promised states whose
+        // isolated cells are zero (the fast march above took them as zero, gcmf_apply then skips k_zero_land): zero them
+        // in the two states of this strip (same lanes, same cells as the stores of the march: program order holds)
+        if (P.lbits && !last && keep) {
+          for (int j = a; j < b; ++j) {
+            const long long off = boff + (long long)j * nx;
+            const uint8_t *zp = lane_ptr(P.lbits + (long long)j * nx, col);
+            const unsigned zb = (VEC == 2) ? (unsigned)*reinterpret_cast<const unsigned short *>(zp)
+                                           : *reinterpret_cast<const unsigned *>(zp);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k)
+              if (!((zb >> (8 * k)) & 1u)) {
+                lane_ptr(P.uo + off, colT)[k] = T(0);
+                lane_ptr(P.vo + off, colT)[k] = T(0);
+              }
+          }
+        }
+      }
     }
   }
 }
 
-template <typename T, typename FB, int KIND, int S> static int launch_ring_s(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
+template <typename T, typename FB, int KIND, int S, bool FIRST>
+static int launch_ring_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int W = 64 * VEC;
   constexpr int M = (S + VEC - 1) / VEC * VEC;
@@ -326,7 +393,9 @@ template <typename T, typename FB, int KIND, int S> static int launch_ring_s(gcm
   P.cN = (const T *)g.coef[1];
   P.ra = (const T *)g.coef[2];
   P.zrow = (const T *)pl->zero_row;
+  P.nfb = pl->ring_nfb;
   P.mbits = g.mbits;
+  P.lbits = (FIRST && pl->n_land > 0) ? pl->lbits : nullptr;
   P.area = (const T *)g.area;
   P.nx = g.nx;
   P.rows = g.rows;
@@ -352,7 +421,7 @@ template <typename T, typename FB, int KIND, int S> static int launch_ring_s(gcm
   P.nstrips = (nrows + H - 1) / H;
   P.nwaves = P.nwx * P.nstrips;
   P.wrap = g.south_wrap && g.north_wrap;
-  P.first = 0;
+  P.first = FIRST ? 1 : 0;
   P.last = a.last;
   P.area_weighted = (KIND == K_FLUX) ? 0 : g.area_weighted;
   P.bstride = (long long)g.rows * g.nx;
@@ -360,11 +429,15 @@ template <typename T, typename FB, int KIND, int S> static int launch_ring_s(gcm
   P.p0 = a.p0;
   P.c = a.c;
   dim3 block(256), grid((P.nwaves + 3) / 4, (unsigned)a.nbatch);
-  hipLaunchKernelGGL((k_ring<T, FB, KIND, S>), grid, block, 0, s, P);
+  hipLaunchKernelGGL((k_ring<T, FB, KIND, S, FIRST>), grid, block, 0, s, P);
   GCMF_HIP(hipGetLastError());
   note_kernel(pl, std::string("gcmf::k_ring<") + tyname<T>() + ", " + tyname<FB>() + ", " + std::to_string(KIND) + ", " +
-                      std::to_string(S) + ">", S);
+                      std::to_string(S) + ", " + (FIRST ? "true" : "false") + ">", S);
   return GCMF_OK;
+}
+
+template <typename T, typename FB, int KIND, int S> static int launch_ring_s(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
+  return a.first ? launch_ring_sf<T, FB, KIND, S, true>(pl, a, s) : launch_ring_sf<T, FB, KIND, S, false>(pl, a, s);
 }
 
 template <typename T, typename FB, int KIND> static int launch_ring_k(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {

@@ -30,8 +30,17 @@ bool multi_supported(const gcmf_plan *pl, int S) {
 // the state, a row of zeros at hand for closed boundaries, and fbar NOT accumulated in place: a strip that meets a NaN /
 // inf is redone from its inputs, which its own stores must not have touched
 bool ring_supported(const gcmf_plan *pl, const MultiArgs &a) {
-  if (!pl->ring || !pl->zero_row || a.first || a.S < 5 || a.S > 8 || a.fb_in == a.fb_out) return false;
-  if (pl->kind == K_MASK) return a.land_zero != 0;
+  if (!pl->ring || !pl->zero_row || a.S < 5 || a.S > 8 || a.fb_in == a.fb_out) return false;
+  if (a.first) {
+    // the first launch of a filter: prepare() is not fused here (area-weighted types keep the general kernel), and land is
+    // zeroed as it is loaded (the caller says it will fix those cells up: ring_first), which needs the plan's byte plane
+    if (!a.ring_first || pl->g.area_weighted) return false;
+    if (pl->kind == K_MASK && !(pl->lbits && pl->n_land > 0)) return false;  // MASKZ stencil: land must really be zero
+    if (pl->kind == K_FLUX && pl->n_land > 0 && !pl->lbits) return false;
+  } else if (pl->kind == K_MASK) {
+    return a.land_zero != 0;
+  }
+  if (pl->kind == K_MASK) return true;
   if (pl->kind == K_FLUX) return pl->d.dtype == GCMF_F64;  // f32 flux: k_flux_multi2 is faster (see gcmf_ring_impl.hpp)
   return pl->kind == K_REG;
 }

@@ -459,6 +459,8 @@ static int launch_multi_s(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   P.cN = (const T *)g.coef[1];
   P.ra = (const T *)g.coef[2];
   P.zrow = nullptr;
+  P.lbits = nullptr;
+  P.nfb = nullptr;
   P.mbits = g.mbits;
   P.area = (const T *)g.area;
   P.nx = g.nx;

@@ -74,6 +74,9 @@ typedef enum gcmf_dtype { GCMF_F32 = 0, GCMF_F64 = 1 } gcmf_dtype;
 /* Chebyshev step modes for gcmf_cheb_step */
 #define GCMF_STEP_FIRST 0x1u /* T1 = A(T0);            fbar  = p0*T0 + p1*T1                  */
 #define GCMF_STEP_LAST 0x2u  /* fbar result is finalised (divided by area) into fbar_out      */
+#define GCMF_STEP_LAND_FIXED 0x8u /* gcmf_cheb_multi with GCMF_STEP_FIRST: the caller will overwrite the result of the cells
+                                    gcmf_zero_land zeroes with gcmf_land_fix (or there are none), so the launch may take them as
+                                    zero while it loads the field; the states it writes then satisfy GCMF_STEP_LAND_ZERO */
 #define GCMF_STEP_LAND_ZERO 0x4u /* gcmf_cheb_multi[_vec]: the caller guarantees that the cells gcmf_zero_land zeroes are
                                     zero in both input states (lets the land-mask kernels drop their per-neighbour tests) */
 
@@ -252,6 +255,10 @@ int gcmf_last_kernel_timing(const gcmf_plan *plan, float *ms_sum, int *n_launche
  * steps per launch since this was last called; "" if none ran.  Reading resets it.  Instrumentation only: bench.py
  * refuses to quote profiled HBM traffic for a kernel other than the one that ran. */
 int gcmf_last_kernel(gcmf_plan *plan, char *buf, int n);
+/* Wave strips of the register-ring kernels (k_ring) that met a NaN / inf since this was last called and were redone by the
+ * general kernel (results are the same; each costs about two strip times).  Synchronises the device; reading resets.  A large
+ * count on ocean data means non-finite values in wet cells (NaN on land is masked on load and costs nothing). */
+int gcmf_ring_fallbacks(gcmf_plan *plan, int64_t *count);
 
 /* Tunables: rows marched per wave of the single-step kernel (0 keeps the default); XCD-aware tile order
  * (1 on, 0 off, <0 keep); temporal blocking: low byte = recurrence steps fused per HBM pass (1 = off,
