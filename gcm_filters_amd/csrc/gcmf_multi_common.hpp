@@ -107,6 +107,7 @@ template <typename T, typename FB> struct MultiP {
   int nx, rows, out_lo, out_hi;
   int H, nwx, nstrips, nwaves;
   int wrap, first, last, area_weighted;
+  int xcd_per;       // k_ring: workgroups per XCD for the XCD-contiguous order (0 = launch order)
   long long bstride;
   double pk[MAX_S];  // coefficient of level t (1-based) at pk[t-1]
   double p0;         // first only

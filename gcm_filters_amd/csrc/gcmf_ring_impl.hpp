@@ -67,7 +67,12 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
   const int lane = threadIdx.x & 63;
   // the wave index is uniform, but the compiler cannot prove it of threadIdx.x >> 6: without the readfirstlane every row
   // index, pointer and loop bound derived from it lives in vector registers and is recomputed with vector instructions
-  const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // Workgroups are dealt to the 8 XCDs round-robin (blockIdx.x % 8) and every XCD has its own L2.  Give each XCD a
+  // CONTIGUOUS range of strips instead of every eighth workgroup, so that the columns two neighbouring windows share and
+  // the halo rows two neighbouring strips share are fetched through the same L2.
+  int bx = blockIdx.x;
+  if (P.xcd_per > 0 && bx < 8 * P.xcd_per) bx = (bx & 7) * P.xcd_per + (bx >> 3);
+  const int wid = bx * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wid >= P.nwaves) return;
   const int wx = wid % P.nwx, st = wid / P.nwx;
   const int nx = P.nx, rows = P.rows;
@@ -429,6 +434,7 @@ static int launch_ring_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   P.p0 = a.p0;
   P.c = a.c;
   dim3 block(256), grid((P.nwaves + 3) / 4, (unsigned)a.nbatch);
+  P.xcd_per = pl->xcd_remap ? (int)(grid.x / 8) : 0;
   hipLaunchKernelGGL((k_ring<T, FB, KIND, S, FIRST>), grid, block, 0, s, P);
   GCMF_HIP(hipGetLastError());
   note_kernel(pl, std::string("gcmf::k_ring<") + tyname<T>() + ", " + tyname<FB>() + ", " + std::to_string(KIND) + ", " +

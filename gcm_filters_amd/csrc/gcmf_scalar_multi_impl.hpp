@@ -461,6 +461,7 @@ static int launch_multi_s(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   P.zrow = nullptr;
   P.lbits = nullptr;
   P.nfb = nullptr;
+  P.xcd_per = 0;
   P.mbits = g.mbits;
   P.area = (const T *)g.area;
   P.nx = g.nx;
