@@ -194,6 +194,11 @@ class Plan:
 
     # -- lifetime ------------------------------------------------------------------------------
     def close(self):
+        hb = self.__dict__.pop("_host_blocks", None)   # row-block pipelines hung on this plan (host_blocks.py)
+        if hb:
+            for pipe in hb["pipes"].values():
+                if pipe is not None:
+                    pipe.close()
         if getattr(self, "_h", None):
             load().gcmf_plan_destroy(self._h)
             self._h = None

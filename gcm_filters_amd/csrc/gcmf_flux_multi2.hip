@@ -13,7 +13,7 @@ namespace gcmf {
 
 template <typename T, typename FB, int S>
 __global__ __launch_bounds__(256, 1) void k_flux_multi2(const MultiP<T, FB> P) {
-  flux_multi2_march<T, FB, S>(P);
+  flux_multi2_march<T, FB, S>(P, blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
 }
 
 template <typename T, typename FB, int S> static int launch_f2(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {

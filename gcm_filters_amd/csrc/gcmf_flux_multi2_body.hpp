@@ -7,14 +7,15 @@
 namespace gcmf {
 
 template <typename T, typename FB, int S>
-__device__ __forceinline__ void flux_multi2_march(const MultiP<T, FB> &P) {
+__device__ __forceinline__ void flux_multi2_march(const MultiP<T, FB> &P, const int wid) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int W = 64 * VEC;
   constexpr int M = (S + VEC - 1) / VEC * VEC;
   constexpr int WI = W - 2 * M;
 
   const int lane = threadIdx.x & 63;
-  const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: scalar row / pointer arithmetic
+  // wid: the wave's (window, strip) index, wave-uniform (scalar row / pointer arithmetic); the caller decides how workgroups map
+  // to strips (k_ring reorders them per XCD)
   if (wid >= P.nwaves) return;
   const int wx = wid % P.nwx, st = wid / P.nwx;
   const int nx = P.nx, rows = P.rows;

@@ -354,8 +354,8 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
     if (dirty) {
       if (P.nfb && (threadIdx.x & 63) == 0) atomicAdd(P.nfb, 1u);  // instrumentation: gcmf_ring_fallbacks
       // the general march reads P.first itself; a first launch still has land in its input: K_MASK, not K_MASKZ
-      if constexpr (FLUX) flux_multi2_march<T, FB, S>(P);
-      else scalar_multi_march<T, FB, (FIRST ? K_MASK : KIND), S, 1>(P);
+      if constexpr (FLUX) flux_multi2_march<T, FB, S>(P, wid);   // the same strip: wid, not blockIdx (XCD order above)
+      else scalar_multi_march<T, FB, (FIRST ? K_MASK : KIND), S, 1>(P, wid);
       if constexpr (FIRST) {
         // the general march carries land through the recurrence; the launches that follow were promised states whose
         // isolated cells are zero (the fast march above took them as zero, gcmf_apply then skips k_zero_land): zero them

@@ -49,7 +49,7 @@ template <typename T, int KIND, int S> struct WavesPerSimd {
 // the march itself as a device function: k_scalar_multi is just this; the static-ring kernels (gcmf_ring_impl.hpp) fall
 // back to it for a strip in which a non-finite value turned up
 template <typename T, typename FB, int KIND, int S, int D>
-__device__ __forceinline__ void scalar_multi_march(const MultiP<T, FB> &P) {
+__device__ __forceinline__ void scalar_multi_march(const MultiP<T, FB> &P, const int wid) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int W = 64 * VEC;
   constexpr int M = (S + VEC - 1) / VEC * VEC;  // x margin, multiple of VEC so that windows stay 16-byte aligned
@@ -57,7 +57,7 @@ __device__ __forceinline__ void scalar_multi_march(const MultiP<T, FB> &P) {
   constexpr bool SAN = (KIND != K_REG);
 
   const int lane = threadIdx.x & 63;
-  const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: scalar row / pointer arithmetic
+  // wid: the wave's (window, strip) index, wave-uniform (scalar row / pointer arithmetic); see flux_multi2_march
   if (wid >= P.nwaves) return;
   const int wx = wid % P.nwx, st = wid / P.nwx;
   const int nx = P.nx, rows = P.rows;
@@ -437,7 +437,7 @@ __device__ __forceinline__ void scalar_multi_march(const MultiP<T, FB> &P) {
 
 template <typename T, typename FB, int KIND, int S, int D>
 __global__ __launch_bounds__(256, (WavesPerSimd<T, KIND, S>::value)) void k_scalar_multi(const MultiP<T, FB> P) {
-  scalar_multi_march<T, FB, KIND, S, D>(P);
+  scalar_multi_march<T, FB, KIND, S, D>(P, blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
 }
 
 // ------------------------------------------------------------------------------------------------------

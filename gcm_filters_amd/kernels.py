@@ -17,7 +17,9 @@ from typing import Any, Dict, Optional, Sequence, Tuple
 
 import numpy as np
 
-from . import _lib
+from . import _lib, host_blocks
+
+_BLOCKS_LOCK = threading.Lock()
 
 GridType = enum.Enum(
     "GridType",
@@ -476,10 +478,51 @@ class _DeviceLaplacian:
         host = [f.detach().cpu().numpy() if _is_torch(f) else np.asarray(f) for f in fields]
         ins = [np.ascontiguousarray(f, dtype=_lib.np_dtype(dtype)) for f in host]
         outs = [_host_output(shape, out_np) for _ in fields]
+        if nbatch == 1 and spec is not None and self._NCOMP == 1 and ny * nx >= host_blocks.MIN_CELLS:
+            # one large host field: upload / recurrence / download overlapped by row blocks (host_blocks.py)
+            pipe = self._row_blocks(plan, dtype, ny, nx, spec)
+            if pipe is not None:
+                c = 2 / spec.s_max if self.is_dimensional else 2 / (spec.s_max * spec.dx_min_sq)
+                try:
+                    pipe.apply(np.asarray(spec.p, dtype=np.float64), c, ins[0].reshape(ny, nx), outs[0].reshape(ny, nx),
+                               bool(out_f32 and dtype == _lib.F32))
+                except _lib.GcmfError as e:
+                    raise _translate(e) from None
+                return outs
         if nbatch:
             self._call(plan, spec, [a.ctypes.data for a in ins], [a.ctypes.data for a in outs], nbatch, False,
                        out_f32, 0)
         return outs
+
+    def _row_blocks(self, plan, dtype, ny, nx, spec):
+        """The row-block pipeline of `plan` for this polynomial length, built once the plan has seen a few single-field
+        host calls (it costs K more plans); None while it is not (yet) worth it."""
+        n = int(spec.n_steps)
+        with _BLOCKS_LOCK:
+            st = plan.__dict__.setdefault("_host_blocks", {"calls": 0, "pipes": {}})
+            st["calls"] += 1
+            if n in st["pipes"]:
+                return st["pipes"][n]
+            if st["calls"] <= host_blocks.BUILD_AFTER_CALLS:
+                return None
+            nblocks = host_blocks.choose_blocks(ny, n)
+            pipe = None
+            if nblocks:
+                host = [a.detach().cpu().numpy() if _is_torch(a) else np.asarray(a) for a in self._planes]
+                try:
+                    pipe = host_blocks.RowBlockPipeline(self.GRID_TYPE.value, dtype, ny, nx, host, plan.device, n, nblocks,
+                                                        skip_kappa_one=self._skip_kappa_one)
+                except _lib.GcmfError:
+                    pipe = None     # e.g. not enough device memory for the extra plans: stay on the plain path
+                if pipe is not None and not pipe.ok:
+                    pipe.close()
+                    pipe = None
+            while len(st["pipes"]) >= 2:    # polynomial lengths come and go with the filter scale: keep two
+                old = st["pipes"].pop(next(iter(st["pipes"])))
+                if old is not None:
+                    old.close()
+            st["pipes"][n] = pipe
+            return pipe
 
     def _call(self, plan, spec, ins, outs, nbatch, device_ptrs, out_f32, stream):
         try:

@@ -796,7 +796,12 @@ def test_ring_kernel_redoes_only_strips_with_non_finite_values(grid):
     g = f.copy()
     g[200, 600] = np.nan   # a wet cell
     assert not land[200, 600]
-    flt.apply(g)
+    got = flt.apply(g)
+    with np.errstate(all="ignore"):
+        fs = flt.filter_spec
+        want = O.filter_func(O.FilterSpec(fs.n_steps, fs.s_max, np.asarray(fs.p), fs.dx_min_sq), grid, g, gv)
+    assert np.array_equal(np.isnan(got), np.isnan(want))   # the redone strips are the RIGHT strips (workgroup order != strip order)
+    assert np.nanmax(np.abs(got - want)) <= 1e-11 * np.nanmax(np.abs(want))
     n = plan.ring_fallbacks()
     if grid == "REGULAR":   # no nan_to_num in the reference's REGULAR kernel: NaN spreads by plain arithmetic, nothing to redo
         assert n == 0
