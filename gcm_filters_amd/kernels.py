@@ -512,8 +512,8 @@ class _DeviceLaplacian:
                 try:
                     pipe = host_blocks.RowBlockPipeline(self.GRID_TYPE.value, dtype, ny, nx, host, plan.device, n, nblocks,
                                                         skip_kappa_one=self._skip_kappa_one)
-                except _lib.GcmfError:
-                    pipe = None     # e.g. not enough device memory for the extra plans: stay on the plain path
+                except (_lib.GcmfError, RuntimeError, MemoryError):
+                    pipe = None     # e.g. not enough device memory for the extra plans and state planes: stay on the plain path
                 if pipe is not None and not pipe.ok:
                     pipe.close()
                     pipe = None
