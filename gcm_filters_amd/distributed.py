@@ -399,6 +399,10 @@ class SlabFilter:
             hi = fo + ro + (v_out if self.gn else 0)
             is_last = (k + S - 1 == n)
             mode = (_lib.STEP_FIRST if k == 1 else 0) | (_lib.STEP_LAST if is_last else 0) | (_lib.STEP_LAND_ZERO if land_zeroed else 0)
+            if k == 1 and keep_land_out and S >= 2 and not is_last:
+                # land_fix below restores the isolated cells: the first launch may drop them while it loads the field
+                # (k_ring's first-launch variant; the general kernels ignore the flag and zero_land does it after them)
+                mode |= _lib.STEP_LAND_FIXED
             if self.time_kernels and k == 1:  # one pair of events per application (per-launch pairs cost 4 %)
                 e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
                 e0.record()
