@@ -39,6 +39,11 @@ for world in (1, 2, 4, 8):
     local = [torch.from_numpy(np.ascontiguousarray(f[None, sf.row_begin:sf.row_end])).cuda()]
     t = timed(sf, local)
     ex = n_ex[0] // 11
+    alt = []
+    for depth in (6, 5, 4):
+        sf.multi_depth = depth
+        alt.append(f"depth {depth}: {timed(sf, local)*1e3:.3f} ms")
+    sf.multi_depth = 8
     base = base or t
     print(f"config {cfg} strong, {world} ranks: rank {rank} owns {sf.rows_owned} rows (+{sf.halo} ghost rows per side), "
-          f"{t*1e3:.3f} ms per application, {ex} exchanges -> compute-side speed-up bound {base/t:.2f}x", flush=True)
+          f"{t*1e3:.3f} ms per application, {ex} exchanges -> compute-side speed-up bound {base/t:.2f}x  [{', '.join(alt)}]", flush=True)
