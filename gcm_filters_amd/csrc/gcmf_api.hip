@@ -693,7 +693,7 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
   const size_t oC = per; if (use_multi || use_vmulti) per += szT;
   const size_t oD = per; if (use_multi || use_vmulti) per += szT;
   const size_t oF = per; per += szF;
-  // second fbar plane (scalar blocked schedule): k_flux_ring re-does a strip from its inputs when it meets a NaN / inf,
+  // second fbar plane (scalar blocked schedule): k_ring re-does a strip from its inputs when it meets a NaN / inf,
   // so a launch must not accumulate fbar in place
   const size_t oF2 = per; if (use_multi) per += szF;
   // flux kinds only: the land-mask kernels have a NaN-only mode that already makes NaN on land free, there the two

@@ -1,5 +1,5 @@
 // The general (NaN / inf aware) two-rows-per-iteration march of the deep flux-form kernels as a device function:
-// k_flux_multi2 (gcmf_flux_multi2.hip) is just this; k_flux_ring (gcmf_flux_ring.hip) falls back to it for a strip in
+// k_flux_multi2 (gcmf_flux_multi2.hip) is just this; k_ring (gcmf_ring_impl.hpp) falls back to it for a strip in
 // which a non-finite value turned up.  See gcmf_flux_multi2.hip for the description.
 #pragma once
 #include "gcmf_multi_common.hpp"

@@ -99,7 +99,7 @@ template <typename T, typename FB> struct MultiP {
   const FB *fb_in;  // running sum in     (unused when first)
   FB *fb_out;       // running sum out / finalised result when last
   const T *cE, *cN, *ra;
-  const T *zrow;    // nx zeros (k_flux_ring: coefficient rows beyond a closed boundary)
+  const T *zrow;    // nx zeros (k_ring: coefficient rows beyond a closed boundary)
   const uint8_t *mbits;
   unsigned *nfb;         // k_ring: counts the wave strips that met a NaN / inf and were redone by the general march (or NULL)
   const uint8_t *lbits;  // k_ring, first launch: bit 0 of a cell's byte = it exchanges with a neighbour (gcmf_plan::lbits) or NULL

@@ -20,13 +20,21 @@
 //     this path, so every one that could reach a stored cell ends up there -- OR-ed into a wave mask, tested once per
 //     unrolled body); a wave that sees one abandons its strip and redoes it with the general march of k_flux_multi2 /
 //     k_scalar_multi, whose results then overwrite whatever the fast march stored (so fbar must not be accumulated in
-//     place).  gcmf_apply keeps land out of the state after its first launch (k_zero_land), so ocean fields with NaN
-//     on land stay on the fast path.  K_REG has no nan_to_num in the reference (NaN spreads): no check, no fallback.
+//     place).  Land never enters the state (FIRST below), so ocean fields with NaN on land stay on the fast path.
+//     K_REG has no nan_to_num in the reference (NaN spreads): no check, no fallback.
 //   * the wave index goes through readfirstlane: row indices, pointers and loop bounds are scalar; neighbours by DPP
 //     with zero fill (no copy of the source); rows beyond a closed boundary read their coefficients from a row of zeros.
 //
-// Not the first launch of a filter (no T_{k-2} / fbar yet, prepare() to fuse, NaN on land still in the field): that one
-// stays with the general kernels.  One wave per SIMD (up to 446 registers at S = 8 in f64).
+//   * FIRST = true is the first launch of a filter (T_0 = the caller's field, no T_{k-2} / fbar yet, fbar = p_0 T_0 + p_1 T_1,
+//     filter.py:192-199): isolated (land) cells are taken as zero while the field is loaded, so NaN on land never enters
+//     the state and gcmf_apply needs no k_zero_land pass; k_land_fix writes those cells' own polynomial at the end.
+//     (Area-weighted types keep the general first launch: prepare() is fused there.)
+//   * all rings start at zero: the upper levels of a strip's first rows run on slots no load has filled yet; what they
+//     produce is never stored but the NaN watch sees it, and stale NaNs left in the registers by an earlier kernel would
+//     send clean strips to the general march.
+//   * workgroups are renumbered so that every XCD owns a contiguous range of strips (one L2 for shared columns / halo rows).
+//
+// One wave per SIMD (up to 446 registers at S = 8 in f64).  gcmf_ring_fallbacks() counts the strips that were redone.
 #pragma once
 #include "gcmf_flux_multi2_body.hpp"
 #include "gcmf_scalar_multi_impl.hpp"

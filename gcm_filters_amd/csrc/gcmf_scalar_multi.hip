@@ -26,7 +26,8 @@ bool multi_supported(const gcmf_plan *pl, int S) {
   return true;
 }
 
-// S in 5..8, not the first launch of a filter (prepare() / p0 T0 + p1 T1 to fuse), land-mask kinds only once land is kept out of
+// S in 5..8; the first launch of a filter only if the caller fixes up the isolated cells afterwards (ring_first) and the type is
+// not area-weighted (prepare() is fused into the general kernels only); land-mask kinds only once land is kept out of
 // the state, a row of zeros at hand for closed boundaries, and fbar NOT accumulated in place: a strip that meets a NaN /
 // inf is redone from its inputs, which its own stores must not have touched
 bool ring_supported(const gcmf_plan *pl, const MultiArgs &a) {
