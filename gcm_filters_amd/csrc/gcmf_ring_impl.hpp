@@ -28,7 +28,7 @@
 //   * FIRST = true is the first launch of a filter (T_0 = the caller's field, no T_{k-2} / fbar yet, fbar = p_0 T_0 + p_1 T_1,
 //     filter.py:192-199): isolated (land) cells are taken as zero while the field is loaded, so NaN on land never enters
 //     the state and gcmf_apply needs no k_zero_land pass; k_land_fix writes those cells' own polynomial at the end.
-//     (Area-weighted types keep the general first launch: prepare() is fused there.)
+//     prepare() of the area-weighted types (field * area, kernels.py:100-101) is applied as the field is loaded.
 //   * all rings start at zero: the upper levels of a strip's first rows run on slots no load has filled yet; what they
 //     produce is never stored but the NaN watch sees it, and stale NaNs left in the registers by an earlier kernel would
 //     send clean strips to the general march.
@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
   FB F[R][VEC];      // fbar rows, same slots
   T V[RV][VEC];      // T_{k-2} rows, slot = (row + 1 - r_begin) mod RV
   unsigned Z[RU];    // FIRST: the "exchanges with a neighbour" bytes of the input rows (same slots as G0)
+  T AR[RU][VEC];     // FIRST, area-weighted types: the area of the input rows (prepare(): T_0 = field * area)
 #pragma unroll
   for (int t = 0; t < S; ++t) {
 #pragma unroll
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
 #pragma unroll
   for (int l = 0; l < RU; ++l) {
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) G0[l][k] = T(0);
+    for (int k = 0; k < VEC; ++k) G0[l][k] = AR[l][k] = T(0);
     Z[l] = 0u;
   }
   // The first S iterations run their upper levels on ring slots no load has filled yet.  What they produce is never stored,
@@ -163,6 +164,8 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
   };
   const bool has_land = FIRST && P.lbits != nullptr;
   const uint8_t *zbase = has_land ? P.lbits : reinterpret_cast<const uint8_t *>(P.u0);  // (bytes of a valid plane, ignored)
+  const bool weigh = FIRST && !FLUX && P.area_weighted;  // prepare() of the area-weighted types (kernels.py:100-101)
+  const T *abase = weigh ? P.area : P.u0;                // (same trick: an unconditional load, ignored when there is no area)
   // addresses = a wave-uniform row pointer (scalar arithmetic) + this lane's column.  Loads past the strip's last row are
   // harmless (a valid row of the plane; what they feed is never stored), so the march needs no clamp of its own.
   auto load_u = [&](auto slot_c) {  // the cursor's row of T_{k-1}
@@ -175,6 +178,7 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
       const uint8_t *zp = lane_ptr(zbase + (long long)(cj * nx), col);
       if (VEC == 2) Z[sl] = *reinterpret_cast<const unsigned short *>(zp);
       else Z[sl] = *reinterpret_cast<const unsigned *>(zp);
+      if constexpr (!FLUX) mload<T, VEC>(AR[sl], lane_ptr(abase + (long long)(cj * nx), colT));
     }
   };
   // the centre-only operands that travel with that row: T_{k-2}, fbar, coefficients / mask bits of the row before it
@@ -291,8 +295,10 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
       // flux-form cell with four closed faces) is taken as zero -- it has L = 0 and evolves on its own; k_land_fix writes
       // its polynomial into the result at the end.  NaN on land therefore never enters this kernel.
 #pragma unroll
-      for (int k = 0; k < VEC; ++k)
+      for (int k = 0; k < VEC; ++k) {
+        if constexpr (!FLUX) G0[ph % RU][k] = weigh ? G0[ph % RU][k] * AR[ph % RU][k] : G0[ph % RU][k];
         G0[ph % RU][k] = (!has_land || ((Z[ph % RU] >> (8 * k)) & 1u)) ? G0[ph % RU][k] : T(0);
+      }
     }
     level(ic<1>{}, ph_c);
     if constexpr (S >= 2) level(ic<2>{}, ph_c);

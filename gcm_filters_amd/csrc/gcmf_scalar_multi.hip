@@ -26,16 +26,15 @@ bool multi_supported(const gcmf_plan *pl, int S) {
   return true;
 }
 
-// S in 5..8; the first launch of a filter only if the caller fixes up the isolated cells afterwards (ring_first) and the type is
-// not area-weighted (prepare() is fused into the general kernels only); land-mask kinds only once land is kept out of
+// S in 5..8; the first launch of a filter only if the caller fixes up the isolated cells afterwards (ring_first); land-mask kinds only once land is kept out of
 // the state, a row of zeros at hand for closed boundaries, and fbar NOT accumulated in place: a strip that meets a NaN /
 // inf is redone from its inputs, which its own stores must not have touched
 bool ring_supported(const gcmf_plan *pl, const MultiArgs &a) {
   if (!pl->ring || !pl->zero_row || a.S < 5 || a.S > 8 || a.fb_in == a.fb_out) return false;
   if (a.first) {
-    // the first launch of a filter: prepare() is not fused here (area-weighted types keep the general kernel), and land is
-    // zeroed as it is loaded (the caller says it will fix those cells up: ring_first), which needs the plan's byte plane
-    if (!a.ring_first || pl->g.area_weighted) return false;
+    // the first launch of a filter: land is zeroed as it is loaded (the caller says it will fix those cells up: ring_first),
+    // which needs the plan's byte plane
+    if (!a.ring_first) return false;
     if (pl->kind == K_MASK && !(pl->lbits && pl->n_land > 0)) return false;  // MASKZ stencil: land must really be zero
     if (pl->kind == K_FLUX && pl->n_land > 0 && !pl->lbits) return false;
   } else if (pl->kind == K_MASK) {
