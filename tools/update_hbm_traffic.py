@@ -45,7 +45,7 @@ if sq:
     wc = vals["SQ_WAVE_CYCLES"]
     arith = sum(vals.get(k, 0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64",
                                          "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32"))
-    rec.update({"bound": "hbm + issue (one wave per SIMD)", "valu_active_frac": vals["SQ_ACTIVE_INST_VALU"] / wc,
+    rec.update({"bound": "hbm: streams at the rate this access pattern reaches on the chip (experiments/stream_probe: 5.0-5.5 TB/s without halos or arithmetic); removing 20 % of its VALU work or adding rows in flight changes nothing", "valu_active_frac": vals["SQ_ACTIVE_INST_VALU"] / wc,
                 "salu_active_frac": vals.get("SQ_ACTIVE_INST_SCA", 0) / wc, "wait_memory_frac": vals["SQ_WAIT_ANY"] / wc,
                 "wait_issue_frac": vals["SQ_WAIT_INST_ANY"] / wc, "valu_arith_share": arith / vals["SQ_INSTS_VALU"],
                 "valu_insts_per_launch": vals["SQ_INSTS_VALU"], "waves": vals["SQ_WAVES"],
