@@ -58,6 +58,18 @@ def choose_blocks(ny: int, n_steps: int) -> int:
     return k if k >= 2 else 0
 
 
+def block_runs(first_row: int, rows: int, ny: int):
+    """Rows [first_row, first_row + rows) of a global field that is periodic in y, as contiguous runs
+    (offset in the block, global row, count)."""
+    r, out = 0, []
+    while r < rows:
+        gj = (first_row + r) % ny
+        n = min(rows - r, ny - gj)
+        out.append((r, gj, n))
+        r += n
+    return out
+
+
 class _Block:
     """One row block: slab plan + state planes + the launch schedule of gcmf_apply on shrinking row ranges."""
 
@@ -86,13 +98,7 @@ class _Block:
 
     # rows [row_begin - gs, row_end + gn) of the global field, wrapped in y, as contiguous runs
     def _runs(self):
-        g0, r, out = self.row_begin - self.gs, 0, []
-        while r < self.rows:
-            gj = (g0 + r) % self.ny
-            n = min(self.rows - r, self.ny - gj)
-            out.append((r, gj, n))
-            r += n
-        return out
+        return block_runs(self.row_begin - self.gs, self.rows, self.ny)
 
     def upload(self, field: np.ndarray):
         t = self.torch
