@@ -783,7 +783,11 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
           if (k == 1 && zero_land && !is_last) {  // keep the isolated cells out of the state from here on
             // (a first launch by k_ring already took them as zero while it loaded the field -- except in the rows of a tripole
             // band, which single steps advance from the raw field)
-            if ((!ring_supported(pl, m) || pl->g.fold) && (rc = launch_zero_land(pl, fr[0], fr[1], nbatch, s))) return rc;
+            if (!ring_supported(pl, m)) {
+              if ((rc = launch_zero_land(pl, fr[0], fr[1], nbatch, s))) return rc;
+            } else if (pl->g.fold) {  // only the band rows: the single steps that advanced them carried land along
+              if ((rc = launch_zero_land(pl, fr[0], fr[1], nbatch, s, rows - S, rows))) return rc;
+            }
             land_zeroed = true;
           }
         } else {

@@ -207,7 +207,7 @@ int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launche
 int launch_prepare(gcmf_plan *pl, const void *const *in, void *const *out, int64_t nbatch, int row_lo,
                    int row_hi, hipStream_t s);
 // the isolated cells' own polynomial, written over out (gcmf_landfix.hip); dp = p[0..n_steps] on the device
-int launch_zero_land(gcmf_plan *pl, void *a, void *b, int64_t nbatch, hipStream_t s);
+int launch_zero_land(gcmf_plan *pl, void *a, void *b, int64_t nbatch, hipStream_t s, int row_lo = 0, int row_hi = 0);
 int launch_land_fix(gcmf_plan *pl, const void *in, void *out, const double *dp, int n_steps, double c, int fb_is_f32,
                     int64_t nbatch, hipStream_t s);
 // plan-time precompute (gcmf_precompute.hip): fills pl->g from the raw global planes (device pointers)

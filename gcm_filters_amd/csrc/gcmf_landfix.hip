@@ -58,27 +58,34 @@ __global__ __launch_bounds__(256) void k_land_fix(const T *in, FB *out, const ui
 
 // zero the isolated cells of two state planes in place (the outputs of the first blocked launch): from then on NaN on land
 // cannot reach the NaN / inf bookkeeping of the blocked kernels.  Reads the byte plane, writes land cells only.
+// Cells [cell0, cell0 + nsub) of every field (both multiples of 4: the caller checks nx % 4 == 0).
 template <typename T>
-__global__ __launch_bounds__(256) void k_zero_land(T *a, T *b, const uint8_t *lbits, long long ncell, long long ntotal) {
+__global__ __launch_bounds__(256) void k_zero_land(T *a, T *b, const uint8_t *lbits, long long ncell, long long cell0, long long nsub,
+                                                   long long ntotal) {
   for (long long q4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; q4 < ntotal; q4 += (long long)gridDim.x * blockDim.x * 4) {
-    const long long cell = q4 % ncell;  // ncell is a multiple of 4 here (checked by the caller): 4 cells of one field
+    const long long field = q4 / nsub, cell = cell0 + (q4 - field * nsub);  // 4 cells of one field
     const unsigned m = *reinterpret_cast<const unsigned *>(lbits + cell);
     if ((m & 0x01010101u) == 0x01010101u) continue;
+    const long long o = field * ncell + cell;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (!((m >> (8 * k)) & 1u)) { a[q4 + k] = T(0); b[q4 + k] = T(0); }
+      if (!((m >> (8 * k)) & 1u)) { a[o + k] = T(0); b[o + k] = T(0); }
   }
 }
 
-int launch_zero_land(gcmf_plan *pl, void *a, void *b, int64_t nbatch, hipStream_t s) {
-  const long long ncell = (long long)pl->rows_alloc * pl->d.nx, ntotal = ncell * nbatch;
+// rows [row_lo, row_hi) of both planes (row_hi <= 0: all rows)
+int launch_zero_land(gcmf_plan *pl, void *a, void *b, int64_t nbatch, hipStream_t s, int row_lo, int row_hi) {
+  if (row_hi <= 0) { row_lo = 0; row_hi = (int)pl->rows_alloc; }
+  const long long ncell = (long long)pl->rows_alloc * pl->d.nx, cell0 = (long long)row_lo * pl->d.nx;
+  const long long nsub = (long long)(row_hi - row_lo) * pl->d.nx, ntotal = nsub * nbatch;
+  if (ntotal <= 0) return GCMF_OK;
   long long nb = (ntotal / 4 + 255) / 256;
   if (nb > 65536) nb = 65536;
   dim3 block(256), grid((unsigned)nb);
   if (pl->d.dtype == GCMF_F64)
-    hipLaunchKernelGGL(k_zero_land<double>, grid, block, 0, s, (double *)a, (double *)b, pl->lbits, ncell, ntotal);
+    hipLaunchKernelGGL(k_zero_land<double>, grid, block, 0, s, (double *)a, (double *)b, pl->lbits, ncell, cell0, nsub, ntotal);
   else
-    hipLaunchKernelGGL(k_zero_land<float>, grid, block, 0, s, (float *)a, (float *)b, pl->lbits, ncell, ntotal);
+    hipLaunchKernelGGL(k_zero_land<float>, grid, block, 0, s, (float *)a, (float *)b, pl->lbits, ncell, cell0, nsub, ntotal);
   GCMF_HIP(hipGetLastError());
   return GCMF_OK;
 }
