@@ -255,6 +255,31 @@ def run_single(cfg, args, dev, steps, warmup, scale=0.0, levels=None, tuned=Fals
                 cells=args.ny * args.nx * nbatch)
 
 
+_COPY_GBS = []
+
+
+def device_copy_gbs():
+    """Rate of a plain 600 MB device-to-device copy on THIS box (read + written bytes / time, HIP events; measured once per
+    process, outside every timed region): what the memory system gives the simplest stream there is.  On the gpurun pool
+    this is 5.1-5.3 TB/s, not the 6.3 TB/s of the guide -- the figure `hbm_frac` should be read against."""
+    if not _COPY_GBS:
+        import torch
+        x = torch.empty(75_000_000, dtype=torch.float64, device="cuda")
+        y = torch.empty_like(x)
+        y.copy_(x)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            y.copy_(x)
+        e1.record()
+        torch.cuda.synchronize()
+        _COPY_GBS.append(2 * x.numel() * 8 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        del x, y
+        torch.cuda.empty_cache()
+    return _COPY_GBS[0]
+
+
 def roofline_of(cfg, r, steps, default_tuning):
     w, nb, grid = r["itemsize"], r["nbatch"], r["grid"]
     if not (r["dom_n"] and r["dom_ms"] > 0):
@@ -285,6 +310,12 @@ def roofline_of(cfg, r, steps, default_tuning):
         gbs = rec["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
         out["hbm_frac"] = gbs / HBM_PEAK_GBS                      # counter bytes / this run's launch time / 8 TB/s
         out["hbm_frac_of_copy_ceiling"] = gbs / HBM_COPY_GBS
+        try:  # the same against what a plain device copy reaches on this box, measured now
+            cp = device_copy_gbs()
+            out["device_copy_GBps_this_box"] = cp
+            out["hbm_rate_over_device_copy"] = gbs / cp
+        except Exception:
+            pass
         out["traffic_over_min_bytes"] = rec["bytes_per_launch"] / minb
         # SQ-counter view of the same kernel (profiles/): how the wave cycles split; `bound` stays the contract's enum
         for k in ("bound", "valu_active_frac", "salu_active_frac", "wait_memory_frac", "wait_issue_frac", "valu_arith_share",
