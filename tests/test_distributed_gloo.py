@@ -1,4 +1,4 @@
-"""Row-slab decomposition + s-step halo exchange on CPU: world_size 2 and 3 over gloo, the per-slab step
+"""Row-slab decomposition + s-step halo exchange on CPU: world_size 2, 3 and 8 over gloo, the per-slab step
 executed by a test-only oracle engine (tests/slab_engines.py).  Checks that the halo choreography of
 gcm_filters_amd.distributed reproduces the single-domain oracle filter."""
 import os
@@ -43,6 +43,16 @@ CASES = [
 ]
 
 
+# BASELINE configs 4 and 5 are 8-GPU configs (config 4: 300 rows per rank): the same choreography on 8 ranks, slabs of 8-12 rows
+CASES_8 = [
+    ("IRREGULAR_WITH_LAND", (64, 16), 2, 1),
+    ("TRIPOLAR_POP_WITH_LAND", (96, 16), 4, 1),     # rank 0 has no southern neighbour, rank 7 folds onto itself
+    ("TRIPOLAR_REGULAR_WITH_LAND_AREA_WEIGHTED", (80, 16), 3, 2),
+    ("REGULAR_WITH_LAND", (67, 16), 8, 1),           # uneven slabs (8 or 9 rows), halo as deep as a slab
+    ("VECTOR_C_GRID", (64, 16), 3, 4),
+]
+
+
 def _problem(grid, shape, nbatch):
     vec = grid in T.VECTOR_GRIDS
     gv = T.vector_grid_vars(grid, shape) if vec else T.scalar_grid_vars(grid, shape)
@@ -64,7 +74,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     errs = {}
     try:
-        for grid, shape, halo, nbatch in CASES:
+        for grid, shape, halo, nbatch in (CASES_8 if world == 8 else CASES):
             gv, fields, fk = _problem(grid, shape, nbatch)
             sf = SlabFilter(grid, gv, fk, shape[0], shape[1], halo=halo, engine_factory=OracleSlabEngine, device=-1)
             sf.overlap = True   # small test slabs: force the overlapped (edge strips first) exchange where it fits
@@ -86,7 +96,7 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_slab_filter_matches_single_domain(world):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
@@ -99,7 +109,7 @@ def test_slab_filter_matches_single_domain(world):
     for p in procs:
         assert p.exitcode == 0, f"worker exit code {p.exitcode}"
     errs = q.get()
-    assert len(errs) == len(CASES)
+    assert len(errs) == len(CASES_8 if world == 8 else CASES)
     for name, (e, nex, n, halo) in errs.items():
         assert e < 1e-12, (name, e)
         assert nex == -(-n // halo), (name, nex, n, halo)  # one exchange per `halo` steps
