@@ -1,4 +1,4 @@
-"""Row-slab path on the real GPU.  A gpurun box has ONE MI355X, so the 2- and 3-rank runs here share cuda:0
+"""Row-slab path on the real GPU.  A gpurun box has ONE MI355X, so the 2-, 3- and 8-rank runs here share cuda:0
 and exchange halos over gloo (packed buffers staged through host memory); the slab kernels, ghost-row
 geometry, s-step shrinking row ranges and the tripole fold are exactly what the RCCL run uses."""
 import os
@@ -34,6 +34,15 @@ CASES = [
 ]
 
 
+# eight ranks (BASELINE configs 4 and 5 are 8-GPU configs): slabs of 16-20 rows, the blocked kernels between exchanges
+CASES_8 = [
+    ("IRREGULAR_WITH_LAND", (144, 64), 8, 2, "f8"),
+    ("TRIPOLAR_POP_WITH_LAND", (160, 64), 8, 2, "f8"),
+    ("REGULAR_WITH_LAND", (131, 64), 5, 2, "f4"),
+    ("VECTOR_C_GRID", (128, 64), 4, 4, "f4"),
+]
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -56,7 +65,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     res = {}
     try:
-        for grid, shape, halo, nbatch, dt in CASES:
+        for grid, shape, halo, nbatch, dt in (CASES_8 if world == 8 else CASES):
             vec = grid in T.VECTOR_GRIDS
             gv = T.vector_grid_vars(grid, shape) if vec else T.scalar_grid_vars(grid, shape)
             fields = [np.stack([T.random_field(shape, 7 + 10 * c + b) for b in range(nbatch)]) for c in range(2 if vec else 1)]
@@ -93,7 +102,7 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_slabs_on_one_gpu_match_single_domain(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -107,7 +116,7 @@ def test_slabs_on_one_gpu_match_single_domain(world):
     for p in procs:
         assert p.exitcode == 0, f"worker exit code {p.exitcode}"
     res = q.get()
-    assert len(res) == len(CASES)
+    assert len(res) == len(CASES_8 if world == 8 else CASES)
     for name, (e_one, e_ref) in res.items():
         f32 = name.endswith("f4")
         assert e_one <= (1e-5 if f32 else 1e-13), (name, e_one)   # slab run == single-domain GPU run
