@@ -288,7 +288,8 @@ def roofline_of(cfg, r, steps, default_tuning):
     avg_ms = r["dom_ms"] / r["dom_n"]                       # HIP events around each launch of the dominant kernel
     # recurrence steps one launch of that kernel advances: its last (vector kernels: fourth) template argument
     targs = r["kernel"][r["kernel"].index("<") + 1: r["kernel"].rindex(">")].split(", ")
-    steps_per_launch = float(targs[3] if any(k in r["kernel"] for k in ("stream2", "k_scalar_multi", "k_ring")) else
+    steps_per_launch = float(targs[2] if "k_ringc<" in r["kernel"] else
+                             targs[3] if any(k in r["kernel"] for k in ("stream2", "k_scalar_multi", "k_ring")) else
                              (targs[-1] if "k_flux_multi2" in r["kernel"] else 1))
     achieved = balg * r["cells"] * steps_per_launch / (avg_ms * 1e-3) / 1e9
     minb = min_bytes_per_cell_launch(grid, w, 8, nb) * r["cells"]

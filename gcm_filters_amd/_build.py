@@ -10,8 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "libgcmf.so")
-SOURCES = ["gcmf_api.hip", "gcmf_precompute.hip", "gcmf_scalar.hip", "gcmf_scalar_multi.hip", "gcmf_scalar_multi_reg.hip", "gcmf_scalar_multi_mask.hip", "gcmf_scalar_multi_maskz.hip", "gcmf_scalar_multi_flux.hip", "gcmf_flux_multi2.hip", "gcmf_vector.hip", "gcmf_cgrid_stream.hip", "gcmf_cgrid_stream2.hip", "gcmf_bgrid_stream.hip", "gcmf_bgrid_stream2.hip", "gcmf_landfix.hip", "gcmf_exchange.hip", "gcmf_ring_flux.hip", "gcmf_ring_maskz.hip", "gcmf_ring_reg.hip"]
-HEADERS = [os.path.join(CSRC, "gcmf_internal.hpp"), os.path.join(CSRC, "gcmf_multi_common.hpp"), os.path.join(CSRC, "gcmf_scalar_multi_impl.hpp"), os.path.join(CSRC, "gcmf_recurrence.hpp"), os.path.join(CSRC, "gcmf_flux_multi2_body.hpp"), os.path.join(CSRC, "gcmf_ring_impl.hpp"), os.path.join(INCLUDE, "gcmf.h")]
+SOURCES = ["gcmf_api.hip", "gcmf_precompute.hip", "gcmf_scalar.hip", "gcmf_scalar_multi.hip", "gcmf_scalar_multi_reg.hip", "gcmf_scalar_multi_mask.hip", "gcmf_scalar_multi_maskz.hip", "gcmf_scalar_multi_flux.hip", "gcmf_flux_multi2.hip", "gcmf_vector.hip", "gcmf_cgrid_stream.hip", "gcmf_cgrid_stream2.hip", "gcmf_bgrid_stream.hip", "gcmf_bgrid_stream2.hip", "gcmf_landfix.hip", "gcmf_exchange.hip", "gcmf_ring_flux.hip", "gcmf_ring_maskz.hip", "gcmf_ring_reg.hip", "gcmf_ringc_flux.hip", "gcmf_ringc_maskz.hip", "gcmf_ringc_reg.hip"]
+HEADERS = [os.path.join(CSRC, "gcmf_internal.hpp"), os.path.join(CSRC, "gcmf_multi_common.hpp"), os.path.join(CSRC, "gcmf_scalar_multi_impl.hpp"), os.path.join(CSRC, "gcmf_recurrence.hpp"), os.path.join(CSRC, "gcmf_flux_multi2_body.hpp"), os.path.join(CSRC, "gcmf_ring_impl.hpp"), os.path.join(CSRC, "gcmf_ringc_impl.hpp"), os.path.join(INCLUDE, "gcmf.h")]
 # -ffp-contract=off: no FMA contraction, so the REGULAR / land-mask / B-grid kernels reproduce the
 # reference's (numpy's) rounding exactly; the kernels are HBM-bound, the extra VALU ops are free.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

@@ -22,14 +22,14 @@ ERR_KAPPA_W_GT1, ERR_KAPPA_S_GT1, ERR_KAPPA_NONE_ONE = 16, 17, 18
 ERR_WET_SOUTH_ROW, ERR_DXN_FOLD, ERR_DYN_FOLD = 19, 20, 21
 F32, F64 = 0, 1
 DEVICE_PTRS, OUT_F32 = 0x1, 0x2
-STEP_FIRST, STEP_LAST, STEP_LAND_ZERO, STEP_LAND_FIXED = 0x1, 0x2, 0x4, 0x8
+STEP_FIRST, STEP_LAST, STEP_LAND_ZERO, STEP_LAND_FIXED, STEP_CLENSHAW = 0x1, 0x2, 0x4, 0x8, 0x10
 
 EXPORTS = [
     "gcmf_plan_create", "gcmf_plan_destroy", "gcmf_grid_nplanes", "gcmf_grid_ncomp", "gcmf_grid_is_dimensional",
     "gcmf_grid_is_tripolar", "gcmf_plan_rows", "gcmf_apply", "gcmf_laplacian", "gcmf_cheb_step", "gcmf_prepare",
     "gcmf_last_timing", "gcmf_set_timing", "gcmf_set_tuning", "gcmf_last_error", "gcmf_version",
     "gcmf_multi_supported", "gcmf_cheb_multi", "gcmf_multi_supported_vec", "gcmf_cheb_multi_vec",
-    "gcmf_has_land", "gcmf_zero_land", "gcmf_land_fix", "gcmf_last_kernel", "gcmf_last_kernel_timing", "gcmf_ring_fallbacks",
+    "gcmf_has_land", "gcmf_zero_land", "gcmf_land_fix", "gcmf_last_kernel", "gcmf_last_kernel_timing", "gcmf_ring_fallbacks", "gcmf_clenshaw_cut",
     "gcmf_comm_unique_id", "gcmf_comm_create", "gcmf_comm_destroy", "gcmf_halo_start", "gcmf_halo_finish",
 ]
 PLAN_SELF_RING, PLAN_SKIP_KAPPA_ONE = 0x1, 0x2
@@ -115,6 +115,8 @@ def load() -> C.CDLL:
         lib.gcmf_last_kernel_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float),
                                                 C.POINTER(C.c_float)]
         lib.gcmf_last_kernel_timing.restype = C.c_int
+        lib.gcmf_clenshaw_cut.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.c_int]
+        lib.gcmf_clenshaw_cut.restype = C.c_int
         lib.gcmf_ring_fallbacks.argtypes = [vp, C.POINTER(C.c_int64)]
         lib.gcmf_ring_fallbacks.restype = C.c_int
         lib.gcmf_last_kernel.argtypes = [vp, C.c_char_p, C.c_int]
@@ -238,11 +240,17 @@ class Plan:
     def cheb_multi(self, u, v, uo, vo, fb_in, fb_out, pk, p0, c, mode, nbatch, row_lo, row_hi, *,
                    out_f32: bool = False, stream: int = 0):
         pk = np.ascontiguousarray(pk, dtype=np.float64)
-        check(load().gcmf_cheb_multi(self._h, C.c_void_p(u), C.c_void_p(v or None), C.c_void_p(uo or None),
+        check(load().gcmf_cheb_multi(self._h, C.c_void_p(u or None), C.c_void_p(v or None), C.c_void_p(uo or None),
                                      C.c_void_p(vo or None), C.c_void_p(fb_in or None), C.c_void_p(fb_out),
                                      pk.ctypes.data_as(C.POINTER(C.c_double)), len(pk), float(p0), float(c), int(mode),
                                      OUT_F32 if out_f32 else 0, int(nbatch), int(row_lo), int(row_hi),
                                      C.c_void_p(stream or None)))
+
+    def clenshaw_cut(self, n_steps: int):
+        """Launch depths of the backward evaluation gcmf_apply uses for this polynomial length ([] = forward recurrence)."""
+        buf = (C.c_int * 1024)()
+        n = load().gcmf_clenshaw_cut(self._h, int(n_steps), buf, 1024)
+        return [buf[i] for i in range(n)]
 
     def multi_supported_vec(self, S: int, nbatch: int) -> bool:
         return bool(load().gcmf_multi_supported_vec(self._h, int(S), int(nbatch)))
@@ -301,10 +309,11 @@ class Plan:
         return buf.value.decode()
 
     def set_tuning(self, rows_per_wave: int = 0, xcd_remap: int = -1, multi_s: int = 0, strip_rows: int = 0,
-                   prefetch_rows: int = 0):
+                   prefetch_rows: int = 0, clenshaw: int = -1):
+        """`clenshaw` (needs multi_s > 0): backward evaluation 0 = off, 1 = flux kinds, 2 = all scalar kinds; -1 keeps it."""
         check(load().gcmf_set_tuning(self._h, int(rows_per_wave), int(xcd_remap),
                                      (int(multi_s) & 0xFF) | ((int(strip_rows) & 0xFFFF) << 8)
-                                     | ((int(prefetch_rows) & 0xF) << 24)))
+                                     | ((int(prefetch_rows) & 0xF) << 24) | (((int(clenshaw) + 1) & 3) << 28 if clenshaw >= 0 else 0)))
 
 
 class Comm:

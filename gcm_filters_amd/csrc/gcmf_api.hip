@@ -396,6 +396,7 @@ int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int 
   if (const char *e = getenv("GCMF_HOST_REGISTER")) pl->host_register = atoi(e);
   if (const char *e = getenv("GCMF_ZERO_LAND")) pl->zero_land = atoi(e);
   if (const char *e = getenv("GCMF_RING")) pl->ring = atoi(e);
+  if (const char *e = getenv("GCMF_CLENSHAW")) pl->clenshaw = atoi(e);
   pl->band_rpw = (pl->d.dtype == GCMF_F32) ? 1 : 0;  // f32: one row per wave shortens the chain (+8 %); f64: no difference
   if (const char *e = getenv("GCMF_BAND_RPW")) pl->band_rpw = atoi(e);
   PLAN_HIP(hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking));
@@ -509,6 +510,7 @@ int gcmf_set_tuning(gcmf_plan *pl, int rows_per_wave, int xcd_remap, int multi_s
     pl->multi_s = multi_s & 0xFF;               // low byte: steps per pass
     pl->strip_rows = (multi_s >> 8) & 0xFFFF;   // bits 8..23: rows per strip (0 = auto)
     pl->prefetch_rows = (multi_s >> 24) & 0xF;  // bits 24..27: operand rows in flight per wave (0 = default)
+    if ((multi_s >> 28) & 3) pl->clenshaw = ((multi_s >> 28) & 3) - 1;  // bits 28..29: backward evaluation 1 = off, 2 = flux kinds, 3 = all
   }
   return GCMF_OK;
 }
@@ -548,9 +550,73 @@ int gcmf_cheb_step(gcmf_plan *pl, const void *const *t1, const void *const *t2, 
 
 int gcmf_multi_supported(const gcmf_plan *pl, int S) { return (pl && multi_supported(pl, S)) ? 1 : 0; }
 
+// Backward (Clenshaw) evaluation (gcmf_ringc_impl.hpp): whether gcmf_apply uses it for this plan and polynomial, and how the
+// n_steps levels are cut into launches of 5..8 (never leaving 1..4 or 9 behind).  plan->clenshaw = 1: the flux kinds, whose
+// launches run at memcpy rate and gain the plane they no longer move (config 3: +10 %); 2: every scalar kind (the land-mask
+// kernel is bound by its instruction stream and gains nothing: 93 -> 92-95 us per launch).  Needs the isolated cells fixed up
+// by k_land_fix when there is land (land_ok).
+static bool land_ok(const gcmf_plan *pl, int n_steps);
+static int clenshaw_cut(const gcmf_plan *pl, int n_steps, int *depths, int max_depths) {
+  if (!pl || pl->ncomp != 1 || !(pl->clenshaw >= 2 || (pl->clenshaw == 1 && pl->kind == K_FLUX))) return 0;
+  if (!pl->ring || !pl->zero_row || pl->d.dtype != GCMF_F64 || pl->g.fold || pl->multi_s < 8 || !multi_supported(pl, 8)) return 0;
+  if (pl->n_land > 0 && !land_ok(pl, n_steps)) return 0;
+  if (!(n_steps >= 10 || (n_steps >= 5 && n_steps <= 8))) return 0;
+  int n = 0, left = n_steps;
+  while (left > 0) {
+    int S = 0;
+    for (int cand = 8; cand >= 5 && !S; --cand) {
+      const int rest = left - cand;
+      if (rest == 0 || (rest >= 5 && rest != 9)) S = cand;
+    }
+    if (!S || n >= max_depths) return 0;
+    depths[n++] = S;
+    left -= S;
+  }
+  return n;
+}
+
+int gcmf_clenshaw_cut(const gcmf_plan *pl, int n_steps, int *depths, int max_depths) {
+  if (!pl || !depths || max_depths < 1) return 0;
+  return clenshaw_cut(pl, n_steps, depths, max_depths);
+}
+
+static int launch_ringc(gcmf_plan *pl, const MultiArgs &m, hipStream_t s) {
+  switch (pl->kind) {
+    case K_REG: return launch_ringc_reg(pl, m, s);
+    case K_MASK: return launch_ringc_maskz(pl, m, s);
+    case K_FLUX: return launch_ringc_flux(pl, m, s);
+    default: break;
+  }
+  set_error("k_ringc: plan is not a scalar kind");
+  return GCMF_ERR_INVALID_ARG;
+}
+
 int gcmf_cheb_multi(gcmf_plan *pl, const void *u, const void *v, void *uo, void *vo, const void *fbar_in,
                     void *fbar_out, const double *pk, int S, double p0, double c, uint32_t mode, uint32_t flags,
                     int64_t nbatch, int64_t row_lo, int64_t row_hi, void *stream) {
+  if (pl && pk && (mode & GCMF_STEP_CLENSHAW)) {
+    // S levels of the backward evaluation on rows [row_lo, row_hi): (u, v) = (b_{k+1}, b_{k+2}) (FIRST: unused, the launch forms
+    // b_n = p0 * f itself), fbar_in = the constant input f, pk[t] = coefficient of level t + 1, LAST: fbar_out = the result
+    const bool first = mode & GCMF_STEP_FIRST, last = mode & GCMF_STEP_LAST;
+    int probe[1];
+    if (pl->d.dtype != GCMF_F64 || pl->g.fold || pl->ncomp != 1 || S < 5 || S > 8 || !pl->ring || !pl->zero_row ||
+        !(clenshaw_cut(pl, S, probe, 1) == 1)) {
+      set_error("gcmf_cheb_multi: the backward evaluation is not available for this plan / depth %d", S);
+      return GCMF_ERR_UNSUPPORTED;
+    }
+    if (!fbar_in || (!first && (!u || !v)) || (!last && (!uo || !vo)) || (last && !fbar_out) || (uo && (uo == u || uo == v)) ||
+        (vo && (vo == u || vo == v)) || row_lo < 0 || row_hi > pl->rows_alloc || row_lo > row_hi) {
+      set_error("gcmf_cheb_multi: missing or aliased buffers / bad row range for the backward evaluation");
+      return GCMF_ERR_INVALID_ARG;
+    }
+    std::lock_guard<std::mutex> lk(pl->mu);
+    GCMF_HIP(hipSetDevice(pl->d.device));
+    MultiArgs m{};
+    m.u0 = u; m.v0 = v; m.uo = uo; m.vo = vo; m.fb_in = fbar_in; m.fb_out = fbar_out;
+    for (int t = 0; t < S; ++t) m.pk[t] = pk[t];
+    m.p0 = p0; m.c = c; m.S = S; m.first = first; m.last = last; m.nbatch = nbatch; m.row_lo = (int)row_lo; m.row_hi = (int)row_hi;
+    return launch_ringc(pl, m, (hipStream_t)stream);
+  }
   if (!pl || !u || !fbar_out || !pk) {
     set_error("gcmf_cheb_multi: null argument");
     return GCMF_ERR_INVALID_ARG;
@@ -742,7 +808,39 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
     ++launches;
   } else {
     const void *x0[2] = {din[0], din[1]};
-    if (use_multi) {
+    int depths[1024];
+    const int n_clen = (use_multi && !fb32) ? clenshaw_cut(pl, n_steps, depths, 1024) : 0;
+    if (n_clen > 0) {
+      // Backward (Clenshaw) evaluation, gcmf_ringc_impl.hpp: state (b_{k+1}, b_{k+2}) in a pool of four planes, the constant
+      // input read by every launch, no fbar planes.  The first launch forms b_n = p[n] f as it loads f; level l = 1..n uses
+      // p[n - l]; the last launch writes the result.
+      void *pool[4] = {A[0], B[0], Cb[0], Db[0]};
+      const void *u = nullptr, *v = nullptr;
+      int lvl = 1;
+      for (int q = 0; q < n_clen; ++q) {
+        const int S = depths[q];
+        void *fr[2] = {nullptr, nullptr};
+        int nf = 0;
+        for (int q = 0; q < 4 && nf < 2; ++q)
+          if (pool[q] != u && pool[q] != v) fr[nf++] = pool[q];
+        MultiArgs m{};
+        m.u0 = u; m.v0 = v; m.uo = fr[0]; m.vo = fr[1];
+        m.fb_in = din[0]; m.fb_out = dout[0];
+        m.first = (q == 0); m.last = (q == n_clen - 1); m.S = S; m.fb_is_f32 = 0;
+        for (int t = 0; t < S; ++t) m.pk[t] = p[n_steps - (lvl + t)];
+        m.p0 = p[n_steps]; m.c = c; m.nbatch = nbatch; m.row_lo = 0; m.row_hi = rows;
+        if ((rc = dom_begin(pl, s))) return rc;
+        if ((rc = launch_ringc(pl, m, s))) return rc;
+        if ((rc = dom_end(pl, s))) return rc;
+        ++launches;
+        u = fr[0]; v = fr[1];
+        lvl += S;
+      }
+      if (pl->n_land > 0) {  // the isolated cells' own polynomial (forward recurrence, as the reference computes it)
+        if ((rc = ensure_dev_p(pl, p, n_steps, s))) return rc;
+        if ((rc = launch_land_fix(pl, din[0], dout[0], pl->dev_p, n_steps, c, 0, nbatch, s))) return rc;
+      }
+    } else if (use_multi) {
       // Temporally blocked schedule (scalar kinds): each launch advances S steps and reads/writes every plane
       // once.  prepare/finalize are fused into the first / last launch.  State buffers rotate through a pool
       // of four because a launch may not overwrite the planes its neighbours' halos are still reading.

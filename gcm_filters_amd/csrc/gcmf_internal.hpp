@@ -163,6 +163,7 @@ struct gcmf_plan {
   unsigned *ring_nfb = nullptr;    // device counter behind gcmf_ring_fallbacks (lives behind zero_row)
   const void *zero_row = nullptr;  // nx zeros: what rows beyond a closed boundary read as coefficients / mask bits (k_ring)
   int band_rpw = 0;       // rows per wave of the tripole band steps (0 = default)
+  int clenshaw = 1;       // backward (Clenshaw) evaluation, k_ringc: 0 off, 1 the flux kinds (default), 2 every scalar kind; env GCMF_CLENSHAW
   double *dev_p = nullptr;   // p[0..n_steps] of the last filter, for k_land_fix
   size_t dev_p_n = 0;
   std::vector<double> host_p;
@@ -186,6 +187,11 @@ int launch_vector_step(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 int launch_scalar_multi(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 bool flux_multi2_supported(const gcmf_plan *pl, int S);
 bool ring_supported(const gcmf_plan *pl, const MultiArgs &a);
+// backward (Clenshaw) evaluation, gcmf_ringc_impl.hpp: one launch of S = 5..8 levels; a.fb_in = the constant input f, a.fb_out =
+// the result (last launch), a.pk[t] = the coefficient of level t + 1 of this launch
+int launch_ringc_reg(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
+int launch_ringc_maskz(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
+int launch_ringc_flux(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_flux_multi2(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_cgrid_stream(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 bool cgrid_stream_supported(const gcmf_plan *pl, const StepArgs &a);

@@ -1,0 +1,407 @@
+// k_ringc: the static-ring kernel (gcmf_ring_impl.hpp) evaluating the filter polynomial BACKWARDS (Clenshaw):
+//
+//     b_{n+1} = b_{n+2} = 0,   b_k = p_k f + 2 A(b_{k+1}) - b_{k+2}  (k = n .. 1),   result = p_0 f + A(b_1) - b_2,
+//     A(x) = -x - c L(x)                                   == sum_k p_k T_k(A) f  of reference filter.py:162-212
+//
+// The forward recurrence carries three planes per field (T_{k-1}, T_{k-2}, fbar: fbar is read AND written by every launch); the
+// backward one carries two (b_{k+1}, b_{k+2}) and re-reads the constant input f: one plane less per launch (8 instead of 9 for
+// the flux kinds, 5 + 1 byte instead of 6 + 1 byte for the land-mask kinds), and the kernels run at the rate the memory
+// system gives.  Same stencils, same time skewing, rings, halo geometry and launch structure as k_ring:
+// b_n = p_n f needs no stencil: the first launch forms it as it loads f (its "input state" is (b_n, 0)); "level" l = 1 .. n of a
+// filter produces b_{n-l}, level n the result (its 2 A(.) is A(.)); the n levels are cut into launches of S = 5 .. 8 -- as
+// many Laplacian applications and launches as the forward recurrence.
+//
+//   * same NaN semantics as the reference: the stencil sees nan_to_num of its operands, "-x", b_{k+2} and p_k f keep a NaN, so
+//     an input NaN in a wet cell stays in that cell's state and result and its column of the stencil is zero -- exactly
+//     what happens to T_k in the forward recurrence.  The fast march only WATCHES (last level); a strip that meets a
+//     non-finite value is redone by the SAME march with nan_to_num on the stencil operands (SANI = true), which needs no
+//     other kernel: no fbar is accumulated, so a strip is always re-computable from its inputs.
+//   * isolated (land) cells: f is masked to zero as it is loaded (every launch: +1 byte per cell), so they stay zero in the
+//     state; k_land_fix writes their own polynomial (forward recurrence, as the reference computes it) at the end.
+//   * prepare() / finalize() of the area-weighted types: f * area as it is loaded, result / area as it is stored.
+//   * rounding differs from the forward recurrence in the last bits (measured <= 3e-15 relative): results are NOT bit-identical
+//     with the single-step kernels; they are bit-identical across different cuts of the levels into launches.
+//
+// f64 state only (the BASELINE scalar configs); not for tripolar plans (the fold band runs forward single steps).
+#pragma once
+#include "gcmf_ring_impl.hpp"
+
+namespace gcmf {
+
+// one march of a strip; returns whether this wave met a non-finite value in its last level (wave-uniform)
+template <typename T, int KIND, int S, bool FIRST, bool SANI>
+__device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid) {
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int W = 64 * VEC;
+  constexpr int M = (S + VEC - 1) / VEC * VEC;
+  constexpr int WI = W - 2 * M;
+  constexpr int R = RingGeom::R, D = RingGeom::D, RU = RingGeom::RU, RV = RingGeom::RV;
+  static_assert(R >= S + D && R % 3 == 0 && R % RU == 0 && R % RV == 0 && RU >= 3 + D && RV >= 1 + D, "ring periods");
+  constexpr bool FLUX = (KIND == K_FLUX), MASK = (KIND == K_MASKZ);
+  constexpr bool WATCH = (KIND != K_REG) && !SANI;  // K_REG has no nan_to_num in the reference: NaN spreads by plain arithmetic
+  constexpr bool FUSED = FLUX;
+
+  const int lane = threadIdx.x & 63;
+  const int wx = wid % P.nwx, st = wid / P.nwx;
+  const int nx = P.nx, rows = P.rows;
+  const int a = P.out_lo + st * P.H;
+  const int b = min(a + P.H, P.out_hi);
+  const long long boff = (long long)blockIdx.y * P.bstride;
+  const int pos = wx * WI - M + lane * VEC;
+  int col_s = pos % nx;
+  if (col_s < 0) col_s += nx;
+  const unsigned col = (unsigned)col_s;
+  const unsigned colT = col * (unsigned)sizeof(T);
+  const bool keep = (lane * VEC >= M) && (lane * VEC < W - M) && (pos < nx);
+  const T c = (T)P.c;
+  const bool last = P.last;
+
+  T G0[RU][VEC];     // rows of b_{k+1} (the newer input state), slot = (row - r_begin) mod RU
+  T G[S][3][VEC];    // G[t], t = 1..S-1: rows of level t, slot = (row - r_begin) mod 3
+  T FN[S + 1][VEC];  // K_FLUX: carried north-face flux per level
+  T cE[R][VEC], cN[R][VEC], ra[R][VEC];
+  unsigned B[R];     // K_MASKZ: mask bytes
+  T Ff[R][VEC];      // rows of the constant input f (prepared: * area, land -> 0), slot as the coefficient rows
+  unsigned Zc[R];    // land bits of those rows
+  T ARc[R][VEC];     // area of those rows (area-weighted types)
+  T V[RV][VEC];      // rows of b_{k+2}
+  unsigned Zu[RU];   // FIRST: land bits of the rows of f that become b_n (slots of G0)
+  T ARu[RU][VEC];    // FIRST, area-weighted types: their area
+#pragma unroll
+  for (int t = 0; t < S; ++t) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) G[t][0][k] = G[t][1][k] = G[t][2][k] = FN[t + 1][k] = T(0);
+  }
+#pragma unroll
+  for (int l = 0; l < RU; ++l) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) G0[l][k] = ARu[l][k] = T(0);
+    Zu[l] = 0u;
+  }
+#pragma unroll
+  for (int l = 0; l < R; ++l) {  // rings start at zero (see k_ring: the NaN watch also sees the levels of the first rows)
+    B[l] = 0u;
+    Zc[l] = 0u;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) cE[l][k] = cN[l][k] = ra[l][k] = Ff[l][k] = ARc[l][k] = T(0);
+  }
+#pragma unroll
+  for (int l = 0; l < RV; ++l) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) V[l][k] = T(0);
+  }
+
+  const bool wrap = P.wrap;
+  const int r_begin = a - S, r_last = b + S - 1;
+  int cj, cj_prev;
+  bool cout_, cout_prev;
+  {
+    const int r = r_begin - 1;
+    const bool lo = r < 0, hi = r >= rows;
+    cj = wrap ? (r + (lo ? rows : 0) - (hi ? rows : 0)) : (lo ? 0 : (hi ? rows - 1 : r));
+    cout_ = !wrap && (lo || hi);
+    cj_prev = cj;
+    cout_prev = cout_;
+  }
+  int cr = r_begin - 1;
+  auto advance = [&]() {
+    cj_prev = cj;
+    cout_prev = cout_;
+    ++cr;
+    const int jn = cj + ((wrap || cr > 0) ? 1 : 0);
+    const bool hit = (jn >= rows);
+    cj = hit ? (wrap ? 0 : rows - 1) : jn;
+    cout_ = !wrap && (cr < 0 || cr >= rows);
+  };
+  const T *fplane = P.fb_in + boff;  // the constant input f (Clenshaw has no fbar: the pointer slot is reused)
+  const bool has_land = P.lbits != nullptr;
+  const uint8_t *zbase = has_land ? P.lbits : reinterpret_cast<const uint8_t *>(P.fb_in);  // (valid bytes, ignored)
+  const bool weigh = !FLUX && P.area_weighted;
+  const T *abase = weigh ? P.area : P.fb_in;  // (an unconditional load, ignored when there is no area)
+
+  auto load_u = [&](auto slot_c) {  // the cursor's row of b_{k+1}; in a first launch that is b_n = p_n f, formed from the row of f
+    constexpr int sl = decltype(slot_c)::value;
+    const long long rcur = (long long)(cj * nx);
+    if constexpr (!FIRST) {
+      mload<T, VEC>(G0[sl], lane_ptr(P.u0 + boff + rcur, colT));
+    } else {
+      mload<T, VEC>(G0[sl], lane_ptr(fplane + rcur, colT));
+      Zu[sl] = *reinterpret_cast<const unsigned short *>(lane_ptr(zbase + rcur, col));
+      if constexpr (!FLUX) mload<T, VEC>(ARu[sl], lane_ptr(abase + rcur, colT));
+    }
+  };
+  auto load_centre = [&](auto slot_c, auto vslot_c) {  // what travels with the row before it: b_{k+2}, f, coefficients / mask bits
+    constexpr int sl = decltype(slot_c)::value;
+    constexpr int vs = decltype(vslot_c)::value;
+    const bool out_c = cout_prev;
+    const long long rc = (long long)(cj_prev * nx);
+    if constexpr (FLUX) {
+      const T *pE = out_c ? P.zrow : P.cE + rc;
+      const T *pN = out_c ? P.zrow : P.cN + rc;
+      const T *pA = out_c ? P.zrow : P.ra + rc;
+      mload<T, VEC>(cE[sl], lane_ptr(pE, colT));
+      mload<T, VEC>(cN[sl], lane_ptr(pN, colT));
+      mload<T, VEC>(ra[sl], lane_ptr(pA, colT));
+    }
+    if constexpr (MASK) {
+      const uint8_t *mp = lane_ptr(out_c ? (const uint8_t *)P.zrow : P.mbits + rc, col);
+      B[sl] = *reinterpret_cast<const unsigned short *>(mp);
+    }
+    mload<T, VEC>(Ff[sl], lane_ptr(fplane + rc, colT));
+    Zc[sl] = *reinterpret_cast<const unsigned short *>(lane_ptr(zbase + rc, col));
+    if constexpr (!FLUX) mload<T, VEC>(ARc[sl], lane_ptr(abase + rc, colT));
+    if constexpr (!FIRST) mload<T, VEC>(V[vs], lane_ptr(P.v0 + boff + rc, colT));  // a first launch: b_{n+1} = 0
+  };
+
+  bool bad = false;
+  T out_v[VEC], out_u[VEC];
+
+  auto level = [&](auto tt, auto ph_c) {
+    constexpr int t = decltype(tt)::value;
+    constexpr int ph = decltype(ph_c)::value;
+    constexpr int sS = pmod(ph - t - 1, 3), sC = pmod(ph - t, 3), sN = pmod(ph - t + 1, 3);
+    constexpr int sl = pmod(ph - t + 1, R);
+    const T(&rS)[VEC] = (t == 1) ? G0[pmod(ph - 2, RU)] : G[t >= 2 ? t - 1 : 1][sS];
+    const T(&rC)[VEC] = (t == 1) ? G0[pmod(ph - 1, RU)] : G[t >= 2 ? t - 1 : 1][sC];
+    const T(&rN)[VEC] = (t == 1) ? G0[pmod(ph, RU)] : G[t >= 2 ? t - 1 : 1][sN];
+    // what the stencil sees: its operands through nan_to_num in the redo pass (kernels.py:175, 300), as they are otherwise
+    T gS[VEC], gC[VEC], gN[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      gS[k] = SANI ? msan(rS[k]) : rS[k];
+      gC[k] = SANI ? msan(rC[k]) : rC[k];
+      gN[k] = SANI ? msan(rN[k]) : rN[k];
+    }
+    const T ev = from_upper_lane0(gC[0]);
+    T fev[VEC], few = T(0), wv = T(0);
+    if constexpr (FLUX) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const T xE = (k == VEC - 1) ? ev : gC[k < VEC - 1 ? k + 1 : k];
+        fev[k] = (xE - gC[k]) * cE[sl][k];
+      }
+      few = from_lower_lane0(fev[VEC - 1]);
+    } else {
+      wv = from_lower_lane0(gC[VEC - 1]);
+    }
+    // the last level of the last launch is the result  p_0 f + A(b_1) - b_2: A, not 2 A
+    const T two = (last && t == S) ? T(1) : T(2);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const T xC = gC[k];
+      T L;
+      if constexpr (FLUX) {
+        const T fe = fev[k];
+        const T fw = (k == 0) ? few : fev[k > 0 ? k - 1 : 0];
+        const T fn = (gN[k] - xC) * cN[sl][k];
+        L = (fe - fw + fn - FN[t][k]) * ra[sl][k];
+        FN[t][k] = fn;
+      } else {
+        const T xW = (k == 0) ? wv : gC[k > 0 ? k - 1 : 0];
+        const T xE = (k == VEC - 1) ? ev : gC[k < VEC - 1 ? k + 1 : k];
+        if constexpr (MASK) {
+          const unsigned bb = (B[sl] >> (8 * k)) & 0xFFu;
+          const T wf = (T)(bb >> 5);
+          L = -wf * xC + xE;
+          L = L + xW;
+          L = L + gN[k];
+          L = L + gS[k];
+          L = (bb & 1u) ? L : T(0);
+        } else {
+          L = T(-4) * xC + xE;
+          L = L + xW;
+          L = L + gN[k];
+          L = L + gS[k];
+        }
+      }
+      const T av = cheb_a<FUSED>(rC[k], c, L);  // "-x" takes the raw value: a NaN stays in its cell (filter.py:166-175)
+      const T x2 = (t == 1) ? V[ph % RV][k] : (t == 2 ? G0[pmod(ph - 2, RU)][k] : G[t >= 3 ? t - 2 : 1][sC][k]);
+      T tk;
+      if (FUSED) {
+        tk = rfma(two, av, -x2);
+        tk = rfma((T)P.pk[t - 1], Ff[sl][k], tk);
+      } else {
+        tk = two * av - x2;
+        tk = tk + (T)P.pk[t - 1] * Ff[sl][k];
+      }
+      if (t < S) G[t < S ? t : 0][sC][k] = tk;
+      if (t == S - 1) out_v[k] = tk;
+      if (t == S) {
+        out_u[k] = tk;
+        if (WATCH) bad = bad || !(mabs(tk) <= MLim<T>::big());
+      }
+    }
+  };
+
+  auto phase = [&](auto ph_c, int r) {
+    constexpr int ph = decltype(ph_c)::value;
+    advance();
+    load_centre(ic<(ph + D) % R>{}, ic<(ph + D) % RV>{});
+    load_u(ic<(ph + D) % RU>{});
+    if constexpr (FIRST) {  // the row of f that has just arrived becomes a row of b_n = p_n f (prepared, land out)
+      constexpr int su = ph % RU;
+      const T pn = (T)P.p0;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        if constexpr (!FLUX) G0[su][k] = weigh ? G0[su][k] * ARu[su][k] : G0[su][k];
+        G0[su][k] = (!has_land || ((Zu[su] >> (8 * k)) & 1u)) ? pn * G0[su][k] : T(0);
+      }
+    }
+    {  // the f row level 1 uses now: prepare() and land out (once per row; the later levels find it that way in the ring)
+      constexpr int s1 = ph % R;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        if constexpr (!FLUX) Ff[s1][k] = weigh ? Ff[s1][k] * ARc[s1][k] : Ff[s1][k];
+        Ff[s1][k] = (!has_land || ((Zc[s1] >> (8 * k)) & 1u)) ? Ff[s1][k] : T(0);
+      }
+    }
+    level(ic<1>{}, ph_c);
+    if constexpr (S >= 2) level(ic<2>{}, ph_c);
+    if constexpr (S >= 3) level(ic<3>{}, ph_c);
+    if constexpr (S >= 4) level(ic<4>{}, ph_c);
+    if constexpr (S >= 5) level(ic<5>{}, ph_c);
+    if constexpr (S >= 6) level(ic<6>{}, ph_c);
+    if constexpr (S >= 7) level(ic<7>{}, ph_c);
+    if constexpr (S >= 8) level(ic<8>{}, ph_c);
+    const int ju = r - S;
+    if (ju >= a && ju < b) {  // wave-uniform
+      const long long off = boff + (long long)ju * nx;
+      if (keep) {
+        if (!last) {
+          mstore<T, VEC>(lane_ptr(P.uo + off, colT), out_u);
+        } else {
+          if (!FLUX && P.area_weighted) {  // finalize(): / area (kernels.py:103-104)
+            T ar[VEC];
+            mload<T, VEC>(ar, lane_ptr(P.area + (long long)ju * nx, colT));
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) out_u[k] = out_u[k] / ar[k];
+          }
+          mstore<T, VEC>(lane_ptr(P.fb_out + off, colT), out_u);
+        }
+      }
+    }
+    const int jv = r - S + 1;
+    if (!last && jv >= a && jv < b) {
+      T *rowp = P.vo + boff + (long long)jv * nx;
+      if (keep) mstore<T, VEC>(lane_ptr(rowp, colT), out_v);
+    }
+  };
+
+  advance();
+  load_centre(ic<0>{}, ic<0>{});
+  load_u(ic<0>{});
+  advance();
+  load_centre(ic<1>{}, ic<1>{});
+  load_u(ic<1>{});
+  advance();
+  load_centre(ic<2>{}, ic<2>{});
+  load_u(ic<2>{});
+  static_assert(D == 3, "prologue");
+  const int niter = (r_last - r_begin + 1 + R - 1) / R * R;
+  for (int i0 = 0; i0 < niter; i0 += R) {
+    const int r0 = r_begin + i0;
+    phase(ic<0>{}, r0);
+    phase(ic<1>{}, r0 + 1);
+    phase(ic<2>{}, r0 + 2);
+    phase(ic<3>{}, r0 + 3);
+    phase(ic<4>{}, r0 + 4);
+    phase(ic<5>{}, r0 + 5);
+    phase(ic<6>{}, r0 + 6);
+    phase(ic<7>{}, r0 + 7);
+    phase(ic<8>{}, r0 + 8);
+    phase(ic<9>{}, r0 + 9);
+    phase(ic<10>{}, r0 + 10);
+    phase(ic<11>{}, r0 + 11);
+    if (WATCH && __any(bad)) return true;
+  }
+  return false;
+}
+
+template <typename T, int KIND, int S, bool FIRST>
+__global__ __launch_bounds__(256, 1) void k_ringc(const MultiP<T, T> P) {
+  int bx = blockIdx.x;
+  if (P.xcd_per > 0 && bx < 8 * P.xcd_per) bx = (bx & 7) * P.xcd_per + (bx >> 3);
+  const int wid = bx * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wid >= P.nwaves) return;
+  if (ringc_march<T, KIND, S, FIRST, false>(P, wid)) {
+    if constexpr (KIND != K_REG) {
+      if (P.nfb && (threadIdx.x & 63) == 0) atomicAdd(P.nfb, 1u);  // instrumentation: gcmf_ring_fallbacks
+      ringc_march<T, KIND, S, FIRST, true>(P, wid);                 // the same strip again, operands through nan_to_num
+    }
+  }
+}
+
+template <typename T, int KIND, int S, bool FIRST>
+static int launch_ringc_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int W = 64 * VEC;
+  constexpr int M = (S + VEC - 1) / VEC * VEC;
+  constexpr int WI = W - 2 * M;
+  constexpr int R = RingGeom::R;
+  const Geom &g = pl->g;
+  MultiP<T, T> P;
+  P.u0 = (const T *)a.u0;
+  P.v0 = (const T *)a.v0;
+  P.uo = (T *)a.uo;
+  P.vo = (T *)a.vo;
+  P.fb_in = (const T *)a.fb_in;   // the constant input f
+  P.fb_out = (T *)a.fb_out;       // the result (last launch)
+  P.cE = (const T *)g.coef[0];
+  P.cN = (const T *)g.coef[1];
+  P.ra = (const T *)g.coef[2];
+  P.zrow = (const T *)pl->zero_row;
+  P.nfb = pl->ring_nfb;
+  P.mbits = g.mbits;
+  P.lbits = (pl->n_land > 0) ? pl->lbits : nullptr;
+  P.area = (const T *)g.area;
+  P.nx = g.nx;
+  P.rows = g.rows;
+  P.out_lo = a.row_lo;
+  P.out_hi = a.row_hi;
+  const int nrows = a.row_hi - a.row_lo;
+  if (nrows <= 0 || a.nbatch <= 0) return GCMF_OK;
+  P.nwx = (g.nx + WI - 1) / WI;
+  int H = pl->strip_rows;
+  if (H <= 0) {
+    long long want = 1024 / ((long long)P.nwx * a.nbatch);
+    if (want < 1) want = 1;
+    H = (int)((nrows + want - 1) / want);
+    if (H < 2 * S) H = 2 * S;
+    H += (R - (H + 2 * S) % R) % R;
+  }
+  if (H > nrows) H = nrows;
+  P.H = H;
+  P.nstrips = (nrows + H - 1) / H;
+  P.nwaves = P.nwx * P.nstrips;
+  P.wrap = g.south_wrap && g.north_wrap;
+  P.first = FIRST ? 1 : 0;
+  P.last = a.last;
+  P.area_weighted = (KIND == K_FLUX) ? 0 : g.area_weighted;
+  P.bstride = (long long)g.rows * g.nx;
+  for (int t = 0; t < MAX_S; ++t) P.pk[t] = t < S ? a.pk[t] : 0.0;
+  P.p0 = a.p0;
+  P.c = a.c;
+  dim3 block(256), grid((P.nwaves + 3) / 4, (unsigned)a.nbatch);
+  P.xcd_per = pl->xcd_remap ? (int)(grid.x / 8) : 0;
+  hipLaunchKernelGGL((k_ringc<T, KIND, S, FIRST>), grid, block, 0, s, P);
+  GCMF_HIP(hipGetLastError());
+  note_kernel(pl, std::string("gcmf::k_ringc<") + tyname<T>() + ", " + std::to_string(KIND) + ", " + std::to_string(S) + ", " +
+                      (FIRST ? "true" : "false") + ">", S);
+  return GCMF_OK;
+}
+
+template <int KIND> static int launch_ringc_kind(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
+  if (pl->d.dtype != GCMF_F64) {
+    set_error("k_ringc: f64 plans only");
+    return GCMF_ERR_UNSUPPORTED;
+  }
+  switch (a.S) {
+    case 5: return a.first ? launch_ringc_sf<double, KIND, 5, true>(pl, a, s) : launch_ringc_sf<double, KIND, 5, false>(pl, a, s);
+    case 6: return a.first ? launch_ringc_sf<double, KIND, 6, true>(pl, a, s) : launch_ringc_sf<double, KIND, 6, false>(pl, a, s);
+    case 7: return a.first ? launch_ringc_sf<double, KIND, 7, true>(pl, a, s) : launch_ringc_sf<double, KIND, 7, false>(pl, a, s);
+    case 8: return a.first ? launch_ringc_sf<double, KIND, 8, true>(pl, a, s) : launch_ringc_sf<double, KIND, 8, false>(pl, a, s);
+  }
+  return GCMF_ERR_INVALID_ARG;
+}
+
+}  // namespace gcmf

@@ -107,7 +107,7 @@ class _Block:
             for r, gj, n in self._runs():
                 self.X[r: r + n].copy_(t.from_numpy(field[gj: gj + n]), non_blocking=True)
 
-    def run(self, p: np.ndarray, c: float, out_f32: bool):
+    def run(self, p: np.ndarray, c: float, out_f32: bool, cut: Sequence[int] = ()):
         """Enqueue the whole polynomial on the current stream (the schedule of gcmf_apply, csrc/gcmf_api.hip)."""
         t = self.torch
         plan, fo, ro = self.plan, self.fo, self.ro
@@ -116,6 +116,25 @@ class _Block:
         if out_f32 and self.O32 is None:
             self.O32 = t.empty((self.rows, self.nx), dtype=t.float32, device=self.X.device)
         O = self.O32 if out_f32 else self.O
+        if cut:   # the backward evaluation gcmf_apply uses on the one-plan path for this polynomial: the same levels on the block
+            u = v = None
+            valid, lvl = self.ghost, 1
+            for q, S in enumerate(cut):
+                free = [b for b in self.pool if b is not u and b is not v]
+                v_out = valid - S
+                lo = fo - (v_out if self.gs else 0)
+                hi = fo + ro + (v_out if self.gn else 0)
+                last = (q == len(cut) - 1)
+                mode = _lib.STEP_CLENSHAW | (_lib.STEP_FIRST if q == 0 else 0) | (_lib.STEP_LAST if last else 0)
+                plan.cheb_multi(0 if u is None else u.data_ptr(), 0 if v is None else v.data_ptr(), free[0].data_ptr(),
+                                free[1].data_ptr(), self.X.data_ptr(), O.data_ptr(), p[n - lvl - S + 1: n - lvl + 1][::-1], p[n], c,
+                                mode, 1, lo, hi, stream=stream)
+                u, v = free[0], free[1]
+                valid = v_out
+                lvl += S
+            if self.has_land:
+                plan.land_fix(p, c, [self.X.data_ptr()], [O.data_ptr()], 1, out_f32=False, stream=stream)
+            return
         Fc, Fn = self.F
         u, v = self.X, None
         valid, k, land_zeroed = self.ghost, 1, False
@@ -152,10 +171,11 @@ class _Block:
 
 class RowBlockPipeline:
     def __init__(self, grid_type: int, dtype: int, ny: int, nx: int, host_planes: Sequence[np.ndarray], device: int,
-                 n_steps: int, nblocks: int, skip_kappa_one: bool = False):
+                 n_steps: int, nblocks: int, skip_kappa_one: bool = False, cut: Sequence[int] = ()):
         import torch
         self.torch = torch
         self.n_steps, self.nblocks, self.device = int(n_steps), int(nblocks), device
+        self.cut = list(cut)   # launch depths of the backward evaluation the ONE-plan path uses ([]: forward recurrence)
         self.lock = threading.Lock()
         npdt = _lib.np_dtype(dtype)
         with torch.cuda.device(device):
@@ -177,6 +197,9 @@ class RowBlockPipeline:
                 raise
             del dev
             self.ok = all(blk.ok for blk in self.blocks)
+            if self.cut:   # the block plans evaluate the way the one-plan path does (whatever their own default would be)
+                for blk in self.blocks:
+                    blk.plan.set_tuning(multi_s=8, clenshaw=2)
             self.s_up, self.s_comp, self.s_down = (torch.cuda.Stream(device) for _ in range(3))
         self.worker = ThreadPoolExecutor(1, thread_name_prefix="gcmf-d2h")
 
@@ -208,7 +231,7 @@ class RowBlockPipeline:
                     ev_up = self.s_up.record_event()
                 with t.cuda.stream(self.s_comp):
                     self.s_comp.wait_event(ev_up)
-                    blk.run(p, c, out_f32)
+                    blk.run(p, c, out_f32, self.cut)
                     ev_c = self.s_comp.record_event()
                 futs.append(self.worker.submit(self._download, blk, out, out_f32, ev_c))
             for f in futs:

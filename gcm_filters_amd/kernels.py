@@ -511,7 +511,7 @@ class _DeviceLaplacian:
                 host = [a.detach().cpu().numpy() if _is_torch(a) else np.asarray(a) for a in self._planes]
                 try:
                     pipe = host_blocks.RowBlockPipeline(self.GRID_TYPE.value, dtype, ny, nx, host, plan.device, n, nblocks,
-                                                        skip_kappa_one=self._skip_kappa_one)
+                                                        skip_kappa_one=self._skip_kappa_one, cut=plan.clenshaw_cut(n))
                 except (_lib.GcmfError, RuntimeError, MemoryError):
                     pipe = None     # e.g. not enough device memory for the extra plans and state planes: stay on the plain path
                 if pipe is not None and not pipe.ok:

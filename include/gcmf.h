@@ -77,6 +77,7 @@ typedef enum gcmf_dtype { GCMF_F32 = 0, GCMF_F64 = 1 } gcmf_dtype;
 #define GCMF_STEP_LAND_FIXED 0x8u /* gcmf_cheb_multi with GCMF_STEP_FIRST: the caller will overwrite the result of the cells
                                     gcmf_zero_land zeroes with gcmf_land_fix (or there are none), so the launch may take them as
                                     zero while it loads the field; the states it writes then satisfy GCMF_STEP_LAND_ZERO */
+#define GCMF_STEP_CLENSHAW 0x10u /* gcmf_cheb_multi: S levels of the BACKWARD evaluation of the polynomial (see gcmf_clenshaw_cut) */
 #define GCMF_STEP_LAND_ZERO 0x4u /* gcmf_cheb_multi[_vec]: the caller guarantees that the cells gcmf_zero_land zeroes are
                                     zero in both input states (lets the land-mask kernels drop their per-neighbour tests) */
 
@@ -188,6 +189,21 @@ int gcmf_cheb_step(gcmf_plan *plan, const void *const *t1, const void *const *t2
  * combination is available (vector grids, odd nx, very short grids are not).
  */
 int gcmf_multi_supported(const gcmf_plan *plan, int S);
+/*
+ * Backward (Clenshaw) evaluation of the same polynomial  sum_k p[k] T_k(A) f  (reference filter.py:162-212):
+ *   b_{n+1} = b_{n+2} = 0,  b_k = p[k] f + 2 A(b_{k+1}) - b_{k+2}  (k = n..1),  result = p[0] f + A(b_1) - b_2.
+ * The state is two planes instead of three (no fbar); every launch re-reads the constant input f: one plane less per launch.
+ * Same NaN / land semantics as the forward recurrence; results differ from it in the last bits (<= 3e-15 relative) and are
+ * identical however the levels are cut.  f64 scalar plans without a tripole fold; gcmf_apply uses it by default for the
+ * flux-form grid types (env GCMF_CLENSHAW = 0 off / 1 flux kinds / 2 all scalar kinds).
+ * gcmf_clenshaw_cut: the launch depths (each 5..8, summing to n_steps) gcmf_apply uses for this plan and n_steps -- return value
+ * = their number, 0 = it runs the forward recurrence.  A slab caller does the same with gcmf_cheb_multi and
+ * GCMF_STEP_CLENSHAW:  level l = 1..n_steps computes b_{n-l};  launch with levels l0 .. l0+S-1:  u = b_{n-l0+1}, v = b_{n-l0+2}
+ * (FIRST, l0 = 1: ignored, the launch forms b_n = p0 * f itself: pass p0 = p[n]),  fbar_in = f,  pk[t] = p[n - (l0 + t)],
+ * uo = b_{n-l0-S+1}, vo = b_{n-l0-S+2};  LAST (l0 + S - 1 = n): fbar_out = the result (finalize() applied), uo / vo unused.
+ * Isolated (land) cells are taken as zero throughout: run gcmf_land_fix on the result when gcmf_has_land(plan).
+ */
+int gcmf_clenshaw_cut(const gcmf_plan *plan, int n_steps, int *depths, int max_depths);
 int gcmf_cheb_multi(gcmf_plan *plan, const void *u, const void *v, void *uo, void *vo, const void *fbar_in,
                     void *fbar_out, const double *pk, int S, double p0, double c, uint32_t mode, uint32_t flags,
                     int64_t nbatch, int64_t row_lo, int64_t row_hi, void *stream);
@@ -262,7 +278,8 @@ int gcmf_ring_fallbacks(gcmf_plan *plan, int64_t *count);
 
 /* Tunables: rows marched per wave of the single-step kernel (0 keeps the default); XCD-aware tile order
  * (1 on, 0 off, <0 keep); temporal blocking: low byte = recurrence steps fused per HBM pass (1 = off,
- * 2..8), higher bits = rows per wave strip (0 = auto); 0 keeps the default. */
+ * 2..8), bits 8-23 = rows per wave strip (0 = auto), bits 24-27 = operand rows in flight of the general kernels, bits 28-29 =
+ * backward evaluation (1 off, 2 flux kinds, 3 all scalar kinds; 0 keep); 0 keeps the default. */
 int gcmf_set_tuning(gcmf_plan *plan, int rows_per_wave, int xcd_remap, int multi);
 
 /* Last error text of the calling thread (never NULL). */

@@ -1,0 +1,107 @@
+"""The backward (Clenshaw) evaluation of the filter polynomial (csrc/gcmf_ringc_impl.hpp; the default for the f64 flux-form grid
+types): same polynomial as the reference's forward recurrence (filter.py:162-212), two state planes instead of three.  Against
+the oracle (the reference's recurrence restated): <= 1e-12 relative, identical NaN pattern -- incl. NaN on land, NaN / inf in
+wet cells (the in-kernel redo with nan_to_num), batches, area weighting; identical bits however the levels are cut into
+launches; and the forward path for everything it does not cover."""
+import numpy as np
+import pytest
+
+from gcm_filters_amd import Filter, FilterShape, GridType, _lib, testing as T
+from gcm_filters_amd.kernels import ALL_KERNELS
+from oracle import gcmf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SCALAR_F64 = ["REGULAR", "REGULAR_AREA_WEIGHTED", "REGULAR_WITH_LAND", "REGULAR_WITH_LAND_AREA_WEIGHTED", "IRREGULAR_WITH_LAND",
+              "MOM5U", "MOM5T"]
+
+
+def _case(grid, shape, n_steps, nanland=False, nanwet=None, nb=1, fshape="TAPER"):
+    f, gv = T.scalar_case(grid, shape)
+    if nb > 1:
+        f = np.stack([f + 0.1 * i for i in range(nb)])
+    land = gv["wet_mask"] == 0 if "wet_mask" in gv else np.zeros(shape, bool)
+    if nanland:
+        f = np.where(land, np.nan, f)
+    if nanwet is not None:
+        f = f.copy()
+        wet = np.argwhere(~land)
+        for q, val in enumerate(nanwet):
+            j, i = wet[(len(wet) * (q + 1)) // (len(nanwet) + 1)]
+            f[..., j, i] = val
+    dx = T.grid_dx_min(grid, gv) if O.DIMENSIONAL[grid] else 1.0
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        flt = Filter(filter_scale=4.0 * dx, dx_min=dx, n_steps=n_steps, filter_shape=FilterShape[fshape], grid_type=GridType[grid],
+                     grid_vars=gv)
+    fs = flt.filter_spec
+    with np.errstate(all="ignore"):
+        want = O.filter_func(O.FilterSpec(fs.n_steps, fs.s_max, np.asarray(fs.p), fs.dx_min_sq), grid, f, gv)
+    plan = ALL_KERNELS[GridType[grid]](**gv)._plan(_lib.F64, shape)
+    return flt, plan, f, want
+
+
+@pytest.mark.parametrize("grid", SCALAR_F64)
+@pytest.mark.parametrize("n_steps,kwargs", [
+    (5, {}), (8, {}), (11, {}), (16, {}), (24, dict(fshape="GAUSSIAN")), (63, {}), (21, dict(nanland=True)),
+    (21, dict(nanwet=[np.nan])), (17, dict(nanwet=[np.nan, np.nan])), (15, dict(nb=3, nanland=True)),
+])
+def test_backward_evaluation_matches_the_reference_recurrence(grid, n_steps, kwargs):
+    # (+-inf in a wet cell is not a case here: nan_to_num turns it into +-DBL_MAX in the stencil and what overflows where then
+    # depends on the order of the operations -- garbage around the cell in the reference too; the forward path keeps the
+    # reference's order for the regular / land-mask kinds, which stay on it by default, tests/test_gpu_parity.py)
+    flt, plan, f, want = _case(grid, (150, 384), n_steps, **kwargs)
+    try:
+        plan.set_tuning(multi_s=8, clenshaw=2)          # every scalar kind (the default covers the flux kinds only)
+        assert plan.clenshaw_cut(n_steps) and sum(plan.clenshaw_cut(n_steps)) == n_steps
+        plan.ring_fallbacks()
+        got = flt.apply(f)
+        assert "k_ringc<" in plan.last_kernel()
+        nfb = plan.ring_fallbacks()
+    finally:
+        plan.set_tuning(multi_s=8, clenshaw=1)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.nanmax(np.abs(got - want)) <= 1e-12 * np.nanmax(np.abs(want))
+    if "nanwet" in kwargs and grid not in ("REGULAR", "REGULAR_AREA_WEIGHTED"):
+        assert 0 < nfb < 60      # the strips around the cells were redone inside the kernel (nan_to_num on the stencil operands)
+    elif not (grid.startswith("MOM5") and kwargs.get("nanland")):   # MOM5: land cells with an open face keep their NaN in the state
+        assert nfb == 0
+
+
+@pytest.mark.parametrize("grid", ["IRREGULAR_WITH_LAND", "REGULAR_WITH_LAND", "REGULAR"])
+def test_same_bits_however_the_levels_are_cut(grid):
+    """strip height and workgroup order change which wave computes what, not the arithmetic of a cell"""
+    flt, plan, f, want = _case(grid, (260, 520), 29, nanland=True)
+    outs = []
+    try:
+        for strip, xcd in ((0, 1), (24, 0), (40, 1)):
+            plan.set_tuning(multi_s=8, strip_rows=strip, xcd_remap=xcd, clenshaw=2)
+            outs.append(flt.apply(f))
+            assert "k_ringc<" in plan.last_kernel()
+    finally:
+        plan.set_tuning(multi_s=8, strip_rows=0, xcd_remap=1, clenshaw=1)
+    assert np.array_equal(outs[0], outs[1], equal_nan=True) and np.array_equal(outs[0], outs[2], equal_nan=True)
+
+
+def test_default_is_backward_for_flux_kinds_and_forward_for_the_rest():
+    for grid, backward in (("IRREGULAR_WITH_LAND", True), ("MOM5U", True), ("REGULAR_WITH_LAND", False), ("REGULAR", False),
+                           ("TRIPOLAR_POP_WITH_LAND", False)):
+        flt, plan, f, want = _case(grid, (120, 256), 16)
+        got = flt.apply(f)
+        assert ("k_ringc<" in plan.last_kernel()) == backward, (grid, plan.last_kernel())
+        assert bool(plan.clenshaw_cut(16)) == backward
+        assert np.nanmax(np.abs(got - want)) <= 1e-12 * np.nanmax(np.abs(want))
+    # polynomial lengths that cannot be cut into launches of 5..8, f32 state: the forward recurrence
+    flt, plan, f, want = _case("IRREGULAR_WITH_LAND", (120, 256), 9)
+    assert plan.clenshaw_cut(9) == [] and plan.clenshaw_cut(4) == [] and plan.clenshaw_cut(10) == [5, 5] and plan.clenshaw_cut(63) == [8] * 7 + [7]
+    got = flt.apply(f)
+    assert "k_ringc<" not in plan.last_kernel()
+    assert np.nanmax(np.abs(got - want)) <= 1e-12 * np.nanmax(np.abs(want))
+    f32, gv = T.scalar_case("IRREGULAR_WITH_LAND", (120, 256))
+    gv = {k: v.astype("f4") for k, v in gv.items()}
+    dx = T.grid_dx_min("IRREGULAR_WITH_LAND", gv)
+    flt = Filter(filter_scale=4.0 * dx, dx_min=dx, n_steps=16, grid_type=GridType.IRREGULAR_WITH_LAND, grid_vars=gv)
+    flt.apply(f32.astype("f4"))
+    plan = ALL_KERNELS[GridType.IRREGULAR_WITH_LAND](**gv)._plan(_lib.F32, (120, 256))
+    assert plan.clenshaw_cut(16) == [] and "k_ringc<" not in plan.last_kernel()

@@ -356,11 +356,11 @@ def test_temporal_blocking_bit_identical(grid, shape, dt, S, strip):
             plan.set_timing(True)
             ref = flt.apply(f)
             n_single = plan.last_timing()[1]
-            plan.set_tuning(multi_s=S, strip_rows=strip)
+            plan.set_tuning(multi_s=S, strip_rows=strip, clenshaw=0)   # the forward recurrence: bit-identity with single steps
             got = flt.apply(f)
             n_multi = plan.last_timing()[1]
         finally:
-            plan.set_tuning(multi_s=8, strip_rows=0)
+            plan.set_tuning(multi_s=8, strip_rows=0, clenshaw=1)
             plan.set_timing(False)
         if grid.startswith("TRIPOLAR"):  # + S single-step launches on the fold band per blocked launch
             assert n_multi != n_single, (n_multi, n_single)
@@ -541,12 +541,12 @@ def test_blocked_kernel_nan_and_inf_modes(grid, dt):
         with np.errstate(all="ignore"):
             ref = flt.apply(f)
         for S in (2, 4, 7, 8):
-            plan.set_tuning(multi_s=S)
+            plan.set_tuning(multi_s=S, clenshaw=0)
             got = flt.apply(f)
             assert np.array_equal(np.isnan(ref), np.isnan(got)), (grid, dt, S)
             assert np.array_equal(ref, got, equal_nan=True), (grid, dt, S)
     finally:
-        plan.set_tuning(multi_s=8)
+        plan.set_tuning(multi_s=8, clenshaw=1)
     assert np.isnan(ref[gv["wet_mask"] == 0]).all() and np.isfinite(ref).sum() > ref.size // 3
 
 
@@ -584,6 +584,7 @@ def test_land_kept_out_of_the_state(grid, dt, monkeypatch):
     gv = {k: v.astype(dt) for k, v in gv.items()}
     dx = T.grid_dx_min(grid, gv)
     outs = {}
+    monkeypatch.setenv("GCMF_CLENSHAW", "0")   # the forward recurrence with and without the land handling: bit for bit
     for z in ("1", "0"):
         monkeypatch.setenv("GCMF_ZERO_LAND", z)
         clear_plan_cache()
@@ -771,8 +772,9 @@ def test_regular_spreads_nan_like_the_reference():
     assert np.array_equal(got, want, equal_nan=True) and np.isnan(got).sum() == 2 * 21 * 22 + 1
 
 
-@pytest.mark.parametrize("grid", ["IRREGULAR_WITH_LAND", "REGULAR_WITH_LAND", "REGULAR"])
-def test_ring_kernel_redoes_only_strips_with_non_finite_values(grid):
+@pytest.mark.parametrize("grid,clenshaw", [("IRREGULAR_WITH_LAND", 1), ("IRREGULAR_WITH_LAND", 0), ("REGULAR_WITH_LAND", 1),
+                                           ("REGULAR_WITH_LAND", 2), ("REGULAR", 1)])
+def test_ring_kernel_redoes_only_strips_with_non_finite_values(grid, clenshaw):
     """k_ring hands a wave strip to the general kernel when its NaN watch fires.  NaN on land is masked on load and must not
     fire it -- nor may stale register contents: the levels of the first rows run on ring slots no load has filled yet, and a
     kernel with NaNs in flight (k_land_fix over NaN land) precedes every first launch of a repeated filter."""
@@ -784,9 +786,12 @@ def test_ring_kernel_redoes_only_strips_with_non_finite_values(grid):
     plan = ALL_KERNELS[GridType[grid]](**gv)._plan(_lib.F64, shape)
     f = T.random_field(shape, 5)
     land = gv["wet_mask"] == 0 if "wet_mask" in gv else np.zeros(shape, bool)
+    plan.set_tuning(multi_s=8, clenshaw=clenshaw)   # 1 (default): backward evaluation for the flux kinds; 2: for every kind
+    request_restore = lambda: plan.set_tuning(multi_s=8, clenshaw=1)
     plan.ring_fallbacks()
     clean = flt.apply(f)
-    assert "k_ring<" in plan.last_kernel()
+    backward = clenshaw == 2 or (clenshaw == 1 and grid == "IRREGULAR_WITH_LAND")
+    assert ("k_ringc<" if backward else "k_ring<") in plan.last_kernel()
     assert plan.ring_fallbacks() == 0
     if land.any():
         for _ in range(3):  # repeated: the second call's first launch follows the first call's k_land_fix
@@ -808,3 +813,4 @@ def test_ring_kernel_redoes_only_strips_with_non_finite_values(grid):
     else:
         assert 0 < n < 40, n   # the strips around the cell, in each of the three launches -- not the whole grid
     assert plan.ring_fallbacks() == 0   # reading resets
+    request_restore()
