@@ -260,7 +260,7 @@ class Plan:
         """Per-component pointer lists (ncomp entries; None for the ones FIRST / LAST do not need)."""
         pk = np.ascontiguousarray(pk, dtype=np.float64)
         z = [None] * self.ncomp
-        check(load().gcmf_cheb_multi_vec(self._h, _ptr_array(u), _ptr_array(v or z), _ptr_array(uo or z),
+        check(load().gcmf_cheb_multi_vec(self._h, _ptr_array(u or z), _ptr_array(v or z), _ptr_array(uo or z),
                                          _ptr_array(vo or z), _ptr_array(fb_in or z), _ptr_array(fb_out),
                                          pk.ctypes.data_as(C.POINTER(C.c_double)), len(pk), float(p0), float(c),
                                          int(mode), OUT_F32 if out_f32 else 0, int(nbatch), int(row_lo), int(row_hi),

@@ -558,7 +558,8 @@ int gcmf_multi_supported(const gcmf_plan *pl, int S) { return (pl && multi_suppo
 static bool land_ok(const gcmf_plan *pl, int n_steps);
 static int clenshaw_cut(const gcmf_plan *pl, int n_steps, int *depths, int max_depths) {
   if (!pl || pl->ncomp != 1 || !(pl->clenshaw >= 2 || (pl->clenshaw == 1 && pl->kind == K_FLUX))) return 0;
-  if (!pl->ring || !pl->zero_row || pl->d.dtype != GCMF_F64 || pl->g.fold || pl->multi_s < 8 || !multi_supported(pl, 8)) return 0;
+  // (tripolar: of the GRID, not of this slab -- every rank of a slab run must take the same decision)
+  if (!pl->ring || !pl->zero_row || pl->d.dtype != GCMF_F64 || pl->tripolar || pl->g.fold || pl->multi_s < 8 || !multi_supported(pl, 8)) return 0;
   if (pl->n_land > 0 && !land_ok(pl, n_steps)) return 0;
   if (!(n_steps >= 10 || (n_steps >= 5 && n_steps <= 8))) return 0;
   int n = 0, left = n_steps;
@@ -599,7 +600,7 @@ int gcmf_cheb_multi(gcmf_plan *pl, const void *u, const void *v, void *uo, void 
     // b_n = p0 * f itself), fbar_in = the constant input f, pk[t] = coefficient of level t + 1, LAST: fbar_out = the result
     const bool first = mode & GCMF_STEP_FIRST, last = mode & GCMF_STEP_LAST;
     int probe[1];
-    if (pl->d.dtype != GCMF_F64 || pl->g.fold || pl->ncomp != 1 || S < 5 || S > 8 || !pl->ring || !pl->zero_row ||
+    if (pl->d.dtype != GCMF_F64 || pl->tripolar || pl->g.fold || pl->ncomp != 1 || S < 5 || S > 8 || !pl->ring || !pl->zero_row ||
         !(clenshaw_cut(pl, S, probe, 1) == 1)) {
       set_error("gcmf_cheb_multi: the backward evaluation is not available for this plan / depth %d", S);
       return GCMF_ERR_UNSUPPORTED;

@@ -74,6 +74,10 @@ class HipSlabEngine:
     def land_fix(self, p, c, ins, outs, nbatch):
         self.plan.land_fix(p, c, self._ptrs(ins), self._ptrs(outs), nbatch, stream=self._stream())
 
+    def clenshaw_cut(self, n_steps):
+        """Launch depths of the backward evaluation gcmf_apply uses for this plan and polynomial ([] = forward recurrence)."""
+        return self.plan.clenshaw_cut(n_steps) if self.plan.ncomp == 1 else []
+
     def multi(self, u, v, uo, vo, fb_in, fb_out, pk, p0, c, mode, nbatch, row_lo, row_hi):
         """S = len(pk) recurrence steps in one HBM pass (gcmf_cheb_multi_vec); per-component tensor lists."""
         self.plan.cheb_multi_vec(self._ptrs(u), self._ptrs(v), self._ptrs(uo), self._ptrs(vo), self._ptrs(fb_in),
@@ -342,6 +346,61 @@ class SlabFilter:
             self.kernel_launches += sum(n for _, _, n in self._pending_events)
             self._pending_events = []
 
+    def _apply_backward(self, cut, st, p, nbatch):
+        """The backward (Clenshaw) evaluation libgcmf uses on one GPU for this plan, on the slab: the state is
+        (b_{k+1}, b_{k+2}), the constant input keeps its ghost rows from ONE exchange at the start, a launch of S levels uses
+        up S ghost rows of the state, the state's ghost rows are refreshed when the next launch needs more than are left."""
+        t = self.torch
+        X, O = st["X"], st["O"]
+        pool = [st["A"], st["B"], st["C"], st["D"]]
+        fo, ro, s, n = self.first_owned, self.rows_owned, self.halo, self.n_steps
+        comps = lambda buf: [buf[k] for k in range(self.ncomp)]
+        if self.multi:
+            self._exchange([X])          # f's ghost rows: the first launch forms b_n = p_n f on them, later ones read f on the rows they compute
+        u = v = None
+        valid, lvl, nlaunch = (s if self.multi else 0), 1, 0
+        if self.time_kernels:
+            e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+            e0.record()
+        for q, S in enumerate(cut):
+            if self.multi and valid < S:
+                self._exchange([u, v])
+                valid = s
+            free = [b for b in pool if b is not u and b is not v]
+            v_out = (valid - S) if self.multi else 0
+            lo = fo - (v_out if self.gs else 0)
+            hi = fo + ro + (v_out if self.gn else 0)
+            last = (q == len(cut) - 1)
+            mode = _lib.STEP_CLENSHAW | (_lib.STEP_FIRST if q == 0 else 0) | (_lib.STEP_LAST if last else 0)
+            pk = p[n - lvl - S + 1: n - lvl + 1][::-1]       # level l uses p[n - l]
+            args = (None if u is None else comps(u), None if v is None else comps(v), comps(free[0]), comps(free[1]), comps(X),
+                    comps(O), pk, p[n], self.c, mode, nbatch)
+            nxt = cut[q + 1] if not last else 0
+            overlap = (self.overlap and self.multi and not last and v_out < nxt and ro >= 4 * s)
+            if overlap:
+                # the next launch needs fresh ghost rows: advance the rows the neighbours need first, post the exchange of the
+                # NEW state, and let the interior rows run while the messages are in flight
+                if self.gs:
+                    self.engine.multi(*args, lo, lo + s)
+                if self.gn:
+                    self.engine.multi(*args, hi - s, hi)
+                pending = self._exchange_start([free[0], free[1]])
+                self.engine.multi(*args, lo + (s if self.gs else 0), hi - (s if self.gn else 0))
+                self._exchange_finish(pending)
+                v_out = s
+            else:
+                self.engine.multi(*args, lo, hi)
+            u, v = free[0], free[1]
+            valid = v_out
+            lvl += S
+            nlaunch += 1
+        if self.engine.has_land():
+            self.engine.land_fix(p, self.c, comps(X), comps(O), nbatch)
+        if self.time_kernels:
+            e1.record()
+            self._pending_events.append((e0, e1, nlaunch))
+        return [O[k][:, fo: fo + ro, :] for k in range(self.ncomp)]
+
     # -- the filter ----------------------------------------------------------------------------
     MULTI_DEPTHS = (8, 7, 6, 5, 4, 3, 2)  # scalar kinds support all of them, the vector kinds 4 / 3 / 2
 
@@ -370,6 +429,9 @@ class SlabFilter:
         prepared = False
         keep_land_out = can_multi and hasattr(self.engine, "has_land") and self.engine.has_land()
         land_zeroed = False
+        cut = self.engine.clenshaw_cut(n) if hasattr(self.engine, "clenshaw_cut") else []
+        if cut and (not self.multi or s >= max(cut)):
+            return self._apply_backward(cut, st, p, nbatch)
         u, v = X, None          # T_{k-1}, T_{k-2}
         valid = 0               # ghost rows of u (and at least valid-1 of v) that are up to date
         events = []
