@@ -201,6 +201,15 @@ class SlabFilter:
                 if self.comm is not None:
                     self.comm.close()
                 self.comm, self.exchange_kind = None, "torch"
+        # the backward (Clenshaw) evaluation libgcmf uses on one GPU: every rank must take the same decision
+        cut = self.engine.clenshaw_cut(self.n_steps) if hasattr(self.engine, "clenshaw_cut") else []
+        use = 1 if (cut and (not self.multi or self.halo >= max(cut))) else 0
+        if self.world > 1 and dist.is_initialized():
+            flag = torch.tensor([use], dtype=torch.int32,
+                                device=self.device if dist.get_backend(group) == "nccl" else torch.device("cpu"))
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            use = int(flag.item())
+        self.backward_cut = list(cut) if use else []
         self.tdtype = torch.float64 if self.np_dtype == np.float64 else torch.float32
         self._bufs = {}
         self.kernel_ms = 0.0
@@ -429,9 +438,8 @@ class SlabFilter:
         prepared = False
         keep_land_out = can_multi and hasattr(self.engine, "has_land") and self.engine.has_land()
         land_zeroed = False
-        cut = self.engine.clenshaw_cut(n) if hasattr(self.engine, "clenshaw_cut") else []
-        if cut and (not self.multi or s >= max(cut)):
-            return self._apply_backward(cut, st, p, nbatch)
+        if self.backward_cut:
+            return self._apply_backward(self.backward_cut, st, p, nbatch)
         u, v = X, None          # T_{k-1}, T_{k-2}
         valid = 0               # ghost rows of u (and at least valid-1 of v) that are up to date
         events = []

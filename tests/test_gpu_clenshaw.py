@@ -86,7 +86,7 @@ def test_same_bits_however_the_levels_are_cut(grid):
 
 def test_default_is_backward_for_flux_kinds_and_forward_for_the_rest():
     for grid, backward in (("IRREGULAR_WITH_LAND", True), ("MOM5U", True), ("REGULAR_WITH_LAND", False), ("REGULAR", False),
-                           ("TRIPOLAR_POP_WITH_LAND", False)):
+                           ("TRIPOLAR_POP_WITH_LAND", False), ("TRIPOLAR_REGULAR_WITH_LAND_AREA_WEIGHTED", False)):
         flt, plan, f, want = _case(grid, (120, 256), 16)
         got = flt.apply(f)
         assert ("k_ringc<" in plan.last_kernel()) == backward, (grid, plan.last_kernel())

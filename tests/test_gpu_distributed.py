@@ -82,8 +82,7 @@ def _worker(rank, world, port, q):
             sf.time_kernels = True
             got = sf.gather_to_global(sf.apply_local(sf.scatter_from_global(fields)))
             sf.collect_kernel_times()
-            cut = sf.engine.clenshaw_cut(sf.n_steps)
-            if cut and sf.halo >= max(cut):   # f64 flux kinds: the slabs evaluate backwards like the one-GPU path (k_ringc)
+            if sf.backward_cut:   # f64 flux kinds, not tripolar: the slabs evaluate backwards like the one-GPU path (k_ringc)
                 assert "k_ringc<" in sf.engine.plan.last_kernel(), (grid, sf.engine.plan.last_kernel())
             if vec:   # the blocked vector kernels really ran on the slabs
                 assert sf.kernel_launches < sf.n_steps, (sf.kernel_launches, sf.n_steps)
