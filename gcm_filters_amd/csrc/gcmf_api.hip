@@ -911,6 +911,42 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
         if ((rc = ensure_dev_p(pl, p, n_steps, s))) return rc;
         if ((rc = launch_land_fix(pl, din[0], dout[0], pl->dev_p, n_steps, c, fb32 ? 1 : 0, nbatch, s))) return rc;
       }
+    } else if (use_vmulti && pl->kind == K_CGRID && pl->clenshaw >= 1 && n_steps >= 2 && vec_multi_supported(pl, nbatch, 2)) {
+      // C-grid, batched levels: the polynomial evaluated backwards (k_cgrid_stream2c): state (b_{k+1}, b_{k+2}) in a pool of four
+      // plane pairs, the constant input (u, v) read by every launch, no fbar planes.  Level l = 1..n uses p[n - l]; the first
+      // launch forms b_n = p[n] f as it loads f, the last one writes the result.
+      const void *u[2] = {x0[0], x0[1]}, *v[2] = {nullptr, nullptr};
+      void *pool[4][2] = {{A[0], A[1]}, {B[0], B[1]}, {Cb[0], Cb[1]}, {Db[0], Db[1]}};
+      // four levels per launch with two operand rows in flight: 353-357 G on config 5; five levels leave one row in flight and
+      // spill (305-310 G); the forward kernel at its best (five levels) 280 G
+      const int smax = std::min(pl->multi_s, 4);
+      int lvl = 1;
+      while (lvl <= n_steps) {
+        const int left = n_steps - lvl + 1;
+        int S = 0;
+        for (int cand = smax; cand >= 2 && !S; --cand)
+          if (cand <= left && left - cand != 1 && vec_multi_supported(pl, nbatch, cand)) S = cand;
+        if (!S) S = left;  // (left = 3 with smax 2 cannot happen: smax >= 4)
+        void *fr[2][2];
+        int nf = 0;
+        for (int q = 0; q < 4 && nf < 2; ++q)
+          if (pool[q][0] != u[0] && pool[q][0] != v[0]) { fr[nf][0] = pool[q][0]; fr[nf][1] = pool[q][1]; ++nf; }
+        const bool is_last = (lvl + S - 1 == n_steps);
+        VecMultiArgs m{};
+        for (int q = 0; q < 2; ++q) {
+          m.u0[q] = u[q]; m.uprev[q] = v[q]; m.u1o[q] = fr[0][q]; m.u2o[q] = fr[1][q];
+          m.fb_in[q] = x0[q]; m.fb_out[q] = dout[q];
+        }
+        for (int t = 0; t < S; ++t) m.pk[t] = p[n_steps - (lvl + t)];
+        m.p0 = p[n_steps]; m.c = c; m.S = S; m.clen = 1;
+        m.first = (lvl == 1); m.last = is_last; m.fb_is_f32 = fb32; m.nbatch = nbatch; m.row_lo = 0; m.row_hi = rows;
+        if ((rc = dom_begin(pl, s))) return rc;
+        if ((rc = launch_vec_multi(pl, m, s))) return rc;
+        if ((rc = dom_end(pl, s))) return rc;
+        for (int q = 0; q < 2; ++q) { u[q] = fr[1][q]; v[q] = fr[0][q]; }
+        lvl += S;
+        ++launches;
+      }
     } else if (use_vmulti) {
       // vector kinds: S = 2..4 steps per pass, (T_{k-1}, T_{k-2}) -> (T_{k+S-2}, T_{k+S-1}).  Neither output may overwrite
       // T_{k-2}: the halo rows / columns a strip recomputes need its neighbours' T_{k-2}.  The state rotates through

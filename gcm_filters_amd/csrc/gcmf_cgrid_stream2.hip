@@ -33,7 +33,10 @@ template <typename T, typename FB> struct CStream2P {
   int nx, rows, out_lo, out_hi;
   int H, nwx, ngroups, nlev, nlev4, wrap, first, last;
   long long bstride;
-  double p0, pk[5], c;
+  double p0, pk[6], c;
+  // backward (Clenshaw) evaluation (k_cgrid_stream2c): fu_in / fv_in = the constant input fields, p0 = p_n (first launch),
+  // last launch: the result goes to du_out / dv_out as f64 (f32 state, default output) or to fu_out / fv_out (state dtype)
+  double *du_out, *dv_out;
 };
 
 template <typename T> __device__ __forceinline__ T c2san(T x) {
@@ -96,8 +99,12 @@ template <typename T, int VEC> struct CgLevel {
 // PRIV (single-level fields): one-wave workgroups, each an independent (window, strip) group; the wave fetches all 14
 // coefficient rows itself, level 1 uses them straight from registers and levels 2..S read them back from the wave's own
 // LDS ring of S-1 slots, refilled at the end of the iteration (no barrier, no shadow waves).
-template <typename T, typename FB, int VEC, int S, int D, bool PRIV>
-__global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) == 8 && (PRIV || S > 2) ? 1 : 2)) void k_cgrid_stream2(const CStream2P<T, FB> P) {
+// CLEN: the polynomial evaluated backwards (Clenshaw, see gcmf_ringc_impl.hpp): the state is (b_{k+1}, b_{k+2}), the conveyor that
+// carries fbar from level to level carries the row of the constant input f instead (b_k = p_k f + 2 A(b_{k+1}) - b_{k+2}), nothing
+// is accumulated and only the last launch writes a result: 54 instead of 78 bytes per cell, level and pass for f32 state.
+template <typename T, typename FB, int VEC, int S, int D, bool PRIV, bool CLEN>
+__device__ __forceinline__ void cgrid_stream2_body(const CStream2P<T, FB> &P) {
+  static_assert(!CLEN || std::is_same<FB, T>::value, "backward evaluation: the conveyor has the state's type");
   constexpr int M = (S + VEC - 1) / VEC * VEC;  // level j is stale j cells per side; windows start on a VEC boundary
   constexpr int W = 64 * VEC, WI = W - 2 * M;
   constexpr int NS = PRIV ? S - 1 : S + 1;
@@ -154,6 +161,8 @@ __global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) == 8 && (PRIV || S > 
     if (!first) {
       mload<T, VEC>(x.up, P.up + boff + rc);
       mload<T, VEC>(x.vp, P.vp + boff + rc);
+    }
+    if (!first || CLEN) {  // fbar -- or, backward evaluation, the row of the constant input
       mload<FB, VEC>(x.fu, P.fu_in + boff + rc);
       mload<FB, VEC>(x.fv, P.fv_in + boff + rc);
     }
@@ -209,7 +218,11 @@ __global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) == 8 && (PRIV || S > 
     T cu[S + 1][VEC], cv[S + 1][VEC];  // newest row of every level this iteration
     FB nau[S + 1][VEC], nav[S + 1][VEC];
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) { cu[0][k] = x.u[k]; cv[0][k] = x.v[k]; }
+    for (int k = 0; k < VEC; ++k) {
+      // (backward evaluation, first launch: the delivered rows of f become rows of b_n = p_n f)
+      cu[0][k] = (CLEN && first) ? (T)P.p0 * x.u[k] : x.u[k];
+      cv[0][k] = (CLEN && first) ? (T)P.p0 * x.v[k] : x.v[k];
+    }
 
 #pragma unroll
     for (int j = 1; j <= S; ++j) {
@@ -240,7 +253,19 @@ __global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) == 8 && (PRIV || S > 
       for (int k = 0; k < VEC; ++k) {
         const T xu = o1u[j - 1][k], xv = o1v[j - 1][k];
         const T avu = -xu - c * lu[k], avv = -xv - c * lv[k];
-        if (j == 1 && first) {
+        if constexpr (CLEN) {
+          const T x2u = (j == 1) ? (first ? T(0) : x.up[k]) : o2u[j >= 2 ? j - 2 : 0][k];
+          const T x2v = (j == 1) ? (first ? T(0) : x.vp[k]) : o2v[j >= 2 ? j - 2 : 0][k];
+          const T fiu = (T)((j == 1) ? x.fu[k] : accu[j - 1][k]);
+          const T fiv = (T)((j == 1) ? x.fv[k] : accv[j - 1][k]);
+          const T two = (last && j == S) ? T(1) : T(2);  // the last level of the last launch is the result: A, not 2 A
+          cu[j][k] = two * avu - x2u;
+          cv[j][k] = two * avv - x2v;
+          cu[j][k] = cu[j][k] + (T)pkj * fiu;
+          cv[j][k] = cv[j][k] + (T)pkj * fiv;
+          nau[j][k] = (FB)fiu;   // the row of f travels on with its row of the state
+          nav[j][k] = (FB)fiv;
+        } else if (j == 1 && first) {
           cu[j][k] = avu;
           cv[j][k] = avv;
           if (std::is_same<FB, T>::value) {
@@ -272,9 +297,23 @@ __global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) == 8 && (PRIV || S > 
           mstore<T, VEC>((j == S ? P.u2o : P.u1o) + off, cu[j]);
           mstore<T, VEC>((j == S ? P.v2o : P.v1o) + off, cv[j]);
         }
-        if (j == S) {
+        if (j == S && !CLEN) {
           mstore<FB, VEC>(P.fu_out + off, nau[j]);
           mstore<FB, VEC>(P.fv_out + off, nav[j]);
+        }
+        if (CLEN && j == S && last) {
+          if (P.du_out) {  // wave-uniform: f64 result from f32 state (one component at a time: registers)
+            double dd[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) dd[k] = (double)cu[j][k];
+            mstore<double, VEC>(P.du_out + off, dd);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) dd[k] = (double)cv[j][k];
+            mstore<double, VEC>(P.dv_out + off, dd);
+          } else {
+            mstore<T, VEC>(reinterpret_cast<T *>(P.fu_out) + off, cu[j]);
+            mstore<T, VEC>(reinterpret_cast<T *>(P.fv_out) + off, cv[j]);
+          }
         }
       }
     }
@@ -330,6 +369,15 @@ __global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) == 8 && (PRIV || S > 
   }
 }
 
+template <typename T, typename FB, int VEC, int S, int D, bool PRIV>
+__global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) == 8 && (PRIV || S > 2) ? 1 : 2)) void k_cgrid_stream2(const CStream2P<T, FB> P) {
+  cgrid_stream2_body<T, FB, VEC, S, D, PRIV, false>(P);
+}
+template <typename T, int VEC, int S, int D, bool PRIV>
+__global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) == 8 && (PRIV || S > 2) ? 1 : 2)) void k_cgrid_stream2c(const CStream2P<T, T> P) {
+  cgrid_stream2_body<T, T, VEC, S, D, PRIV, true>(P);
+}
+
 static bool c2al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 bool cgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
@@ -351,7 +399,7 @@ bool cgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
   return true;
 }
 
-template <typename T, typename FB, int VEC, int S, int D, bool PRIV> static int launch_c2(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
+template <typename T, typename FB, int VEC, int S, int D, bool PRIV, bool CLEN = false> static int launch_c2(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
   constexpr int M = (S + VEC - 1) / VEC * VEC, W = 64 * VEC, WI = W - 2 * M;
   const Geom &g = pl->g;
   CStream2P<T, FB> P;
@@ -361,6 +409,11 @@ template <typename T, typename FB, int VEC, int S, int D, bool PRIV> static int 
   P.u1o = (T *)a.u1o[0];  P.v1o = (T *)a.u1o[1];
   P.u2o = (T *)a.u2o[0];  P.v2o = (T *)a.u2o[1];
   P.fu_out = (FB *)a.fb_out[0];  P.fv_out = (FB *)a.fb_out[1];
+  P.du_out = P.dv_out = nullptr;
+  if (CLEN && a.last && sizeof(T) == 4 && !a.fb_is_f32) {  // f32 state, f64 result (NumPy >= 2 promotion of the reference)
+    P.du_out = (double *)a.fb_out[0];
+    P.dv_out = (double *)a.fb_out[1];
+  }
   for (int k = 0; k < MAX_COEF; ++k) P.coef[k] = (const T *)g.coef[k];
   P.nx = g.nx;
   P.rows = g.rows;
@@ -399,13 +452,23 @@ template <typename T, typename FB, int VEC, int S, int D, bool PRIV> static int 
   P.last = a.last;
   P.bstride = (long long)g.rows * g.nx;
   P.p0 = a.p0;
-  for (int t = 0; t < 5; ++t) P.pk[t] = a.pk[t];
+  for (int t = 0; t < 6; ++t) P.pk[t] = a.pk[t];
   P.c = a.c;
   const long long groups_per_xcd = (P.ngroups + 7) / 8;
   const long long blocks_per_xcd = PRIV ? groups_per_xcd * P.nlev : (groups_per_xcd * P.nlev4 + 3) / 4;
   dim3 block(PRIV ? 64 : 256), grid((unsigned)(blocks_per_xcd * 8));
   const size_t lds = (size_t)(PRIV ? S - 1 : S + 1) * 14 * 64 * sizeof(MPack<T, VEC>);
   static bool attr_set = false;  // per instantiation
+  if constexpr (CLEN) {
+    if (!attr_set && lds > 48 * 1024) {
+      GCMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cgrid_stream2c<T, VEC, S, D, PRIV>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((k_cgrid_stream2c<T, VEC, S, D, PRIV>), grid, block, lds, s, P);
+    note_kernel(pl, std::string("gcmf::k_cgrid_stream2c<") + tyname<T>() + ", " + std::to_string(VEC) + ", " + std::to_string(S) + ", " +
+                        std::to_string(D) + ", " + (PRIV ? "true" : "false") + ">", S);
+  } else {
   if (!attr_set && lds > 48 * 1024) {
     GCMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cgrid_stream2<T, FB, VEC, S, D, PRIV>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -414,6 +477,7 @@ template <typename T, typename FB, int VEC, int S, int D, bool PRIV> static int 
   hipLaunchKernelGGL((k_cgrid_stream2<T, FB, VEC, S, D, PRIV>), grid, block, lds, s, P);
   note_kernel(pl, std::string("gcmf::k_cgrid_stream2<") + tyname<T>() + ", " + tyname<FB>() + ", " + std::to_string(VEC) + ", " +
                       std::to_string(S) + ", " + std::to_string(D) + ", " + (PRIV ? "true" : "false") + ">", S);
+  }
   GCMF_HIP(hipGetLastError());
   return GCMF_OK;
 }
@@ -432,6 +496,25 @@ template <typename T, typename FB, int S> static int launch_c2_sel(gcmf_plan *pl
 }
 
 int launch_cgrid_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
+  if (a.clen) {  // backward evaluation: the conveyor has the state's type; single-level fields: private coefficient rings as above
+    static const bool priv_ok = !(getenv("GCMF_VEC_PRIV") && atoi(getenv("GCMF_VEC_PRIV")) == 0);
+    const bool priv = a.nbatch == 1 && priv_ok;
+    if (pl->d.dtype == GCMF_F64) {
+      switch (a.S) {
+        case 2: return priv ? launch_c2<double, double, 2, 2, 1, true, true>(pl, a, s) : launch_c2<double, double, 2, 2, 1, false, true>(pl, a, s);
+        case 3: return priv ? launch_c2<double, double, 2, 3, 1, true, true>(pl, a, s) : launch_c2<double, double, 2, 3, 2, false, true>(pl, a, s);
+        case 4: return priv ? launch_c2<double, double, 2, 4, 1, true, true>(pl, a, s) : launch_c2<double, double, 2, 4, 2, false, true>(pl, a, s);
+      }
+      return GCMF_ERR_INVALID_ARG;
+    }
+    switch (a.S) {
+      case 2: return priv ? launch_c2<float, float, 2, 2, 1, true, true>(pl, a, s) : launch_c2<float, float, 2, 2, 2, false, true>(pl, a, s);
+      case 3: return priv ? launch_c2<float, float, 2, 3, 1, true, true>(pl, a, s) : launch_c2<float, float, 2, 3, 2, false, true>(pl, a, s);
+      case 4: return priv ? launch_c2<float, float, 2, 4, 1, true, true>(pl, a, s) : launch_c2<float, float, 2, 4, 2, false, true>(pl, a, s);
+      case 5: return launch_c2<float, float, 2, 5, 1, false, true>(pl, a, s);
+    }
+    return GCMF_ERR_INVALID_ARG;
+  }
   if (pl->d.dtype == GCMF_F64) {
     switch (a.S) {
       case 2: return launch_c2_sel<double, double, 2>(pl, a, s);

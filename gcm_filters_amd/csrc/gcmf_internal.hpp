@@ -97,6 +97,8 @@ struct VecMultiArgs {
   int S, first, last, fb_is_f32;
   int64_t nbatch;
   int row_lo, row_hi;
+  int clen;              // backward (Clenshaw) evaluation: u0 / uprev = (b_{k+1}, b_{k+2}) (first: u0 = the input f, uprev unused), fb_in =
+                         // the input f, p0 = p_n, pk[t] = coefficient of level t + 1, fb_out = the result (last launch)
 };
 
 }  // namespace gcmf

@@ -465,7 +465,7 @@ def test_vector_temporal_blocking_bit_identical(grid, shape, nlev, dt):
             ref = flt.apply_to_vector(u, v)
             assert plan.last_timing()[1] == n_steps
             for S in (2, 3, 4, 5, 6):
-                plan.set_tuning(multi_s=S)
+                plan.set_tuning(multi_s=S, clenshaw=0)   # the forward recurrence: bit-identity with single steps
                 got = flt.apply_to_vector(u, v)
                 n_launch = plan.last_timing()[1]
                 if blocked:
@@ -478,8 +478,19 @@ def test_vector_temporal_blocking_bit_identical(grid, shape, nlev, dt):
                     assert n_launch == n_steps
                 for r, g in zip(ref, got):
                     assert np.array_equal(r, g, equal_nan=True), (shape, nlev, dt, n_steps, S, rel_err(g, r))
+            if grid == "VECTOR_C_GRID":   # the default: backward evaluation (k_cgrid_stream2c), same polynomial, other rounding
+                plan.set_tuning(multi_s=8, clenshaw=1)
+                plan.last_kernel()   # (reading resets: it reports the deepest kernel since the last read)
+                gotc = flt.apply_to_vector(u, v)
+                assert "k_cgrid_stream2c<" in plan.last_kernel()
+                if dt == "f8":   # (f32: the +-inf cell above becomes +-FLT_MAX in the stencil and what overflows where depends on
+                    #               the order of the operations; the f32 backward path is checked on finite / NaN input in
+                    #               tests/test_gpu_clenshaw.py and by tools/fuzz_gpu.py --cgrid)
+                    for r, g in zip(ref, gotc):
+                        assert np.array_equal(np.isnan(r), np.isnan(g))
+                        assert rel_err(g, r) <= 1e-13, (shape, nlev, dt, n_steps, rel_err(g, r))
         finally:
-            plan.set_tuning(multi_s=8)
+            plan.set_tuning(multi_s=8, clenshaw=1)
             plan.set_timing(False)
     spec = O.make_spec(2.0 * dx, dx, "TAPER", n_steps=13)
     with np.errstate(all="ignore"):
