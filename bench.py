@@ -55,6 +55,8 @@ def min_bytes_per_cell_launch(grid, w, f, L, backward=False):
     backward (k_ringc, Clenshaw): two state planes read and written, the constant input and its land byte read, no fbar."""
     ncomp = 2 if grid.startswith("VECTOR") else 1
     coef = 1.0 if NCOEF[grid] is None else NCOEF[grid] * w
+    if backward and ncomp == 2:   # per component: two state planes read and written, the input read; coefficients shared by L levels
+        return ncomp * 5 * w + coef / L
     if backward:
         return 5 * w + 1 + coef
     return ncomp * 2 * (2 * w + f) + coef / L
@@ -299,11 +301,11 @@ def roofline_of(cfg, r, steps, default_tuning):
     avg_ms = r["dom_ms"] / r["dom_n"]                       # HIP events around each launch of the dominant kernel
     # recurrence steps one launch of that kernel advances: its last (vector kernels: fourth) template argument
     targs = r["kernel"][r["kernel"].index("<") + 1: r["kernel"].rindex(">")].split(", ")
-    steps_per_launch = float(targs[2] if "k_ringc<" in r["kernel"] else
+    steps_per_launch = float(targs[2] if ("k_ringc<" in r["kernel"] or "k_cgrid_stream2c<" in r["kernel"]) else
                              targs[3] if any(k in r["kernel"] for k in ("stream2", "k_scalar_multi", "k_ring")) else
                              (targs[-1] if "k_flux_multi2" in r["kernel"] else 1))
     achieved = balg * r["cells"] * steps_per_launch / (avg_ms * 1e-3) / 1e9
-    minb = min_bytes_per_cell_launch(grid, w, 8, nb, backward="k_ringc<" in r["kernel"]) * r["cells"]
+    minb = min_bytes_per_cell_launch(grid, w, 8, nb, backward=("k_ringc<" in r["kernel"] or "k_cgrid_stream2c<" in r["kernel"])) * r["cells"]
     rec, src = load_traffic(cfg, r["kernel"]) if default_tuning else (None, "non-default tuning: traffic withheld")
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "traffic": rec.get("bytes_per_launch") if rec else None, "traffic_source": src,
