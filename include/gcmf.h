@@ -194,8 +194,10 @@ int gcmf_multi_supported(const gcmf_plan *plan, int S);
  *   b_{n+1} = b_{n+2} = 0,  b_k = p[k] f + 2 A(b_{k+1}) - b_{k+2}  (k = n..1),  result = p[0] f + A(b_1) - b_2.
  * The state is two planes instead of three (no fbar); every launch re-reads the constant input f: one plane less per launch.
  * Same NaN / land semantics as the forward recurrence; results differ from it in the last bits (<= 3e-15 relative) and are
- * identical however the levels are cut.  f64 scalar plans without a tripole fold; gcmf_apply uses it by default for the
- * flux-form grid types (env GCMF_CLENSHAW = 0 off / 1 flux kinds / 2 all scalar kinds).
+ * identical however the levels are cut.  gcmf_apply uses it by default for the f64 flux-form grid types without a tripole fold
+ * and for VECTOR_C_GRID (f32 state: the whole recurrence then runs in f32, 2e-6 from the f64-accumulated forward result at
+ * n = 44); env GCMF_CLENSHAW = 0 off / 1 those / 2 also the other f64 scalar types.  gcmf_cheb_multi_vec (vector slab callers)
+ * runs the forward recurrence.
  * gcmf_clenshaw_cut: the launch depths (each 5..8, summing to n_steps) gcmf_apply uses for this plan and n_steps -- return value
  * = their number, 0 = it runs the forward recurrence.  A slab caller does the same with gcmf_cheb_multi and
  * GCMF_STEP_CLENSHAW:  level l = 1..n_steps computes b_{n-l};  launch with levels l0 .. l0+S-1:  u = b_{n-l0+1}, v = b_{n-l0+2}
