@@ -214,7 +214,7 @@ def load_traffic(cfg, kernel_ran):
     return rec, f"profiles/hbm_traffic.json:{key} <- {rec.get('source')} ({prof})"
 
 
-def run_single(cfg, args, dev, steps, warmup, scale=0.0, levels=None, tuned=False):
+def run_single(cfg, args, dev, steps, warmup, scale=0.0, levels=None, tuned=False, clenshaw=-1):
     """Time `steps` filter applications of BASELINE config `cfg` on this process's GPU.  Returns a dict with the raw
     measurements, the workload and the device outputs of the last application."""
     import torch
@@ -235,6 +235,8 @@ def run_single(cfg, args, dev, steps, warmup, scale=0.0, levels=None, tuned=Fals
     plan = lap._plan(_lib.F64 if itemsize == 8 else _lib.F32, (args.ny, args.nx), dev.index)
     if tuned:
         plan.set_tuning(args.rows_per_wave, args.xcd_remap, args.multi or 8, args.strip, args.prefetch)
+    if clenshaw >= 0:   # 2: the backward evaluation also for the grid types that default to the (bit-exact) forward recurrence
+        plan.set_tuning(multi_s=args.multi or 8, clenshaw=clenshaw)
     plan.set_timing(False)
     d_in = [torch.from_numpy(f).to(dev) for f in wl["fields"]]
     run = (lambda: flt.apply_to_vector(d_in[0], d_in[1])) if len(d_in) == 2 else (lambda: (flt.apply(d_in[0]),))
@@ -263,6 +265,8 @@ def run_single(cfg, args, dev, steps, warmup, scale=0.0, levels=None, tuned=Fals
         ms, nl, lo, hi = plan.last_kernel_timing()
         dom_ms, dom_n, dom_min, dom_max = dom_ms + ms, dom_n + nl, min(dom_min, lo), max(dom_max, hi)
     plan.set_timing(False)
+    if clenshaw >= 0:
+        plan.set_tuning(multi_s=args.multi or 8, clenshaw=1)   # back to the default for whoever uses the cached plan next
     return dict(dom_ms=dom_ms, dom_n=dom_n, dom_min=dom_min, dom_max=dom_max, dom_reps=dom_reps, wl=wl, grid=grid, fk=fk, itemsize=itemsize, nbatch=nbatch, n_steps=n_steps, elapsed=elapsed,
                 kernel_ms=kernel_ms, launches=launches, outs=list(outs), kernel=plan.last_kernel(), flt=flt, d_in=d_in,
                 cells=args.ny * args.nx * nbatch)
@@ -524,6 +528,20 @@ def main_single(args):
                     failed.append(f"config {cfg} reference probes: rel_err {rec['parity']['rel_err']:.3e}")
             if cfg == 5 and not args.no_cpu:
                 rec["cpu_baseline_pool"] = cpu_baseline_pool(5, args.ny, args.nx, r["nbatch"], 4)
+            if cfg == 2:
+                # not the default: the land-mask (and REGULAR) types run the reference's forward recurrence and are bit-exact with
+                # numpy; GCMF_CLENSHAW=2 evaluates them backwards too (fused arithmetic, one plane less: <= 1e-14 from numpy)
+                r2 = None
+                free_gpu()
+                r2 = run_single(cfg, args, dev, steps=xs, warmup=xw, clenshaw=2)
+                opt = {"what": "GCMF_CLENSHAW=2: backward evaluation (not bit-exact with numpy; NOT the default)", "kernel": r2["kernel"],
+                       "value": r2["cells"] * r2["n_steps"] * xs / r2["elapsed"], "unit": "cell-steps/s", "ms_per_step": 1e3 * r2["elapsed"] / xs}
+                chk2 = golden_probe_check(cfg, 0.0, (args.ny, args.nx), r2["outs"])
+                if chk2 is not None:
+                    opt["parity"] = dict(finish_probe_check(chk2), tolerance=tol(r2["itemsize"]))
+                    if not opt["parity"]["rel_err"] <= opt["parity"]["tolerance"]:
+                        failed.append(f"config {cfg} backward evaluation: rel_err {opt['parity']['rel_err']:.3e}")
+                rec["backward_opt_in"] = opt
             extras.append(rec)
         out["extra_configs"] = extras
     if args.config == 5 and not args.no_cpu:

@@ -39,7 +39,7 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
   static_assert(R >= S + D && R % 3 == 0 && R % RU == 0 && R % RV == 0 && RU >= 3 + D && RV >= 1 + D, "ring periods");
   constexpr bool FLUX = (KIND == K_FLUX), MASK = (KIND == K_MASKZ);
   constexpr bool WATCH = (KIND != K_REG) && !SANI;  // K_REG has no nan_to_num in the reference: NaN spreads by plain arithmetic
-  constexpr bool FUSED = FLUX;
+  constexpr bool FUSED = true;   // nothing here is bit-identical with numpy anyway: every multiply-add pair is one fma
 
   const int lane = threadIdx.x & 63;
   const int wx = wid % P.nwx, st = wid / P.nwx;
@@ -202,13 +202,13 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
         if constexpr (MASK) {
           const unsigned bb = (B[sl] >> (8 * k)) & 0xFFu;
           const T wf = (T)(bb >> 5);
-          L = -wf * xC + xE;
+          L = rfma(-wf, xC, xE);
           L = L + xW;
           L = L + gN[k];
           L = L + gS[k];
           L = (bb & 1u) ? L : T(0);
         } else {
-          L = T(-4) * xC + xE;
+          L = rfma(T(-4), xC, xE);
           L = L + xW;
           L = L + gN[k];
           L = L + gS[k];
