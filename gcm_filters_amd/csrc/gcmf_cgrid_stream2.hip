@@ -11,6 +11,7 @@
 // 4w + 2f + 14w/4 + 4w + 2f bytes per cell.level whatever S is (78 B with f32 state and f64 fbar; 65 B for S = 1).
 // Arithmetic per level is the single-step kernel's: bit-identical results.
 #include "gcmf_multi_common.hpp"
+#include "gcmf_recurrence.hpp"
 #include <cstdlib>
 
 // Row-loop unroll factor: the per-level state of one iteration (previous-row stresses, the last two output rows, the fbar
@@ -259,10 +260,10 @@ __device__ __forceinline__ void cgrid_stream2_body(const CStream2P<T, FB> &P) {
           const T fiu = (T)((j == 1) ? x.fu[k] : accu[j - 1][k]);
           const T fiv = (T)((j == 1) ? x.fv[k] : accv[j - 1][k]);
           const T two = (last && j == S) ? T(1) : T(2);  // the last level of the last launch is the result: A, not 2 A
-          cu[j][k] = two * avu - x2u;
-          cv[j][k] = two * avv - x2v;
-          cu[j][k] = cu[j][k] + (T)pkj * fiu;
-          cv[j][k] = cv[j][k] + (T)pkj * fiv;
+          // (nothing here is bit-identical with numpy: every multiply-add pair is one fma -- fewer instructions, fewer roundings)
+          const T afu = rfma(-c, lu[k], -xu), afv = rfma(-c, lv[k], -xv);
+          cu[j][k] = rfma((T)pkj, fiu, rfma(two, afu, -x2u));
+          cv[j][k] = rfma((T)pkj, fiv, rfma(two, afv, -x2v));
           nau[j][k] = (FB)fiu;   // the row of f travels on with its row of the state
           nav[j][k] = (FB)fiv;
         } else if (j == 1 && first) {
