@@ -1,7 +1,10 @@
 """Build libgcmf.so (HIP, gfx950 only) in-tree with hipcc.  No torch, no cmake: the translation units compile in parallel."""
 from __future__ import annotations
 
+import glob
+import hashlib
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -11,7 +14,8 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "libgcmf.so")
 SOURCES = ["gcmf_api.hip", "gcmf_precompute.hip", "gcmf_scalar.hip", "gcmf_scalar_multi.hip", "gcmf_scalar_multi_reg.hip", "gcmf_scalar_multi_mask.hip", "gcmf_scalar_multi_maskz.hip", "gcmf_scalar_multi_flux.hip", "gcmf_flux_multi2.hip", "gcmf_vector.hip", "gcmf_cgrid_stream.hip", "gcmf_cgrid_stream2.hip", "gcmf_bgrid_stream.hip", "gcmf_bgrid_stream2.hip", "gcmf_landfix.hip", "gcmf_exchange.hip", "gcmf_ring_flux.hip", "gcmf_ring_maskz.hip", "gcmf_ring_reg.hip", "gcmf_ringc_flux.hip", "gcmf_ringc_maskz.hip", "gcmf_ringc_reg.hip"]
-HEADERS = [os.path.join(CSRC, "gcmf_internal.hpp"), os.path.join(CSRC, "gcmf_multi_common.hpp"), os.path.join(CSRC, "gcmf_scalar_multi_impl.hpp"), os.path.join(CSRC, "gcmf_recurrence.hpp"), os.path.join(CSRC, "gcmf_flux_multi2_body.hpp"), os.path.join(CSRC, "gcmf_ring_impl.hpp"), os.path.join(CSRC, "gcmf_ringc_impl.hpp"), os.path.join(INCLUDE, "gcmf.h")]
+BUILD_ID_SOURCE = "gcmf_buildid.hip"   # compiled on every link with -DGCMF_BUILD_ID=<source_build_id()>
+HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(INCLUDE, "gcmf.h")]
 # -ffp-contract=off: no FMA contraction, so the REGULAR / land-mask / B-grid kernels reproduce the
 # reference's (numpy's) rounding exactly; the kernels are HBM-bound, the extra VALU ops are free.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -19,6 +23,37 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 
 
 FLAGS += os.environ.get("GCMF_EXTRA_HIPCC_FLAGS", "").split()  # experiments (A/B builds on the GPU box)
+
+
+_ID_MARK = b"GCMF_BUILD_ID="
+
+
+def source_build_id() -> str:
+    """sha256 over every file under csrc/ that is source (*.hip, *.hpp, *.h), include/gcmf.h and the compiler flags:
+    the identity of the sources a binary has to come from.  libgcmf.so carries the value it was built with
+    (gcmf_build_id(), and a marker string in its data segment that binary_build_id() reads without dlopen)."""
+    h = hashlib.sha256()
+    files = sorted(p for ext in ("*.hip", "*.hpp", "*.h") for p in glob.glob(os.path.join(CSRC, ext)))
+    files.append(os.path.join(INCLUDE, "gcmf.h"))
+    for p in files:
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    h.update(" ".join(a for a in FLAGS if a not in (INCLUDE, CSRC)).encode())
+    return h.hexdigest()
+
+
+def binary_build_id(path: str = None):
+    """The build id baked into a libgcmf.so (None when the file is missing or carries none)."""
+    path = path or LIB
+    try:
+        with open(path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    m = re.search(re.escape(_ID_MARK) + rb"([0-9a-f]{64})", blob)
+    return m.group(1).decode() if m else None
 
 
 def hipcc() -> str:
@@ -38,6 +73,10 @@ def _stale(target: str, deps) -> bool:
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile every .hip source to an object (in parallel) and link csrc/libgcmf.so.  Returns its path."""
     objs, procs = [], []
+    want_id = source_build_id()
+    if not force and os.path.exists(LIB) and binary_build_id() != want_id and not any(
+            _stale(os.path.join(CSRC, s.replace(".hip", ".o")), [os.path.join(CSRC, s)] + HEADERS) for s in SOURCES):
+        force = True    # the objects look fresh by mtime but the binary was made from other sources: trust the hash
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
@@ -56,11 +95,20 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             print(out, file=sys.stderr)
     if failed:
         raise RuntimeError("hipcc failed:\n" + "\n".join(failed))
-    if force or procs or _stale(LIB, objs):
-        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    if force or procs or _stale(LIB, objs) or binary_build_id() != want_id:
+        ido = os.path.join(CSRC, BUILD_ID_SOURCE.replace(".hip", ".o"))
+        r = subprocess.run([hipcc(), *FLAGS, f'-DGCMF_BUILD_ID="{want_id}"', "-c", os.path.join(CSRC, BUILD_ID_SOURCE), "-o", ido],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + r.stdout)
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, ido]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout)
+        for junk in glob.glob(LIB + ".*"):      # offload-bundler by-products of the link
+            os.remove(junk)
+        if binary_build_id() != want_id:
+            raise RuntimeError("libgcmf.so does not carry the build id it was linked with")
     return LIB
 
 

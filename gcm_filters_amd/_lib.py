@@ -31,6 +31,7 @@ EXPORTS = [
     "gcmf_multi_supported", "gcmf_cheb_multi", "gcmf_multi_supported_vec", "gcmf_cheb_multi_vec",
     "gcmf_has_land", "gcmf_zero_land", "gcmf_land_fix", "gcmf_last_kernel", "gcmf_last_kernel_timing", "gcmf_ring_fallbacks", "gcmf_clenshaw_cut",
     "gcmf_comm_unique_id", "gcmf_comm_create", "gcmf_comm_destroy", "gcmf_halo_start", "gcmf_halo_finish",
+    "gcmf_build_id",
 ]
 PLAN_SELF_RING, PLAN_SKIP_KAPPA_ONE = 0x1, 0x2
 
@@ -54,16 +55,43 @@ _lib = None
 _lock = threading.Lock()
 
 
+class StaleLibraryError(RuntimeError):
+    """csrc/libgcmf.so was not built from the sources next to it and cannot be rebuilt here."""
+
+
+def ensure_fresh_library() -> str:
+    """Make sure csrc/libgcmf.so comes from the sources beside it: the binary carries the sha256 of csrc/* +
+    include/gcmf.h + flags it was compiled from (gcmf_build_id()).  Missing or different: rebuild with hipcc when
+    there is one, raise StaleLibraryError otherwise -- a stale binary is never loaded silently."""
+    from . import _build
+    want = _build.source_build_id()
+    have = _build.binary_build_id(LIB_PATH)
+    if have == want:
+        return want
+    try:
+        _build.hipcc()
+    except RuntimeError:
+        what = "is missing" if have is None and not os.path.exists(LIB_PATH) else f"has build id {have}"
+        raise StaleLibraryError(f"{LIB_PATH} {what}, the sources have {want}, and there is no hipcc to rebuild it") from None
+    _build.build_library()
+    have = _build.binary_build_id(LIB_PATH)
+    if have != want:
+        raise StaleLibraryError(f"rebuilt {LIB_PATH} carries build id {have}, the sources have {want}")
+    return want
+
+
 def load() -> C.CDLL:
-    """dlopen libgcmf.so, building it with hipcc first if the in-tree binary is missing."""
+    """dlopen libgcmf.so after checking that it was built from the sources beside it (rebuilt with hipcc if not)."""
     global _lib
     with _lock:
         if _lib is not None:
             return _lib
-        if not os.path.exists(LIB_PATH):
-            from ._build import build_library
-            build_library()
+        want = ensure_fresh_library()
         lib = C.CDLL(LIB_PATH)
+        lib.gcmf_build_id.argtypes = []
+        lib.gcmf_build_id.restype = C.c_char_p
+        if lib.gcmf_build_id().decode() != want:
+            raise StaleLibraryError(f"{LIB_PATH}: gcmf_build_id() disagrees with the marker in the file")
         vp, vpp = C.c_void_p, C.POINTER(C.c_void_p)
         lib.gcmf_plan_create.argtypes = [C.POINTER(PlanDesc), vpp, C.c_int, vpp]
         lib.gcmf_plan_create.restype = C.c_int

@@ -287,6 +287,9 @@ int gcmf_set_tuning(gcmf_plan *plan, int rows_per_wave, int xcd_remap, int multi
 /* Last error text of the calling thread (never NULL). */
 const char *gcmf_last_error(void);
 int gcmf_version(void);
+/* sha256 (64 hex digits) of the sources and compiler flags this binary was built from; the loader
+ * (gcm_filters_amd/_lib.py load()) recomputes it from csrc/ + include/gcmf.h and refuses a binary that does not match. */
+const char *gcmf_build_id(void);
 
 #ifdef __cplusplus
 }

@@ -32,6 +32,39 @@ def test_library_exports_every_declared_symbol():
     assert lib.gcmf_version() == 1
 
 
+def test_binary_is_bound_to_its_sources(monkeypatch):
+    """libgcmf.so carries the sha256 of the sources it was compiled from; the loader rebuilds a binary that does not
+    match when hipcc is there and refuses it otherwise -- it never loads a stale binary silently."""
+    from gcm_filters_amd import _build
+    want = _build.source_build_id()
+    assert re.fullmatch(r"[0-9a-f]{64}", want)
+    assert _build.binary_build_id() == want                      # the in-tree binary is the sources' binary
+    assert _lib.load().gcmf_build_id().decode() == want          # ... and says so through the C ABI
+    assert _lib.ensure_fresh_library() == want                   # fresh: neither branch below is taken
+
+    built = []
+    monkeypatch.setattr(_build, "source_build_id", lambda: "f" * 64)   # pretend the sources changed
+    monkeypatch.setattr(_build, "build_library", lambda *a, **k: built.append(1))
+    with pytest.raises(_lib.StaleLibraryError, match="rebuilt .* carries build id"):   # hipcc present: a rebuild is tried
+        _lib.ensure_fresh_library()
+    assert built == [1]
+
+    def no_hipcc():
+        raise RuntimeError("hipcc not found")
+    monkeypatch.setattr(_build, "hipcc", no_hipcc)
+    with pytest.raises(_lib.StaleLibraryError, match="no hipcc to rebuild"):            # no compiler: refuse
+        _lib.ensure_fresh_library()
+    assert built == [1]
+
+
+def test_no_build_by_products_are_tracked():
+    import subprocess
+    if not os.path.isdir(os.path.join(REPO, ".git")):
+        pytest.skip("not a git checkout")
+    files = subprocess.run(["git", "ls-files"], cwd=REPO, capture_output=True, text=True).stdout.split()
+    assert not [f for f in files if "libgcmf.so" in f or f.endswith((".o", ".so"))]
+
+
 def test_static_grid_facts_match_reference_table():
     lib = _lib.load()
     for name, val in O.GRID_TYPE_VALUES.items():
