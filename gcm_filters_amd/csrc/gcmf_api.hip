@@ -471,6 +471,7 @@ int gcmf_set_timing(gcmf_plan *pl, int enabled) {
 }
 int gcmf_last_kernel_timing(const gcmf_plan *pl, float *ms_sum, int *n_launches, float *ms_min, float *ms_max) {
   if (!pl) return GCMF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(const_cast<gcmf_plan *>(pl)->mu);   // dom_* are written by a running gcmf_apply
   if (ms_sum) *ms_sum = pl->dom_ms;
   if (n_launches) *n_launches = pl->dom_n;
   if (ms_min) *ms_min = pl->dom_min;
@@ -479,6 +480,7 @@ int gcmf_last_kernel_timing(const gcmf_plan *pl, float *ms_sum, int *n_launches,
 }
 int gcmf_last_timing(const gcmf_plan *pl, float *ms_total, int *n_launches) {
   if (!pl) return GCMF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(const_cast<gcmf_plan *>(pl)->mu);
   if (ms_total) *ms_total = pl->last_ms;
   if (n_launches) *n_launches = pl->last_launches;
   return GCMF_OK;
@@ -496,7 +498,9 @@ int gcmf_ring_fallbacks(gcmf_plan *pl, int64_t *count) {
   *count = 0;
   if (!pl->ring_nfb) return GCMF_OK;
   unsigned n = 0;
-  GCMF_HIP(hipDeviceSynchronize());
+  std::lock_guard<std::mutex> lk(pl->mu);          // not while an apply of this plan is enqueueing
+  GCMF_HIP(hipSetDevice(pl->d.device));            // the plan's device, not whichever is current in this thread
+  GCMF_HIP(hipDeviceSynchronize());                // callers may run the plan on any stream of that device
   GCMF_HIP(hipMemcpy(&n, pl->ring_nfb, sizeof n, hipMemcpyDeviceToHost));
   GCMF_HIP(hipMemset(pl->ring_nfb, 0, sizeof n));
   *count = n;

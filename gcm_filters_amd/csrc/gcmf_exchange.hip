@@ -79,6 +79,30 @@ static bool rccl_load() {
     }                                                                                           \
   } while (0)
 
+// Inside ncclGroupStart .. ncclGroupEnd: remember the first failure, keep going to GroupEnd (an early return would leave the
+// group open and the comm unusable), then GCMF_NCCL_GROUP_END reports it and clears the exchange state.
+#define GCMF_NCCL_IN_GROUP(call)                                                                    \
+  do {                                                                                              \
+    int r_ = grp_rc ? 0 : (call);                                                                   \
+    if (r_ != 0) {                                                                                  \
+      grp_rc = r_;                                                                                  \
+      set_error("%s failed: %s (%s:%d)", #call, g_rccl.GetErrorString(r_), __FILE__, __LINE__);     \
+    }                                                                                               \
+  } while (0)
+#define GCMF_NCCL_GROUP_END()                                                                       \
+  do {                                                                                              \
+    int e_ = g_rccl.GroupEnd();                                                                     \
+    if (!grp_rc && e_ != 0) {                                                                       \
+      grp_rc = e_;                                                                                  \
+      set_error("ncclGroupEnd failed: %s (%s:%d)", g_rccl.GetErrorString(e_), __FILE__, __LINE__);  \
+    }                                                                                               \
+    if (grp_rc) {                                                                                   \
+      c->states.clear();                                                                            \
+      c->pending_unpack = false;                                                                    \
+      return GCMF_ERR_HIP;                                                                          \
+    }                                                                                               \
+  } while (0)
+
 // rows [r0, r0 + nrows) of every block of `src` (nblocks, rows_alloc, nx) <-> a packed (nblocks, nrows, nx) buffer;
 // 16 bytes per lane, row_bytes is a multiple of 16 (checked by the caller)
 __global__ void k_pack_rows(const uint4 *__restrict__ state, uint4 *__restrict__ packed, long long block_q, int row_q, int r0,
@@ -201,6 +225,12 @@ int gcmf_halo_start(gcmf_comm *c, void *const *states, int nstate, int64_t nbloc
   c->states.assign(states, states + nstate);
   c->nblocks = nblocks; c->rows_alloc = (int)rows_alloc; c->nx = (int)nx; c->first_owned = (int)first_owned;
   c->rows_owned = (int)rows_owned; c->halo = halo; c->south = south; c->north = north; c->esize = es;
+  int grp_rc = 0;
+  struct Abandon {   // any failing return below leaves no half-posted exchange behind (the next gcmf_halo_start would refuse)
+    gcmf_comm *c;
+    bool posted = false;
+    ~Abandon() { if (!posted) { c->states.clear(); c->pending_unpack = false; } }
+  } abandon{c};
   if (!packed) {
     GCMF_NCCL(g_rccl.GroupStart());
     // per peer the order of sends is [northward, southward] and of receives [into south ghosts, into north ghosts]:
@@ -208,12 +238,12 @@ int gcmf_halo_start(gcmf_comm *c, void *const *states, int nstate, int64_t nbloc
     for (int q = 0; q < nstate; ++q)
       for (int64_t b = 0; b < nblocks; ++b) {
         char *base = (char *)states[q] + (size_t)b * block_bytes;
-        if (north >= 0) GCMF_NCCL(g_rccl.Send(base + (size_t)r_top * row_bytes, edge, 0, north, c->comm, c->side));
-        if (south >= 0) GCMF_NCCL(g_rccl.Send(base + (size_t)r_bot * row_bytes, edge, 0, south, c->comm, c->side));
-        if (south >= 0) GCMF_NCCL(g_rccl.Recv(base + (size_t)g_s * row_bytes, edge, 0, south, c->comm, c->side));
-        if (north >= 0) GCMF_NCCL(g_rccl.Recv(base + (size_t)g_n * row_bytes, edge, 0, north, c->comm, c->side));
+        if (north >= 0) GCMF_NCCL_IN_GROUP(g_rccl.Send(base + (size_t)r_top * row_bytes, edge, 0, north, c->comm, c->side));
+        if (south >= 0) GCMF_NCCL_IN_GROUP(g_rccl.Send(base + (size_t)r_bot * row_bytes, edge, 0, south, c->comm, c->side));
+        if (south >= 0) GCMF_NCCL_IN_GROUP(g_rccl.Recv(base + (size_t)g_s * row_bytes, edge, 0, south, c->comm, c->side));
+        if (north >= 0) GCMF_NCCL_IN_GROUP(g_rccl.Recv(base + (size_t)g_n * row_bytes, edge, 0, north, c->comm, c->side));
       }
-    GCMF_NCCL(g_rccl.GroupEnd());
+    GCMF_NCCL_GROUP_END();
     c->pending_unpack = false;
   } else {
     const size_t part = (size_t)nstate * nblocks * edge;
@@ -243,14 +273,15 @@ int gcmf_halo_start(gcmf_comm *c, void *const *states, int nstate, int64_t nbloc
     }
     GCMF_HIP(hipGetLastError());
     GCMF_NCCL(g_rccl.GroupStart());
-    if (north >= 0) GCMF_NCCL(g_rccl.Send(sn, part, 0, north, c->comm, c->side));
-    if (south >= 0) GCMF_NCCL(g_rccl.Send(ss, part, 0, south, c->comm, c->side));
-    if (south >= 0) GCMF_NCCL(g_rccl.Recv(rs, part, 0, south, c->comm, c->side));
-    if (north >= 0) GCMF_NCCL(g_rccl.Recv(rn, part, 0, north, c->comm, c->side));
-    GCMF_NCCL(g_rccl.GroupEnd());
+    if (north >= 0) GCMF_NCCL_IN_GROUP(g_rccl.Send(sn, part, 0, north, c->comm, c->side));
+    if (south >= 0) GCMF_NCCL_IN_GROUP(g_rccl.Send(ss, part, 0, south, c->comm, c->side));
+    if (south >= 0) GCMF_NCCL_IN_GROUP(g_rccl.Recv(rs, part, 0, south, c->comm, c->side));
+    if (north >= 0) GCMF_NCCL_IN_GROUP(g_rccl.Recv(rn, part, 0, north, c->comm, c->side));
+    GCMF_NCCL_GROUP_END();
     c->pending_unpack = true;
   }
   (void)g_s; (void)g_n;
+  abandon.posted = true;
   return GCMF_OK;
 }
 

@@ -389,12 +389,16 @@ class SlabFilter:
             if overlap:
                 # the next launch needs fresh ghost rows: advance the rows the neighbours need first, post the exchange of the
                 # NEW state, and let the interior rows run while the messages are in flight
+                # The messages carry the OWNED edge rows [fo, fo+s) / [fo+ro-s, fo+ro): with ghost rows left over (v_out > 0)
+                # the edge launches start v_out rows outside them and must reach to their inner end
+                ilo = fo + s if self.gs else lo
+                ihi = fo + ro - s if self.gn else hi
                 if self.gs:
-                    self.engine.multi(*args, lo, lo + s)
+                    self.engine.multi(*args, lo, ilo)
                 if self.gn:
-                    self.engine.multi(*args, hi - s, hi)
+                    self.engine.multi(*args, ihi, hi)
                 pending = self._exchange_start([free[0], free[1]])
-                self.engine.multi(*args, lo + (s if self.gs else 0), hi - (s if self.gn else 0))
+                self.engine.multi(*args, ilo, ihi)
                 self._exchange_finish(pending)
                 v_out = s
             else:

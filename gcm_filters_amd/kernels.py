@@ -238,35 +238,63 @@ class _PlanCache:
         self.capacity = capacity
         self._d: "OrderedDict[Tuple, Tuple]" = OrderedDict()   # key -> (plan, owner weakrefs, lock tickets)
         self._lock = threading.Lock()
+        self._building: Dict[Tuple, threading.Lock] = {}      # key -> lock held by the thread folding that plan
 
     @staticmethod
     def _drop(entry):
+        """Explicit clear only: frees the HBM now.  Nobody may be running the plan."""
         plan, _, tickets = entry
         plan.close()
         _HOST_LOCKS.release(tickets)
 
+    @staticmethod
+    def _forget(entry):
+        """Take an entry out of the cache WITHOUT destroying its plan: another (dask worker) thread may have been handed
+        it a moment ago and be inside gcmf_apply.  The plan frees its HBM when its last holder lets go (Plan.__del__)."""
+        _HOST_LOCKS.release(entry[2])
+
+    def _lookup(self, key):
+        ent = self._d.get(key)
+        if ent is None:
+            return None
+        if all(r() is not None for r in ent[1]):
+            self._d.move_to_end(key)
+            return ent[0]
+        self._forget(self._d.pop(key))   # a buffer was freed since: same address, unknown contents
+        return None
+
     def get(self, key, factory, host_planes=()):
         """The plan for `key`, built by `factory` if absent.  `host_planes`: the numpy grid planes the plan is folded from
-        (write-protected while the plan is cached; the entry dies with the owners of their buffers)."""
+        (write-protected while the plan is cached; the entry dies with the owners of their buffers).  Threads that miss on
+        the same key together build ONE plan: the first folds it, the others wait and are handed the same object."""
         with self._lock:
-            ent = self._d.get(key)
-            if ent is not None:
-                if all(r() is not None for r in ent[1]):
-                    self._d.move_to_end(key)
-                    return ent[0]
-                self._drop(self._d.pop(key))   # a buffer was freed since: same address, unknown contents
-        p = factory()
-        nps = [a for a in host_planes if isinstance(a, np.ndarray)]
-        owners = [weakref.ref(_owner(a)) for a in nps]
-        tickets = _HOST_LOCKS.acquire(nps)
-        with self._lock:
-            old = self._d.pop(key, None)
-            if old is not None:
-                self._drop(old)
-            self._d[key] = (p, owners, tickets)
-            while len(self._d) > self.capacity:
-                _, ev = self._d.popitem(last=False)
-                self._drop(ev)
+            p = self._lookup(key)
+            if p is not None:
+                return p
+            gate = self._building.setdefault(key, threading.Lock())
+        with gate:
+            with self._lock:
+                p = self._lookup(key)     # folded by the thread that held the gate before us
+                if p is not None:
+                    return p
+            try:
+                p = factory()
+            except BaseException:
+                with self._lock:
+                    self._building.pop(key, None)
+                raise
+            nps = [a for a in host_planes if isinstance(a, np.ndarray)]
+            owners = [weakref.ref(_owner(a)) for a in nps]
+            tickets = _HOST_LOCKS.acquire(nps)
+            with self._lock:
+                old = self._d.pop(key, None)
+                if old is not None:       # cannot happen under the gate; never destroy what another thread may hold
+                    self._forget(old)
+                self._d[key] = (p, owners, tickets)
+                self._building.pop(key, None)
+                while len(self._d) > self.capacity:
+                    _, ev = self._d.popitem(last=False)
+                    self._forget(ev)
         return p
 
     def clear(self):

@@ -94,3 +94,60 @@ class OracleSlabEngine:
                 uo[q][:, rows, :] = lvl[S][q][:, rows, :]
                 vo[q][:, rows, :] = lvl[S - 1][q][:, rows, :]
                 fb_out[q][:, rows, :] = fb[q][:, rows, :]
+
+
+STEP_CLENSHAW = 0x10
+
+
+class OracleClenshawSlabEngine(OracleSlabEngine):
+    """The same stand-in offering the BACKWARD evaluation (gcmf_cheb_multi with GCMF_STEP_CLENSHAW) so
+    that SlabFilter._apply_backward runs under gloo: b_n = p_n f, b_k = p_k f + 2A(b_{k+1}) - b_{k+2}, result
+    p_0 f + A(b_1) - b_2, cut into launches of DEPTHS levels (tests set the class attribute)."""
+    DEPTH = 4
+
+    def clenshaw_cut(self, n_steps):
+        if self.name in O.VECTOR:
+            return []
+        cut, left = [], n_steps
+        while left > 0:
+            cut.append(min(self.DEPTH, left))
+            left -= cut[-1]
+        return cut
+
+    def has_land(self):
+        return False          # land cells take part in the stand-in's state: no land_fix pass
+
+    def _A(self, x, c, rows):
+        """A(x) = -x - c L(x) on rows `rows` of the slab array x (nbatch, rows_alloc, nx); poison outside what is valid."""
+        with np.errstate(all="ignore"):
+            L = self.lap(self._embed(x))
+        return -x[:, rows, :] - c * L[:, self.gidx, :][:, rows, :]
+
+    def multi(self, u, v, uo, vo, fb_in, fb_out, pk, p0, c, mode, nbatch, row_lo, row_hi):
+        if not (mode & STEP_CLENSHAW):
+            return super().multi(u, v, uo, vo, fb_in, fb_out, pk, p0, c, mode, nbatch, row_lo, row_hi)
+        S = len(pk)
+        first, last = bool(mode & STEP_FIRST), bool(mode & STEP_LAST)
+        f = fb_in[0].numpy().copy()
+        if self.area is not None:
+            f = f * self.area[self.gidx]
+        if first:
+            b1, b2 = p0 * f, np.zeros_like(f)
+        else:
+            b1, b2 = u[0].numpy().copy(), v[0].numpy().copy()
+        for t in range(1, S + 1):
+            lo, hi = max(row_lo - (S - t), 0), min(row_hi + (S - t), self.rows_alloc)
+            rows = slice(lo, hi)
+            new = np.full_like(b1, POISON)
+            two = 1.0 if (last and t == S) else 2.0
+            new[:, rows, :] = pk[t - 1] * f[:, rows, :] + two * self._A(b1, c, rows) - b2[:, rows, :]
+            b1, b2 = new, b1
+        rows = slice(row_lo, row_hi)
+        if last:
+            res = b1[:, rows, :]
+            if self.area is not None:
+                res = res / self.area[self.gidx[rows]]
+            fb_out[0].numpy()[:, rows, :] = res
+        else:
+            uo[0].numpy()[:, rows, :] = b1[:, rows, :]
+            vo[0].numpy()[:, rows, :] = b2[:, rows, :]

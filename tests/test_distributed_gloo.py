@@ -53,6 +53,18 @@ CASES_8 = [
 ]
 
 
+# The backward (Clenshaw) slab driver (SlabFilter._apply_backward) with the overlapped exchange: (grid, shape, halo, depth of a
+# launch, n_steps).  halo not a multiple of the depth leaves ghost rows over (v_out > 0) when the exchange is posted -- the
+# case ADVICE r2 found sending rows the interior launch had not written yet.
+CASES_BACKWARD = [
+    ("IRREGULAR_WITH_LAND", (72, 16), 6, 4, 13),        # valid 6 -> 2 (overlap, v_out 2) -> 6 -> 2 ...
+    ("REGULAR_WITH_LAND_AREA_WEIGHTED", (96, 16), 7, 5, 17),
+    ("REGULAR", (72, 16), 4, 4, 12),                     # halo a multiple of the depth: v_out = 0 at every exchange
+    ("MOM5T", (90, 16), 5, 3, 11),
+    ("IRREGULAR_WITH_LAND", (24, 16), 4, 3, 9),         # slabs too short to overlap: one launch + blocking exchange
+]
+
+
 def _problem(grid, shape, nbatch):
     vec = grid in T.VECTOR_GRIDS
     gv = T.vector_grid_vars(grid, shape) if vec else T.scalar_grid_vars(grid, shape)
@@ -90,6 +102,20 @@ def _worker(rank, world, port, q):
                     want = (O.filter_func(spec, grid, fields[0], gv),)
             e = max(float(np.abs(g - w).max() / np.abs(w).max()) for g, w in zip(got, want))
             errs[f"{grid}-{shape}-h{halo}-b{nbatch}"] = (e, sf.exchanges, sf.n_steps, sf.halo)
+        for grid, shape, halo, depth, n in (CASES_BACKWARD if world in (2, 3) else []):
+            from slab_engines import OracleClenshawSlabEngine
+            gv, fields, fk = _problem(grid, shape, 2)
+            fk["n_steps"] = n
+            eng = type("Eng", (OracleClenshawSlabEngine,), {"DEPTH": depth})
+            sf = SlabFilter(grid, gv, fk, shape[0], shape[1], halo=halo, engine_factory=eng, device=-1)
+            assert sf.backward_cut and max(sf.backward_cut) == depth
+            sf.overlap = True
+            got = sf.gather_to_global(sf.apply_local(sf.scatter_from_global(fields)))
+            spec = O.make_spec(fk["filter_scale"], fk["dx_min"], "GAUSSIAN", n_steps=n)
+            with np.errstate(all="ignore"):
+                want = O.filter_func(spec, grid, fields[0], gv)
+            e = float(np.abs(got[0] - want).max() / np.abs(want).max())
+            errs[f"backward-{grid}-{shape}-h{halo}-d{depth}-n{n}"] = (e, None, n, halo)
         if rank == 0:
             q.put(errs)
     finally:
@@ -109,10 +135,11 @@ def test_slab_filter_matches_single_domain(world):
     for p in procs:
         assert p.exitcode == 0, f"worker exit code {p.exitcode}"
     errs = q.get()
-    assert len(errs) == len(CASES_8 if world == 8 else CASES)
+    assert len(errs) == (len(CASES_8) if world == 8 else len(CASES) + len(CASES_BACKWARD))
     for name, (e, nex, n, halo) in errs.items():
         assert e < 1e-12, (name, e)
-        assert nex == -(-n // halo), (name, nex, n, halo)  # one exchange per `halo` steps
+        if nex is not None:
+            assert nex == -(-n // halo), (name, nex, n, halo)  # one exchange per `halo` steps
 
 
 def test_slab_bounds_cover_grid():

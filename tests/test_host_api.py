@@ -303,3 +303,65 @@ def test_host_planes_are_write_protected_while_a_plan_refers_to_them():
     K._HOST_LOCKS.release(K._HOST_LOCKS.acquire([ro]))
     assert not ro.flags.writeable
     assert K._owner(v) is a and K._fingerprint(a) == K._fingerprint(a)
+
+
+# ---------------------------------------------------------------------------------------------------
+# plan cache (a displaced / evicted plan must never be destroyed under a thread that holds it)
+# ---------------------------------------------------------------------------------------------------
+class _FakePlan:
+    def __init__(self):
+        self.closed = 0
+
+    def close(self):
+        self.closed += 1
+
+
+def test_plan_cache_cold_miss_from_many_threads_builds_one_plan():
+    import threading
+    import time
+    from gcm_filters_amd.kernels import _PlanCache
+
+    cache = _PlanCache(capacity=4)
+    built, got = [], []
+    start = threading.Barrier(8)
+
+    def factory():
+        time.sleep(0.05)              # long enough for every thread to have missed
+        built.append(_FakePlan())
+        return built[-1]
+
+    def worker():
+        start.wait()
+        got.append(cache.get(("k",), factory))
+
+    th = [threading.Thread(target=worker) for _ in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert len(built) == 1 and all(g is built[0] for g in got) and built[0].closed == 0
+
+
+def test_plan_cache_eviction_and_dead_owner_do_not_destroy_a_plan_in_use():
+    from gcm_filters_amd.kernels import _PlanCache
+
+    cache = _PlanCache(capacity=2)
+    plans = [cache.get((k,), _FakePlan) for k in range(4)]       # 0 and 1 are evicted while a caller still holds them
+    assert [p.closed for p in plans] == [0, 0, 0, 0]
+    assert cache.get((3,), _FakePlan) is plans[3] and cache.get((0,), _FakePlan) is not plans[0]
+    a = np.ones((4, 4))
+    held = cache.get(("arr",), _FakePlan, host_planes=[a])
+    assert not a.flags.writeable                                   # write-protected while cached
+    del a                                                          # owner dies: the entry is forgotten, the plan survives
+    assert cache.get(("arr",), _FakePlan) is not held and held.closed == 0
+    cache.clear()                                                  # the explicit clear is the only thing that closes
+
+
+def test_plan_cache_factory_error_leaves_no_gate_behind():
+    from gcm_filters_amd.kernels import _PlanCache
+
+    cache = _PlanCache()
+
+    def boom():
+        raise ValueError("kappa")
+    with pytest.raises(ValueError):
+        cache.get(("k",), boom)
+    assert cache.get(("k",), _FakePlan).closed == 0 and not cache._building
