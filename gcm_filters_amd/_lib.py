@@ -31,7 +31,7 @@ EXPORTS = [
     "gcmf_multi_supported", "gcmf_cheb_multi", "gcmf_multi_supported_vec", "gcmf_cheb_multi_vec",
     "gcmf_has_land", "gcmf_zero_land", "gcmf_land_fix", "gcmf_last_kernel", "gcmf_last_kernel_timing", "gcmf_ring_fallbacks", "gcmf_clenshaw_cut",
     "gcmf_comm_unique_id", "gcmf_comm_create", "gcmf_comm_destroy", "gcmf_halo_start", "gcmf_halo_finish",
-    "gcmf_build_id",
+    "gcmf_build_id", "gcmf_last_kernel_geometry",
 ]
 PLAN_SELF_RING, PLAN_SKIP_KAPPA_ONE = 0x1, 0x2
 
@@ -149,6 +149,8 @@ def load() -> C.CDLL:
         lib.gcmf_ring_fallbacks.restype = C.c_int
         lib.gcmf_last_kernel.argtypes = [vp, C.c_char_p, C.c_int]
         lib.gcmf_last_kernel.restype = C.c_int
+        lib.gcmf_last_kernel_geometry.argtypes = [vp, C.c_char_p, C.c_int]
+        lib.gcmf_last_kernel_geometry.restype = C.c_int
         lib.gcmf_set_timing.argtypes = [vp, C.c_int]
         lib.gcmf_set_timing.restype = C.c_int
         lib.gcmf_set_tuning.argtypes = [vp, C.c_int, C.c_int, C.c_int]
@@ -335,6 +337,16 @@ class Plan:
         buf = C.create_string_buffer(256)
         check(load().gcmf_last_kernel(self._h, buf, 256))
         return buf.value.decode()
+
+    def last_kernel_geometry(self) -> dict:
+        """Launch geometry of the kernel last_kernel() named: {"H", "nstrips", "nwx", "xcd", "grid", "rows"} ({} if none)."""
+        buf = C.create_string_buffer(256)
+        check(load().gcmf_last_kernel_geometry(self._h, buf, 256))
+        out = {}
+        for tok in buf.value.decode().split():
+            k, _, v = tok.partition("=")
+            out[k] = v if "x" in v else int(v)
+        return out
 
     def set_tuning(self, rows_per_wave: int = 0, xcd_remap: int = -1, multi_s: int = 0, strip_rows: int = 0,
                    prefetch_rows: int = 0, clenshaw: int = -1):

@@ -493,6 +493,12 @@ int gcmf_last_kernel(gcmf_plan *pl, char *buf, int n) {
   pl->last_kernel_weight = 0;
   return GCMF_OK;
 }
+int gcmf_last_kernel_geometry(gcmf_plan *pl, char *buf, int n) {
+  if (!pl || !buf || n < 1) return GCMF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(pl->mu);
+  snprintf(buf, (size_t)n, "%s", pl->last_geom.c_str());
+  return GCMF_OK;
+}
 int gcmf_ring_fallbacks(gcmf_plan *pl, int64_t *count) {
   if (!pl || !count) return GCMF_ERR_INVALID_ARG;
   *count = 0;

@@ -468,7 +468,8 @@ template <typename T, typename FB, int VEC, int S, int D, bool PRIV, bool CLEN =
     }
     hipLaunchKernelGGL((k_cgrid_stream2c<T, VEC, S, D, PRIV>), grid, block, lds, s, P);
     note_kernel(pl, std::string("gcmf::k_cgrid_stream2c<") + tyname<T>() + ", " + std::to_string(VEC) + ", " + std::to_string(S) + ", " +
-                        std::to_string(D) + ", " + (PRIV ? "true" : "false") + ">", S);
+                        std::to_string(D) + ", " + (PRIV ? "true" : "false") + ">", S,
+                launch_geom(P.H, (nrows + H - 1) / H, P.nwx, 1, grid.x, grid.y, nrows));
   } else {
   if (!attr_set && lds > 48 * 1024) {
     GCMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cgrid_stream2<T, FB, VEC, S, D, PRIV>),
@@ -477,7 +478,8 @@ template <typename T, typename FB, int VEC, int S, int D, bool PRIV, bool CLEN =
   }
   hipLaunchKernelGGL((k_cgrid_stream2<T, FB, VEC, S, D, PRIV>), grid, block, lds, s, P);
   note_kernel(pl, std::string("gcmf::k_cgrid_stream2<") + tyname<T>() + ", " + tyname<FB>() + ", " + std::to_string(VEC) + ", " +
-                      std::to_string(S) + ", " + std::to_string(D) + ", " + (PRIV ? "true" : "false") + ">", S);
+                      std::to_string(S) + ", " + std::to_string(D) + ", " + (PRIV ? "true" : "false") + ">", S,
+              launch_geom(P.H, (nrows + H - 1) / H, P.nwx, 1, grid.x, grid.y, nrows));
   }
   GCMF_HIP(hipGetLastError());
   return GCMF_OK;

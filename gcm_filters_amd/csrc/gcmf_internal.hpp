@@ -145,6 +145,7 @@ struct gcmf_plan {
   // bench.py ties its HBM-traffic figures to the kernel that actually ran)
   std::string last_kernel;
   int last_kernel_weight = 0;
+  std::string last_geom;   // launch geometry of last_kernel (note_kernel)
   float last_ms = 0.f;
   int last_launches = 0;
   int rows_per_wave = 0;
@@ -175,12 +176,20 @@ struct gcmf_plan {
 namespace gcmf {
 template <typename T> inline const char *tyname() { return sizeof(T) == 8 ? "double" : "float"; }
 // name as rocprofv3 prints it (without "void " and the argument list); weight = recurrence steps per launch
-inline void note_kernel(gcmf_plan *pl, const std::string &name, int weight) {
+// geom: the launch geometry of blocked kernels ("H=.. nstrips=.. nwx=.. xcd=.. grid=..x.. rows=.."), what a PMC traffic
+// record of the kernel is only valid for (gcmf_last_kernel_geometry; bench.py load_traffic)
+inline void note_kernel(gcmf_plan *pl, const std::string &name, int weight, const std::string &geom = std::string()) {
   pl->last_launched = name;
   if (weight >= pl->last_kernel_weight) {
     pl->last_kernel = name;
     pl->last_kernel_weight = weight;
+    pl->last_geom = geom;
   }
+}
+inline std::string launch_geom(int H, int nstrips, int nwx, int xcd, unsigned gx, unsigned gy, int nrows) {
+  char b[160];
+  snprintf(b, sizeof b, "H=%d nstrips=%d nwx=%d xcd=%d grid=%ux%u rows=%d", H, nstrips, nwx, xcd, gx, gy, nrows);
+  return b;
 }
 size_t dtype_size(int dtype);
 // kernel launchers (defined in gcmf_scalar.hip / gcmf_vector.hip)

@@ -386,7 +386,7 @@ static int launch_ringc_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   hipLaunchKernelGGL((k_ringc<T, KIND, S, FIRST>), grid, block, 0, s, P);
   GCMF_HIP(hipGetLastError());
   note_kernel(pl, std::string("gcmf::k_ringc<") + tyname<T>() + ", " + std::to_string(KIND) + ", " + std::to_string(S) + ", " +
-                      (FIRST ? "true" : "false") + ">", S);
+                      (FIRST ? "true" : "false") + ">", S, launch_geom(P.H, P.nstrips, P.nwx, P.xcd_per > 0, grid.x, grid.y, nrows));
   return GCMF_OK;
 }
 

@@ -273,6 +273,10 @@ int gcmf_last_kernel_timing(const gcmf_plan *plan, float *ms_sum, int *n_launche
  * steps per launch since this was last called; "" if none ran.  Reading resets it.  Instrumentation only: bench.py
  * refuses to quote profiled HBM traffic for a kernel other than the one that ran. */
 int gcmf_last_kernel(gcmf_plan *plan, char *buf, int n);
+/* Launch geometry of that kernel ("H=<rows per strip> nstrips=.. nwx=<column windows> xcd=<0|1> grid=XxY rows=..";
+ * "" for kernels that are not strip-marched).  Survives gcmf_last_kernel's reset.  A PMC traffic record only
+ * describes the kernel at the geometry it was profiled with. */
+int gcmf_last_kernel_geometry(gcmf_plan *plan, char *buf, int n);
 /* Wave strips of the register-ring kernels (k_ring) that met a NaN / inf since this was last called and were redone by the
  * general kernel (results are the same; each costs about two strip times).  Synchronises the device; reading resets.  A large
  * count on ocean data means non-finite values in wet cells (NaN on land is masked on load and costs nothing). */

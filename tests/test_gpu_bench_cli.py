@@ -52,6 +52,15 @@ def test_single_gpu_line_carries_parity_and_roofline():
     assert par["rel_err"] <= 1e-6 and par["nan_pattern_equal"] is True
     assert par["reference_probes"]["rel_err"] <= 1e-6 and par["reference_probes"]["n_probes"] == 300
     rf = line["roofline"]
-    assert rf["kernel"].startswith("gcmf::k_") and rf["min_bytes_per_launch"] > 0 and 0 < rf["min_bytes_frac"] < 1
-    assert rf["traffic"] is None or rf["traffic_source"].startswith("profiles/")
+    # the contract's roofline is a hardware fraction: algorithmic bytes of one launch / launch time / 8 TB/s
+    assert rf["kernel"].startswith("gcmf::k_") and rf["alg_bytes_per_launch"] > 0 and 0 < rf["frac"] < 1
+    assert abs(rf["achieved"] - rf["alg_bytes_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9) <= 1e-6 * rf["achieved"]
+    assert rf["alg_one_pass_per_step_frac"] > rf["frac"] and rf["geometry"]["H"] > 0
+    if rf["traffic"] is not None:   # counter bytes are quoted only for the kernel AND launch geometry that were profiled
+        assert rf["traffic_source"].startswith("profiles/") and rf["frac"] <= rf["hbm_frac"] < 1
+        assert str(rf["geometry"]["H"]) in rf["traffic_source"]
+    for k in ("value_min", "value_max", "value_mean"):
+        assert line[k] > 0
+    assert line["value_min"] <= line["value"] <= line["value_max"]
+    assert line["timing"]["blocks"] == 2 and line["timing"]["plans_refolded_between_blocks"] == 1
     assert line["cpu_baseline"]["cores"] == 1

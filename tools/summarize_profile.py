@@ -39,6 +39,17 @@ for sub, cs in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]), ("
         for c, vals in d.items():
             res.setdefault(short, {})[c] = {"n": len(vals), "mean": sum(vals) / len(vals), "max": max(vals)}
 summary["pmc"] = res
+# the bench line of the traced run names the dominant kernel and the launch geometry it ran with: a PMC record is only
+# valid for that geometry (bench.py load_traffic compares it with gcmf_last_kernel_geometry of the run it annotates)
+for log in ("bench_trace.log", "bench_fetch.log"):
+    try:
+        line = [l for l in open(os.path.join(out, log)) if l.startswith("{")][-1]
+        rf = json.loads(line)["roofline"]
+        summary["bench_kernel"], summary["bench_geometry"] = rf["kernel"], rf["geometry"]
+        lines.append(f"== bench.py ({log}) ==\n{rf['kernel']}  geometry {rf['geometry']}  avg launch {rf['avg_launch_ms'] * 1e3:.1f} us (HIP events)")
+        break
+    except Exception:
+        continue
 lines.append("== PMC (per dispatch means) ==")
 for k, d in res.items():
     lines.append(k)

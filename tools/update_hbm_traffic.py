@@ -32,6 +32,10 @@ rec = {
     "l2_hit_rate": (p["TCC_HIT_sum"]["mean"] / (p["TCC_HIT_sum"]["mean"] + p["TCC_MISS_sum"]["mean"])) if "TCC_HIT_sum" in p else None,
     "source": f"profiles/{rnd}/{base}_summary.txt",
 }
+if s.get("bench_kernel") and s["bench_kernel"] in kern.replace("void ", ""):
+    rec["geometry"] = s["bench_geometry"]   # launch geometry at profile time: bench.py quotes the bytes only for the same one
+else:
+    print(f"WARNING: the traced bench line names {s.get('bench_kernel')!r}, not {kern!r}: no geometry recorded, bench.py will withhold the traffic")
 if sq:
     txt = open(sq).read()
     blk = txt[txt.index(kern):]
