@@ -154,14 +154,26 @@ static int dom_collect(gcmf_plan *pl) {
 // streaming kernel, so the top S rows ("band") are advanced by S single-step launches instead.  Band step t
 // recomputes a ghost zone [rows-2S+t, rows-S) below the band that shrinks by one row per step (the same
 // trick the multi-GPU slabs use) and only rows >= rows-S update fbar / the output states.
-int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launches) {
+static int launch_ringc(gcmf_plan *pl, const MultiArgs &m, hipStream_t s) {
+  switch (pl->kind) {
+    case K_REG: return launch_ringc_reg(pl, m, s);
+    case K_MASK: return launch_ringc_maskz(pl, m, s);
+    case K_FLUX: return launch_ringc_flux(pl, m, s);
+    default: break;
+  }
+  set_error("k_ringc: plan is not a scalar kind");
+  return GCMF_ERR_INVALID_ARG;
+}
+
+int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launches, bool backward) {
   const Geom &g = pl->g;
   const int rows = g.rows, S = m.S;
   const bool band = g.fold && m.row_hi == rows;
   int rc;
+  auto blocked = [&](const MultiArgs &a) { return backward ? launch_ringc(pl, a, s) : launch_scalar_multi(pl, a, s); };
   if (!band) {
     if ((rc = dom_begin(pl, s))) return rc;
-    if ((rc = launch_scalar_multi(pl, m, s))) return rc;
+    if ((rc = blocked(m))) return rc;
     if ((rc = dom_end(pl, s))) return rc;
     if (launches) ++*launches;
     return GCMF_OK;
@@ -173,6 +185,32 @@ int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launche
   }
   MultiArgs mm = m;
   mm.row_hi = blo;
+  if (pl->fold_band && fold_band_supported(pl, m)) {
+    // the band in ONE launch (k_fold_band, gcmf_foldband.hip) on the side stream beside the blocked launch: neither reads what the
+    // other writes (the band reads rows >= rows - 2S of the input planes, the two write disjoint rows of the output planes)
+    if (!pl->side) {
+      GCMF_HIP(hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking));
+      GCMF_HIP(hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
+      GCMF_HIP(hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
+    }
+    GCMF_HIP(hipEventRecord(pl->ev_fork, s));
+    GCMF_HIP(hipStreamWaitEvent(pl->side, pl->ev_fork, 0));
+    if ((rc = launch_fold_band(pl, m, backward, pl->side))) return rc;
+    if (launches) ++*launches;
+    GCMF_HIP(hipEventRecord(pl->ev_join, pl->side));
+    if (mm.row_hi > mm.row_lo) {
+      if ((rc = dom_begin(pl, s))) return rc;
+      if ((rc = blocked(mm))) return rc;
+      if ((rc = dom_end(pl, s))) return rc;
+      if (launches) ++*launches;
+    }
+    GCMF_HIP(hipStreamWaitEvent(s, pl->ev_join, 0));
+    return GCMF_OK;
+  }
+  if (backward) {
+    set_error("advance_multi: the backward evaluation on a tripolar plan needs k_fold_band");
+    return GCMF_ERR_UNSUPPORTED;
+  }
   const size_t ts = dtype_size(pl->d.dtype);
   const size_t plane = align_up((size_t)m.nbatch * rows * g.nx * ts, 256);
   if (pl->band_bytes < 3 * plane) {
@@ -399,6 +437,7 @@ int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int 
   if (const char *e = getenv("GCMF_CLENSHAW")) pl->clenshaw = atoi(e);
   pl->band_rpw = (pl->d.dtype == GCMF_F32) ? 1 : 0;  // f32: one row per wave shortens the chain (+8 %); f64: no difference
   if (const char *e = getenv("GCMF_BAND_RPW")) pl->band_rpw = atoi(e);
+  if (const char *e = getenv("GCMF_FOLD_BAND")) pl->fold_band = atoi(e);
   PLAN_HIP(hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking));
   PLAN_HIP(hipEventCreate(&pl->ev0));
   PLAN_HIP(hipEventCreate(&pl->ev1));
@@ -569,7 +608,8 @@ static bool land_ok(const gcmf_plan *pl, int n_steps);
 static int clenshaw_cut(const gcmf_plan *pl, int n_steps, int *depths, int max_depths) {
   if (!pl || pl->ncomp != 1 || !(pl->clenshaw >= 2 || (pl->clenshaw == 1 && pl->kind == K_FLUX))) return 0;
   // (tripolar: of the GRID, not of this slab -- every rank of a slab run must take the same decision)
-  if (!pl->ring || !pl->zero_row || pl->d.dtype != GCMF_F64 || pl->tripolar || pl->g.fold || pl->multi_s < 8 || !multi_supported(pl, 8)) return 0;
+  // tripolar plans: the seam rows run k_fold_band beside every launch (GCMF_FOLD_BAND=0 keeps the forward single steps there)
+  if (!pl->ring || !pl->zero_row || pl->d.dtype != GCMF_F64 || (pl->tripolar && !pl->fold_band) || pl->multi_s < 8 || !multi_supported(pl, 8)) return 0;
   if (pl->n_land > 0 && !land_ok(pl, n_steps)) return 0;
   if (!(n_steps >= 10 || (n_steps >= 5 && n_steps <= 8))) return 0;
   int n = 0, left = n_steps;
@@ -591,17 +631,6 @@ int gcmf_clenshaw_cut(const gcmf_plan *pl, int n_steps, int *depths, int max_dep
   return clenshaw_cut(pl, n_steps, depths, max_depths);
 }
 
-static int launch_ringc(gcmf_plan *pl, const MultiArgs &m, hipStream_t s) {
-  switch (pl->kind) {
-    case K_REG: return launch_ringc_reg(pl, m, s);
-    case K_MASK: return launch_ringc_maskz(pl, m, s);
-    case K_FLUX: return launch_ringc_flux(pl, m, s);
-    default: break;
-  }
-  set_error("k_ringc: plan is not a scalar kind");
-  return GCMF_ERR_INVALID_ARG;
-}
-
 int gcmf_cheb_multi(gcmf_plan *pl, const void *u, const void *v, void *uo, void *vo, const void *fbar_in,
                     void *fbar_out, const double *pk, int S, double p0, double c, uint32_t mode, uint32_t flags,
                     int64_t nbatch, int64_t row_lo, int64_t row_hi, void *stream) {
@@ -610,7 +639,7 @@ int gcmf_cheb_multi(gcmf_plan *pl, const void *u, const void *v, void *uo, void 
     // b_n = p0 * f itself), fbar_in = the constant input f, pk[t] = coefficient of level t + 1, LAST: fbar_out = the result
     const bool first = mode & GCMF_STEP_FIRST, last = mode & GCMF_STEP_LAST;
     int probe[1];
-    if (pl->d.dtype != GCMF_F64 || pl->tripolar || pl->g.fold || pl->ncomp != 1 || S < 5 || S > 8 || !pl->ring || !pl->zero_row ||
+    if (pl->d.dtype != GCMF_F64 || pl->ncomp != 1 || S < 5 || S > 8 || !pl->ring || !pl->zero_row ||
         !(clenshaw_cut(pl, S, probe, 1) == 1)) {
       set_error("gcmf_cheb_multi: the backward evaluation is not available for this plan / depth %d", S);
       return GCMF_ERR_UNSUPPORTED;
@@ -626,7 +655,7 @@ int gcmf_cheb_multi(gcmf_plan *pl, const void *u, const void *v, void *uo, void 
     m.u0 = u; m.v0 = v; m.uo = uo; m.vo = vo; m.fb_in = fbar_in; m.fb_out = fbar_out;
     for (int t = 0; t < S; ++t) m.pk[t] = pk[t];
     m.p0 = p0; m.c = c; m.S = S; m.first = first; m.last = last; m.nbatch = nbatch; m.row_lo = (int)row_lo; m.row_hi = (int)row_hi;
-    return launch_ringc(pl, m, (hipStream_t)stream);
+    return advance_multi(pl, m, (hipStream_t)stream, nullptr, true);
   }
   if (!pl || !u || !fbar_out || !pk) {
     set_error("gcmf_cheb_multi: null argument");
@@ -840,10 +869,7 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
         m.first = (q == 0); m.last = (q == n_clen - 1); m.S = S; m.fb_is_f32 = 0;
         for (int t = 0; t < S; ++t) m.pk[t] = p[n_steps - (lvl + t)];
         m.p0 = p[n_steps]; m.c = c; m.nbatch = nbatch; m.row_lo = 0; m.row_hi = rows;
-        if ((rc = dom_begin(pl, s))) return rc;
-        if ((rc = launch_ringc(pl, m, s))) return rc;
-        if ((rc = dom_end(pl, s))) return rc;
-        ++launches;
+        if ((rc = advance_multi(pl, m, s, &launches, true))) return rc;   // (+ the tripole band on tripolar plans)
         u = fr[0]; v = fr[1];
         lvl += S;
       }
@@ -894,7 +920,7 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
             // band, which single steps advance from the raw field)
             if (!ring_supported(pl, m)) {
               if ((rc = launch_zero_land(pl, fr[0], fr[1], nbatch, s))) return rc;
-            } else if (pl->g.fold) {  // only the band rows: the single steps that advanced them carried land along
+            } else if (pl->g.fold && !(pl->fold_band && fold_band_supported(pl, m))) {  // only the band rows: the single steps that advanced them carried land along (k_fold_band drops it on load)
               if ((rc = launch_zero_land(pl, fr[0], fr[1], nbatch, s, rows - S, rows))) return rc;
             }
             land_zeroed = true;

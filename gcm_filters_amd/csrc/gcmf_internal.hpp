@@ -166,6 +166,7 @@ struct gcmf_plan {
   unsigned *ring_nfb = nullptr;    // device counter behind gcmf_ring_fallbacks (lives behind zero_row)
   const void *zero_row = nullptr;  // nx zeros: what rows beyond a closed boundary read as coefficients / mask bits (k_ring)
   int band_rpw = 0;       // rows per wave of the tripole band steps (0 = default)
+  int fold_band = 1;      // the tripole band in one launch (k_fold_band); env GCMF_FOLD_BAND=0: a chain of single steps
   int clenshaw = 1;       // backward (Clenshaw) evaluation, k_ringc: 0 off, 1 the flux kinds (default), 2 every scalar kind; env GCMF_CLENSHAW
   double *dev_p = nullptr;   // p[0..n_steps] of the last filter, for k_land_fix
   size_t dev_p_n = 0;
@@ -220,7 +221,11 @@ inline int launch_vec_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s)
   return pl->kind == K_CGRID ? launch_cgrid_multi(pl, a, s) : launch_bgrid_multi(pl, a, s);
 }
 // S fused steps on rows [row_lo,row_hi) incl. the tripole band when the range ends at the fold row (gcmf_api.hip)
-int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launches);
+// backward: m = the arguments of a k_ringc launch (the polynomial evaluated backwards)
+int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launches, bool backward = false);
+// the tripole seam rows of an S-step launch in one launch (gcmf_foldband.hip)
+bool fold_band_supported(const gcmf_plan *pl, const MultiArgs &a);
+int launch_fold_band(gcmf_plan *pl, const MultiArgs &a, bool backward, hipStream_t s);
 int launch_prepare(gcmf_plan *pl, const void *const *in, void *const *out, int64_t nbatch, int row_lo,
                    int row_hi, hipStream_t s);
 // the isolated cells' own polynomial, written over out (gcmf_landfix.hip); dp = p[0..n_steps] on the device

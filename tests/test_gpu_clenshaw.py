@@ -13,7 +13,7 @@ from oracle import gcmf_oracle as O
 pytestmark = pytest.mark.gpu
 
 SCALAR_F64 = ["REGULAR", "REGULAR_AREA_WEIGHTED", "REGULAR_WITH_LAND", "REGULAR_WITH_LAND_AREA_WEIGHTED", "IRREGULAR_WITH_LAND",
-              "MOM5U", "MOM5T"]
+              "MOM5U", "MOM5T", "TRIPOLAR_POP_WITH_LAND", "TRIPOLAR_REGULAR_WITH_LAND_AREA_WEIGHTED"]   # tripolar: + k_fold_band on the seam rows
 
 
 def _case(grid, shape, n_steps, nanland=False, nanwet=None, nb=1, fshape="TAPER"):
@@ -69,7 +69,7 @@ def test_backward_evaluation_matches_the_reference_recurrence(grid, n_steps, kwa
         assert nfb == 0
 
 
-@pytest.mark.parametrize("grid", ["IRREGULAR_WITH_LAND", "REGULAR_WITH_LAND", "REGULAR"])
+@pytest.mark.parametrize("grid", ["IRREGULAR_WITH_LAND", "REGULAR_WITH_LAND", "REGULAR", "TRIPOLAR_POP_WITH_LAND"])
 def test_same_bits_however_the_levels_are_cut(grid):
     """strip height and workgroup order change which wave computes what, not the arithmetic of a cell"""
     flt, plan, f, want = _case(grid, (260, 520), 29, nanland=True)
@@ -86,7 +86,7 @@ def test_same_bits_however_the_levels_are_cut(grid):
 
 def test_default_is_backward_for_flux_kinds_and_forward_for_the_rest():
     for grid, backward in (("IRREGULAR_WITH_LAND", True), ("MOM5U", True), ("REGULAR_WITH_LAND", False), ("REGULAR", False),
-                           ("TRIPOLAR_POP_WITH_LAND", False), ("TRIPOLAR_REGULAR_WITH_LAND_AREA_WEIGHTED", False)):
+                           ("TRIPOLAR_POP_WITH_LAND", True), ("TRIPOLAR_REGULAR_WITH_LAND_AREA_WEIGHTED", False)):
         flt, plan, f, want = _case(grid, (120, 256), 16)
         got = flt.apply(f)
         assert ("k_ringc<" in plan.last_kernel()) == backward, (grid, plan.last_kernel())

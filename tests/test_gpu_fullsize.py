@@ -85,13 +85,18 @@ def test_tripolar_pop_fullsize_fold_band(monkeypatch):
     try:
         plan.set_tuning(multi_s=1)
         ref = flt.apply(f)
-        plan.set_tuning(multi_s=8)    # tripolar grids run the forward recurrence: blocked launches + band of single steps
+        plan.set_tuning(multi_s=8, clenshaw=0)    # the forward recurrence: blocked launches + the seam rows by k_fold_band
         got = flt.apply(f)
         assert "k_ring<" in plan.last_kernel()
+        plan.set_tuning(multi_s=8, clenshaw=1)    # the default: backward evaluation, the seam rows by k_fold_band's backward form
+        back = flt.apply(f)
+        assert "k_ringc<" in plan.last_kernel()
     finally:
-        plan.set_tuning(multi_s=8)
-    assert np.array_equal(ref, got)
-    np.testing.assert_allclose((got * gv["tarea"] * gv["wet_mask"]).sum(), (f * gv["tarea"] * gv["wet_mask"]).sum(), rtol=1e-10)
+        plan.set_tuning(multi_s=8, clenshaw=1)
+    assert np.array_equal(ref, got)                # bit-identical with 56 single steps, seam included
+    assert np.abs(back - ref).max() <= 1e-13 * np.abs(ref).max()
+    for o in (got, back):
+        np.testing.assert_allclose((o * gv["tarea"] * gv["wet_mask"]).sum(), (f * gv["tarea"] * gv["wet_mask"]).sum(), rtol=1e-10)
 
 
 # ---------------------------------------------------------------------------------------------------
