@@ -151,9 +151,7 @@ static int dom_collect(gcmf_plan *pl) {
 // One temporally blocked advance of S steps on rows [row_lo, row_hi) of a scalar plan.
 //
 // Tripolar grids: the fold couples column i of the top row with column nx-1-i, i.e. with a DIFFERENT wave of the
-// streaming kernel, so the top S rows ("band") are advanced by S single-step launches instead.  Band step t
-// recomputes a ghost zone [rows-2S+t, rows-S) below the band that shrinks by one row per step (the same
-// trick the multi-GPU slabs use) and only rows >= rows-S update fbar / the output states.
+// strip-marching kernel, which therefore stops S rows below the seam; the top S rows ("band") are advanced by k_fold_band.
 static int launch_ringc(gcmf_plan *pl, const MultiArgs &m, hipStream_t s) {
   switch (pl->kind) {
     case K_REG: return launch_ringc_reg(pl, m, s);
@@ -185,104 +183,32 @@ int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launche
   }
   MultiArgs mm = m;
   mm.row_hi = blo;
-  if (pl->fold_band && fold_band_supported(pl, m)) {
-    // the band in ONE launch (k_fold_band, gcmf_foldband.hip) on the side stream beside the blocked launch: neither reads what the
-    // other writes (the band reads rows >= rows - 2S of the input planes, the two write disjoint rows of the output planes)
-    if (!pl->side) {
-      GCMF_HIP(hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking));
-      GCMF_HIP(hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
-      GCMF_HIP(hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
-    }
-    GCMF_HIP(hipEventRecord(pl->ev_fork, s));
-    GCMF_HIP(hipStreamWaitEvent(pl->side, pl->ev_fork, 0));
-    if ((rc = launch_fold_band(pl, m, backward, pl->side))) return rc;
-    if (launches) ++*launches;
-    GCMF_HIP(hipEventRecord(pl->ev_join, pl->side));
-    if (mm.row_hi > mm.row_lo) {
-      if ((rc = dom_begin(pl, s))) return rc;
-      if ((rc = blocked(mm))) return rc;
-      if ((rc = dom_end(pl, s))) return rc;
-      if (launches) ++*launches;
-    }
-    GCMF_HIP(hipStreamWaitEvent(s, pl->ev_join, 0));
-    return GCMF_OK;
-  }
-  if (backward) {
-    set_error("advance_multi: the backward evaluation on a tripolar plan needs k_fold_band");
+  if (!fold_band_supported(pl, m)) {
+    set_error("advance_multi: k_fold_band does not cover this plan / depth %d / batch %lld", S, (long long)m.nbatch);
     return GCMF_ERR_UNSUPPORTED;
   }
-  const size_t ts = dtype_size(pl->d.dtype);
-  const size_t plane = align_up((size_t)m.nbatch * rows * g.nx * ts, 256);
-  if (pl->band_bytes < 3 * plane) {
-    if (pl->band) GCMF_HIP(hipFree(pl->band));
-    pl->band = nullptr;
-    pl->band_bytes = 0;
-    GCMF_HIP(hipMalloc(&pl->band, 3 * plane));
-    pl->band_bytes = 3 * plane;
-  }
-  void *E[2] = {pl->band, (char *)pl->band + plane};
-  void *Pb = (char *)pl->band + 2 * plane;
-  const void *lvl0 = m.u0;
-  bool prep_band = false;
-  if (m.first && g.area_weighted) {
-    prep_band = true;
-    lvl0 = Pb;
-  }
-  // where level t (1..S) of the band lives.  Level S-1 goes to scratch as well (with its ghost row just below the band,
-  // which step S needs) and its band rows are copied into vo afterwards: no band step then reads anything the blocked
-  // launch writes, so the whole band chain runs beside it.
-  auto level_buf = [&](int t) -> void * {
-    if (t == S) return m.uo;
-    return E[t & 1];
-  };
-  // The band steps do not depend on the blocked launch, so they run on a side stream concurrently with it: they are
-  // tiny, latency-bound launches (~6 us each) that fit beside the one-wave-per-SIMD blocked kernel.  All writes of
-  // the two streams are row-disjoint.
+  // The seam rows in ONE launch (k_fold_band, gcmf_foldband.hip) on a side stream beside the blocked launch: neither reads what
+  // the other writes (the band reads rows >= rows - 2S of the input planes, the two write disjoint rows of the output planes).
   if (!pl->side) {
+    // both streams are on this device and nothing between fork and join is read by the host or a peer: no system-scope
+    // fence on these events (agent scope orders the two queues; measured +2 % on config 4: the fork / join packets are
+    // the only cost the seam has left, ~6 us per launch)
+    const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
     GCMF_HIP(hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking));
-    GCMF_HIP(hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
-    GCMF_HIP(hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
+    GCMF_HIP(hipEventCreateWithFlags(&pl->ev_fork, evf));
+    GCMF_HIP(hipEventCreateWithFlags(&pl->ev_join, evf));
   }
-  const int n_early = S;  // steps 1..n_early are independent of the blocked launch
   GCMF_HIP(hipEventRecord(pl->ev_fork, s));
   GCMF_HIP(hipStreamWaitEvent(pl->side, pl->ev_fork, 0));
-  if (prep_band) {  // T_0 = field * area for the band rows (the blocked kernel fuses this, single steps do not)
-    const void *pin[1] = {m.u0};
-    void *pout[1] = {Pb};
-    if ((rc = launch_prepare(pl, pin, pout, m.nbatch, rows - 2 * S, rows, n_early >= 1 ? pl->side : s))) return rc;
-    if (launches) ++*launches;
-  }
-  if ((rc = dom_begin(pl, s))) return rc;
-  if ((rc = launch_scalar_multi(pl, mm, s))) return rc;
-  if ((rc = dom_end(pl, s))) return rc;
+  if ((rc = launch_fold_band(pl, m, backward, pl->side))) return rc;
   if (launches) ++*launches;
-  for (int t = 1; t <= S; ++t) {
-    hipStream_t ts_ = pl->side;
-    StepArgs a{};
-    a.mode = ((m.first && t == 1) ? GCMF_STEP_FIRST : 0u) | ((m.last && t == S) ? GCMF_STEP_LAST : 0u);
-    a.coef0 = (m.first && t == 1) ? m.p0 : m.pk[t - 1];
-    a.coef1 = m.pk[0];
-    a.c = m.c;
-    a.fb_is_f32 = m.fb_is_f32;
-    a.nbatch = m.nbatch;
-    a.t1[0] = (t == 1) ? lvl0 : level_buf(t - 1);
-    a.t2[0] = (t == 1) ? m.v0 : (t == 2 ? lvl0 : level_buf(t - 2));
-    a.t0[0] = level_buf(t);
-    a.fb_in[0] = (m.first && t == 1) ? nullptr : ((t == 1) ? m.fb_in : (m.last ? m.fb_in : m.fb_out));
-    a.fb_out[0] = (m.last && t < S) ? const_cast<void *>(m.fb_in) : m.fb_out;
-    a.row_lo = (t == S) ? blo : rows - 2 * S + t;
-    a.row_hi = rows;
-    a.fb_lo = blo;
-    a.rpw = pl->band_rpw;  // rows per wave of the band steps (env GCMF_BAND_RPW; 0 = default)
-    if ((rc = launch_scalar_step(pl, a, ts_))) return rc;
-    if (launches) ++*launches;
-    if (t == S - 1 && !m.last) {  // the band rows of T_{k+S-2} into the caller's plane (rows < blo are the blocked launch's)
-      const size_t rowb = (size_t)g.nx * ts, pitch = (size_t)rows * rowb;
-      GCMF_HIP(hipMemcpy2DAsync((char *)m.vo + (size_t)blo * rowb, pitch, (const char *)level_buf(t) + (size_t)blo * rowb, pitch,
-                                (size_t)S * rowb, (size_t)m.nbatch, hipMemcpyDeviceToDevice, ts_));
-    }
-  }
   GCMF_HIP(hipEventRecord(pl->ev_join, pl->side));
+  if (mm.row_hi > mm.row_lo) {
+    if ((rc = dom_begin(pl, s))) return rc;
+    if ((rc = blocked(mm))) return rc;
+    if ((rc = dom_end(pl, s))) return rc;
+    if (launches) ++*launches;
+  }
   GCMF_HIP(hipStreamWaitEvent(s, pl->ev_join, 0));
   return GCMF_OK;
 }
@@ -320,7 +246,6 @@ void gcmf_plan_destroy(gcmf_plan *pl) {
   for (void *p : pl->owned) (void)hipFree(p);
   for (hipEvent_t e : pl->dom_ev) (void)hipEventDestroy(e);
   if (pl->work) (void)hipFree(pl->work);
-  if (pl->band) (void)hipFree(pl->band);
   if (pl->side) { (void)hipStreamSynchronize(pl->side); (void)hipStreamDestroy(pl->side); }
   if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
   if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
@@ -435,9 +360,6 @@ int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int 
   if (const char *e = getenv("GCMF_ZERO_LAND")) pl->zero_land = atoi(e);
   if (const char *e = getenv("GCMF_RING")) pl->ring = atoi(e);
   if (const char *e = getenv("GCMF_CLENSHAW")) pl->clenshaw = atoi(e);
-  pl->band_rpw = (pl->d.dtype == GCMF_F32) ? 1 : 0;  // f32: one row per wave shortens the chain (+8 %); f64: no difference
-  if (const char *e = getenv("GCMF_BAND_RPW")) pl->band_rpw = atoi(e);
-  if (const char *e = getenv("GCMF_FOLD_BAND")) pl->fold_band = atoi(e);
   PLAN_HIP(hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking));
   PLAN_HIP(hipEventCreate(&pl->ev0));
   PLAN_HIP(hipEventCreate(&pl->ev1));
@@ -608,8 +530,8 @@ static bool land_ok(const gcmf_plan *pl, int n_steps);
 static int clenshaw_cut(const gcmf_plan *pl, int n_steps, int *depths, int max_depths) {
   if (!pl || pl->ncomp != 1 || !(pl->clenshaw >= 2 || (pl->clenshaw == 1 && pl->kind == K_FLUX))) return 0;
   // (tripolar: of the GRID, not of this slab -- every rank of a slab run must take the same decision)
-  // tripolar plans: the seam rows run k_fold_band beside every launch (GCMF_FOLD_BAND=0 keeps the forward single steps there)
-  if (!pl->ring || !pl->zero_row || pl->d.dtype != GCMF_F64 || (pl->tripolar && !pl->fold_band) || pl->multi_s < 8 || !multi_supported(pl, 8)) return 0;
+  // (tripolar plans: the seam rows run k_fold_band's backward form beside every launch)
+  if (!pl->ring || !pl->zero_row || pl->d.dtype != GCMF_F64 || pl->multi_s < 8 || !multi_supported(pl, 8)) return 0;
   if (pl->n_land > 0 && !land_ok(pl, n_steps)) return 0;
   if (!(n_steps >= 10 || (n_steps >= 5 && n_steps <= 8))) return 0;
   int n = 0, left = n_steps;
@@ -916,13 +838,10 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
           --launches;  // counted once more below
           u = fr[0]; v = fr[1];
           if (k == 1 && zero_land && !is_last) {  // keep the isolated cells out of the state from here on
-            // (a first launch by k_ring already took them as zero while it loaded the field -- except in the rows of a tripole
-            // band, which single steps advance from the raw field)
+            // (a first launch by k_ring already took them as zero while it loaded the field)
             if (!ring_supported(pl, m)) {
               if ((rc = launch_zero_land(pl, fr[0], fr[1], nbatch, s))) return rc;
-            } else if (pl->g.fold && !(pl->fold_band && fold_band_supported(pl, m))) {  // only the band rows: the single steps that advanced them carried land along (k_fold_band drops it on load)
-              if ((rc = launch_zero_land(pl, fr[0], fr[1], nbatch, s, rows - S, rows))) return rc;
-            }
+            }   // (k_ring's first launch and k_fold_band took the land as zero while they loaded the field)
             land_zeroed = true;
           }
         } else {

@@ -117,9 +117,7 @@ struct gcmf_plan {
   // work buffers of gcmf_apply (grow-only)
   void *work = nullptr;
   size_t work_bytes = 0;
-  void *band = nullptr;  // scratch of the tripole-band single steps that accompany a temporally blocked launch
-  size_t band_bytes = 0;
-  hipStream_t side = nullptr;           // the band's early steps run here, concurrently with the blocked launch
+  hipStream_t side = nullptr;           // k_fold_band (the tripole seam rows) runs here, concurrently with the blocked launch
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t stream = nullptr;
   // pipelined host path (batched host arrays): staging slots, upload / download streams, per-slot events
@@ -165,8 +163,6 @@ struct gcmf_plan {
   int ring = 1;           // env GCMF_RING=0: deep launches stay with k_flux_multi2 / k_scalar_multi
   unsigned *ring_nfb = nullptr;    // device counter behind gcmf_ring_fallbacks (lives behind zero_row)
   const void *zero_row = nullptr;  // nx zeros: what rows beyond a closed boundary read as coefficients / mask bits (k_ring)
-  int band_rpw = 0;       // rows per wave of the tripole band steps (0 = default)
-  int fold_band = 1;      // the tripole band in one launch (k_fold_band); env GCMF_FOLD_BAND=0: a chain of single steps
   int clenshaw = 1;       // backward (Clenshaw) evaluation, k_ringc: 0 off, 1 the flux kinds (default), 2 every scalar kind; env GCMF_CLENSHAW
   double *dev_p = nullptr;   // p[0..n_steps] of the last filter, for k_land_fix
   size_t dev_p_n = 0;

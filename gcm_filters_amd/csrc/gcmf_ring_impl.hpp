@@ -425,10 +425,8 @@ static int launch_ring_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   P.nwx = (g.nx + WI - 1) / WI;
   int H = pl->strip_rows;
   if (H <= 0) {  // one resident round of waves at one wave per SIMD (all strips march in lock-step)
-    // tripolar plans: the single steps of the fold band run beside this launch on a side stream (advance_multi).  Their
-    // waves (94 registers) do not fit next to a 446-register wave on a SIMD, so 16 of the 256 CUs are left to them
-    const long long slots = (g.fold && !pl->fold_band) ? 960 : 1024;   // (k_fold_band's waves fit beside these on a SIMD)
-    long long want = slots / ((long long)P.nwx * a.nbatch);
+    // (tripolar plans: k_fold_band runs beside this launch on a side stream; its 48-register waves fit on the SIMDs next to these)
+    long long want = 1024 / ((long long)P.nwx * a.nbatch);
     if (want < 1) want = 1;
     H = (int)((nrows + want - 1) / want);
     if (H < 2 * S) H = 2 * S;

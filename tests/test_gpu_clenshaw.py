@@ -138,3 +138,37 @@ def test_cgrid_backward_evaluation(dt, nlev, n_steps):
         l = nlev - 1
         a1, b1 = flt.apply_to_vector(u[l:l + 1], v[l:l + 1])
         assert np.array_equal(a1[0], gu[l], equal_nan=True) and np.array_equal(b1[0], gw[l], equal_nan=True)
+
+
+@pytest.mark.parametrize("grid", ["TRIPOLAR_POP_WITH_LAND", "TRIPOLAR_REGULAR_WITH_LAND_AREA_WEIGHTED"])
+@pytest.mark.parametrize("backward", [False, True])
+@pytest.mark.parametrize("n_steps,nb", [(16, 1), (21, 3)])
+def test_tripole_seam_rows_with_nan_in_wet_cells(grid, backward, n_steps, nb):
+    """k_fold_band (the top S rows of every blocked launch on a tripolar plan, reference kernels.py:33-40): NaN in wet cells ON the
+    seam row, on its mirror partner's side and in the ghost rows below the band -- the stencil sees nan_to_num, the cell keeps its
+    NaN (filter.py:166-175) -- in the forward (bit-identical with single steps) and the backward form."""
+    shape = (70, 384)
+    flt, plan, f, want = _case(grid, shape, n_steps, nanland=True, nb=nb)
+    f = f.copy()
+    _, gv = T.scalar_case(grid, shape)
+    wet = gv["wet_mask"] != 0
+    spots = [(shape[0] - 1, 37), (shape[0] - 1, shape[1] - 1 - 36), (shape[0] - 2, 200), (shape[0] - 9, 120), (shape[0] - 14, 300)]
+    spots = [(j, i) for j, i in spots if wet[j, i]]
+    assert len(spots) >= 3
+    for j, i in spots:
+        f[..., j, i] = np.nan
+    fs = flt.filter_spec
+    with np.errstate(all="ignore"):
+        want = O.filter_func(O.FilterSpec(fs.n_steps, fs.s_max, np.asarray(fs.p), fs.dx_min_sq), grid, f, gv)
+    try:
+        plan.set_tuning(multi_s=1)
+        single = flt.apply(f)
+        plan.set_tuning(multi_s=8, clenshaw=2 if backward else 0)
+        got = flt.apply(f)
+        assert ("k_ringc<" in plan.last_kernel()) == backward
+    finally:
+        plan.set_tuning(multi_s=8, clenshaw=1)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(got[..., spots[0][0], spots[0][1]]).all()
+    assert np.nanmax(np.abs(got - want)) <= 1e-12 * np.nanmax(np.abs(want))
+    if not backward:
+        assert np.array_equal(got, single, equal_nan=True)
