@@ -771,7 +771,8 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
   } else {
     const void *x0[2] = {din[0], din[1]};
     int depths[1024];
-    const int n_clen = (use_multi && !fb32) ? clenshaw_cut(pl, n_steps, depths, 1024) : 0;
+    const bool fwd_only = flags & GCMF_FORWARD_RECURRENCE;   // the caller wants the reference's forward recurrence / accumulation
+    const int n_clen = (use_multi && !fb32 && !fwd_only) ? clenshaw_cut(pl, n_steps, depths, 1024) : 0;
     if (n_clen > 0) {
       // Backward (Clenshaw) evaluation, gcmf_ringc_impl.hpp: state (b_{k+1}, b_{k+2}) in a pool of four planes, the constant
       // input read by every launch, no fbar planes.  The first launch forms b_n = p[n] f as it loads f; level l = 1..n uses
@@ -866,7 +867,7 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
         if ((rc = ensure_dev_p(pl, p, n_steps, s))) return rc;
         if ((rc = launch_land_fix(pl, din[0], dout[0], pl->dev_p, n_steps, c, fb32 ? 1 : 0, nbatch, s))) return rc;
       }
-    } else if (use_vmulti && pl->kind == K_CGRID && pl->clenshaw >= 1 && n_steps >= 2 && vec_multi_supported(pl, nbatch, 2)) {
+    } else if (use_vmulti && pl->kind == K_CGRID && pl->clenshaw >= 1 && !fwd_only && n_steps >= 2 && vec_multi_supported(pl, nbatch, 2)) {
       // C-grid, batched levels: the polynomial evaluated backwards (k_cgrid_stream2c): state (b_{k+1}, b_{k+2}) in a pool of four
       // plane pairs, the constant input (u, v) read by every launch, no fbar planes.  Level l = 1..n uses p[n - l]; the first
       // launch forms b_n = p[n] f as it loads f, the last one writes the result.

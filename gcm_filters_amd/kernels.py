@@ -401,7 +401,7 @@ class _DeviceLaplacian:
                     sub.append(a[tuple(0 if n == 1 else i for i, n in zip(gi, lead))])
             self._levels[g] = type(self)(*sub, _skip_kappa_one=True)
 
-    def _run_levels(self, fields, spec, out_f32):
+    def _run_levels(self, fields, spec, out_f32, forward=False):
         fields = [_unwrap(f) for f in fields]
         shape = tuple(fields[0].shape)
         if len(shape) < 2:
@@ -416,7 +416,7 @@ class _DeviceLaplacian:
             for f in fields:
                 fb = f.expand(*out_lead, *core) if _is_torch(f) else np.broadcast_to(f, out_lead + core)
                 sub.append(fb[idx])
-            res = lap._run(sub, spec=spec, out_f32=out_f32)
+            res = lap._run(sub, spec=spec, out_f32=out_f32, forward=forward)
             if outs is None:
                 if _is_torch(res[0]):
                     import torch
@@ -466,10 +466,12 @@ class _DeviceLaplacian:
             return self._own_plan
         return PLAN_CACHE.get(key, factory, () if on_gpu else self._planes)
 
-    def _run(self, fields: Sequence, spec=None, out_f32: bool = False):
-        """Shared driver of __call__ (spec None: one Laplacian) and of filter_func (spec: whole polynomial)."""
+    def _run(self, fields: Sequence, spec=None, out_f32: bool = False, forward: bool = False):
+        """Shared driver of __call__ (spec None: one Laplacian) and of filter_func (spec: whole polynomial).
+        forward: evaluate the polynomial by the reference's forward recurrence with its accumulation scheme (f64 running sum
+        also for f32 state) even where the library would evaluate it backwards (Filter(evaluation="reference"))."""
         if self._levels is not None:
-            return self._run_levels(fields, spec, out_f32)
+            return self._run_levels(fields, spec, out_f32, forward)
         fields = [_unwrap(f) for f in fields]
         shape = tuple(fields[0].shape)
         if len(shape) < 2:
@@ -497,7 +499,7 @@ class _DeviceLaplacian:
                 with torch.cuda.device(dev):
                     stream = torch.cuda.current_stream().cuda_stream
                     self._call(plan, spec, [t.data_ptr() for t in ins], [t.data_ptr() for t in outs], nbatch,
-                               True, out_f32, stream)
+                               True, out_f32, stream, forward)
                     # inputs converted above may be temporaries: keep them alive until the stream is done
                     for t in ins:
                         t.record_stream(torch.cuda.current_stream())
@@ -506,7 +508,7 @@ class _DeviceLaplacian:
         host = [f.detach().cpu().numpy() if _is_torch(f) else np.asarray(f) for f in fields]
         ins = [np.ascontiguousarray(f, dtype=_lib.np_dtype(dtype)) for f in host]
         outs = [_host_output(shape, out_np) for _ in fields]
-        if nbatch == 1 and spec is not None and self._NCOMP == 1 and ny * nx >= host_blocks.MIN_CELLS:
+        if nbatch == 1 and spec is not None and self._NCOMP == 1 and ny * nx >= host_blocks.MIN_CELLS and not forward:
             # one large host field: upload / recurrence / download overlapped by row blocks (host_blocks.py)
             pipe = self._row_blocks(plan, dtype, ny, nx, spec)
             if pipe is not None:
@@ -519,7 +521,7 @@ class _DeviceLaplacian:
                 return outs
         if nbatch:
             self._call(plan, spec, [a.ctypes.data for a in ins], [a.ctypes.data for a in outs], nbatch, False,
-                       out_f32, 0)
+                       out_f32, 0, forward)
         return outs
 
     def _row_blocks(self, plan, dtype, ny, nx, spec):
@@ -552,7 +554,7 @@ class _DeviceLaplacian:
             st["pipes"][n] = pipe
             return pipe
 
-    def _call(self, plan, spec, ins, outs, nbatch, device_ptrs, out_f32, stream):
+    def _call(self, plan, spec, ins, outs, nbatch, device_ptrs, out_f32, stream, forward=False):
         try:
             if spec is None:
                 plan.laplacian(ins, outs, nbatch, device_ptrs=device_ptrs, stream=stream)
@@ -560,7 +562,7 @@ class _DeviceLaplacian:
                 # shift of the spectrum to [-1, 1]: reference filter.py:170-173
                 c = 2 / spec.s_max if self.is_dimensional else 2 / (spec.s_max * spec.dx_min_sq)
                 plan.apply(np.asarray(spec.p, dtype=np.float64), c, ins, outs, nbatch, device_ptrs=device_ptrs,
-                           out_f32=out_f32, stream=stream)
+                           out_f32=out_f32, stream=stream, forward=forward)
         except _lib.GcmfError as e:
             raise _translate(e) from None
 

@@ -70,6 +70,10 @@ typedef enum gcmf_dtype { GCMF_F32 = 0, GCMF_F64 = 1 } gcmf_dtype;
 #define GCMF_DEVICE_PTRS 0x1u /* in/out are device pointers on the plan's device (else host)  */
 #define GCMF_OUT_F32 0x2u     /* f32 plan only: write f32 output (default: f64, as NumPy >= 2 */
                               /* promotes p[k]*T)                       */
+#define GCMF_FORWARD_RECURRENCE 0x4u /* gcmf_apply: sum the polynomial by the reference's forward     */
+                              /* recurrence with its accumulation scheme (filter.py:192-206: f64 running sum   */
+                              /* also for f32 state) even where the library would evaluate it backwards        */
+                              /* (Clenshaw: f64 flux-form plans, C-grid plans)                                  */
 
 /* Chebyshev step modes for gcmf_cheb_step */
 #define GCMF_STEP_FIRST 0x1u /* T1 = A(T0);            fbar  = p0*T0 + p1*T1                  */

@@ -172,3 +172,66 @@ def test_tripole_seam_rows_with_nan_in_wet_cells(grid, backward, n_steps, nb):
     assert np.nanmax(np.abs(got - want)) <= 1e-12 * np.nanmax(np.abs(want))
     if not backward:
         assert np.array_equal(got, single, equal_nan=True)
+
+
+def _cgrid_f32_case(shape, nlev, n_steps, scale):
+    import warnings
+    gv = {k: v.astype("f4") for k, v in T.vector_grid_vars("VECTOR_C_GRID", shape).items()}
+    u = np.stack([T.random_field(shape, 42 + 2 * l).astype("f4") for l in range(nlev)])
+    v = np.stack([T.random_field(shape, 43 + 2 * l).astype("f4") for l in range(nlev)])
+    dx = T.grid_dx_min("VECTOR_C_GRID", gv)
+    flts = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for ev in ("auto", "reference"):
+            flts[ev] = Filter(filter_scale=scale * dx, dx_min=dx, n_steps=n_steps, grid_type=GridType.VECTOR_C_GRID, grid_vars=gv,
+                              evaluation=ev)
+    fs = flts["auto"].filter_spec
+    spec = O.FilterSpec(fs.n_steps, fs.s_max, np.asarray(fs.p), fs.dx_min_sq)
+    with np.errstate(all="ignore"):
+        ref = O.filter_func_vec(spec, "VECTOR_C_GRID", u, v, gv)       # the reference's own f32 path: f32 T_k, f64 fbar
+        truth = O.filter_func_vec(spec, "VECTOR_C_GRID", u.astype("f8"), v.astype("f8"), {k: x.astype("f8") for k, x in gv.items()})
+    plan = ALL_KERNELS[GridType.VECTOR_C_GRID](**gv)._plan(_lib.F32, shape)
+    return flts, plan, u, v, ref, truth
+
+
+def _rel2(a, b):
+    return max(float(np.abs(x - y).max() / np.abs(y).max()) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("n_steps,scale", [(44, 40), (63, 57), (98, 90), (125, 114)])
+def test_cgrid_f32_precision_policy(n_steps, scale):
+    """float32 C-grid fields.  The reference carries T_k in f32 and the running sum in f64; the default here
+    (evaluation="auto": Clenshaw, everything in f32) must stay in the accuracy class of the reference's OWN f32 path measured against
+    f64 arithmetic -- within 2 x its error, growing linearly with n_steps like it (DESIGN.md 3.4 has the table) -- and
+    Filter(evaluation="reference") must run the reference's scheme (forward kernel, f64 running sum) without any env var."""
+    flts, plan, u, v, ref, truth = _cgrid_f32_case((96, 160), 8, n_steps, scale)
+    e_ref = _rel2(ref, truth)                       # what f32 state costs the reference itself: 3e-6 (n 44) ... 1.3e-5 (n 125)
+    got = flts["auto"].apply_to_vector(u, v)
+    assert "k_cgrid_stream2c<float" in plan.last_kernel()
+    fwd = flts["reference"].apply_to_vector(u, v)
+    assert "k_cgrid_stream2<float, double" in plan.last_kernel()
+    assert got[0].dtype == np.float64 and fwd[0].dtype == np.float64
+    e_auto, e_fwd = _rel2(got, truth), _rel2(fwd, truth)
+    print(f"n_steps {n_steps}: error against f64 arithmetic -- reference's f32 path {e_ref:.2e}, evaluation='reference' {e_fwd:.2e}, "
+          f"'auto' (backward, f32) {e_auto:.2e}; 'auto' against the reference's f32 result {_rel2(got, ref):.2e}")
+    assert e_fwd <= 1.5 * e_ref + 1e-6              # the same scheme as the reference: the same error
+    assert e_auto <= 2.0 * e_ref + 1e-6             # the default: same class (measured 1.4-1.8 x)
+    assert e_auto <= 2.5e-5 and _rel2(got, ref) <= 3e-5   # absolute ceilings at the longest polynomial of the tutorials (SURVEY 8d gate: 1e-4)
+
+
+def test_evaluation_option_reaches_the_plan_for_scalar_grids_too():
+    import warnings
+    f, gv = T.scalar_case("IRREGULAR_WITH_LAND", (120, 256))
+    dx = T.grid_dx_min("IRREGULAR_WITH_LAND", gv)
+    plan = ALL_KERNELS[GridType.IRREGULAR_WITH_LAND](**gv)._plan(_lib.F64, (120, 256))
+    outs = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for ev, kern in (("auto", "k_ringc<"), ("reference", "k_ring<")):
+            flt = Filter(filter_scale=4.0 * dx, dx_min=dx, n_steps=16, grid_type=GridType.IRREGULAR_WITH_LAND, grid_vars=gv, evaluation=ev)
+            outs[ev] = flt.apply(f)
+            assert kern in plan.last_kernel(), (ev, plan.last_kernel())
+        with pytest.raises(ValueError, match="evaluation must be one of"):
+            Filter(filter_scale=4.0, dx_min=1.0, evaluation="fast")
+    assert np.abs(outs["auto"] - outs["reference"]).max() <= 1e-13 * np.abs(outs["reference"]).max()

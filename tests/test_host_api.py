@@ -198,12 +198,12 @@ def xr_model(monkeypatch):
     import fake_xarray
     monkeypatch.setitem(sys.modules, "xarray", fake_xarray)
 
-    def oracle_filter_func(spec, Laplacian):
+    def oracle_filter_func(spec, Laplacian, evaluation="auto"):
         o = O.FilterSpec(spec.n_steps, spec.s_max, np.asarray(spec.p), spec.dx_min_sq)
         names = Laplacian.required_grid_args()
         return lambda field, *args: O.filter_func(o, Laplacian.GRID_TYPE.name, field, dict(zip(names, args)))
 
-    def oracle_filter_func_vec(spec, Laplacian):
+    def oracle_filter_func_vec(spec, Laplacian, evaluation="auto"):
         o = O.FilterSpec(spec.n_steps, spec.s_max, np.asarray(spec.p), spec.dx_min_sq)
         names = Laplacian.required_grid_args()
         return lambda u, v, *args: O.filter_func_vec(o, Laplacian.GRID_TYPE.name, u, v, dict(zip(names, args)))
