@@ -343,26 +343,33 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
   load_centre(ic<2>{}, ic<2>{});
   load_u(ic<2>{});
   static_assert(D == 3, "prologue");
-  const int niter = (r_last - r_begin + 1 + R - 1) / R * R;  // padded to whole periods: the extra rows store nothing
+  // The last period is left after the strip's last row (a wave-uniform scalar branch per row): a short strip -- the slab of one
+  // rank of an 8-GPU run marches 11 + 2 S rows -- does not pay for rows up to the next multiple of the period.
   bool dirty = false;
-  for (int i0 = 0; i0 < niter; i0 += R) {
-    const int r0 = r_begin + i0;
-    phase(ic<0>{}, r0);
-    phase(ic<1>{}, r0 + 1);
-    phase(ic<2>{}, r0 + 2);
-    phase(ic<3>{}, r0 + 3);
-    phase(ic<4>{}, r0 + 4);
-    phase(ic<5>{}, r0 + 5);
-    phase(ic<6>{}, r0 + 6);
-    phase(ic<7>{}, r0 + 7);
-    phase(ic<8>{}, r0 + 8);
-    phase(ic<9>{}, r0 + 9);
-    phase(ic<10>{}, r0 + 10);
-    phase(ic<11>{}, r0 + 11);
+  for (int r0 = r_begin;; r0 += R) {
+    bool done = true;
+    do {
+      phase(ic<0>{}, r0);
+      phase(ic<1>{}, r0 + 1);
+      phase(ic<2>{}, r0 + 2);
+      phase(ic<3>{}, r0 + 3);
+      if (r0 + 3 >= r_last) break;     // (exits every four rows: one per row costs the kernel 100 registers more)
+      phase(ic<4>{}, r0 + 4);
+      phase(ic<5>{}, r0 + 5);
+      phase(ic<6>{}, r0 + 6);
+      phase(ic<7>{}, r0 + 7);
+      if (r0 + 7 >= r_last) break;
+      phase(ic<8>{}, r0 + 8);
+      phase(ic<9>{}, r0 + 9);
+      phase(ic<10>{}, r0 + 10);
+      phase(ic<11>{}, r0 + 11);
+      done = (r0 + 11 >= r_last);
+    } while (false);
     if (SAN && __any(bad)) {  // wave-uniform: a NaN / inf somewhere in this strip -> the general march redoes the strip
       dirty = true;
       break;
     }
+    if (done) break;
   }
   if constexpr (SAN) {
     if (dirty) {
@@ -429,9 +436,9 @@ static int launch_ring_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
     long long want = 1024 / ((long long)P.nwx * a.nbatch);
     if (want < 1) want = 1;
     H = (int)((nrows + want - 1) / want);
-    if (H < 2 * S) H = 2 * S;
-    // the march is padded to whole ring periods: make the padding carry real rows (never more strips than before)
-    H += (R - (H + 2 * S) % R) % R;
+    // (no rounding to the ring period: the march leaves its last period early, so the slab of one rank of an 8-GPU run marches
+    // 11 + 2 S rows, not 36.  At least S rows per strip: below that a strip marches more than three rows per row it owns)
+    if (H < S) H = S;
   }
   if (H > nrows) H = nrows;
   P.H = H;

@@ -297,22 +297,27 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
   load_centre(ic<2>{}, ic<2>{});
   load_u(ic<2>{});
   static_assert(D == 3, "prologue");
-  const int niter = (r_last - r_begin + 1 + R - 1) / R * R;
-  for (int i0 = 0; i0 < niter; i0 += R) {
-    const int r0 = r_begin + i0;
-    phase(ic<0>{}, r0);
-    phase(ic<1>{}, r0 + 1);
-    phase(ic<2>{}, r0 + 2);
-    phase(ic<3>{}, r0 + 3);
-    phase(ic<4>{}, r0 + 4);
-    phase(ic<5>{}, r0 + 5);
-    phase(ic<6>{}, r0 + 6);
-    phase(ic<7>{}, r0 + 7);
-    phase(ic<8>{}, r0 + 8);
-    phase(ic<9>{}, r0 + 9);
-    phase(ic<10>{}, r0 + 10);
-    phase(ic<11>{}, r0 + 11);
+  for (int r0 = r_begin;; r0 += R) {   // (the last period is left after the strip's last row, see k_ring)
+    bool done = true;
+    do {
+      phase(ic<0>{}, r0);
+      phase(ic<1>{}, r0 + 1);
+      phase(ic<2>{}, r0 + 2);
+      phase(ic<3>{}, r0 + 3);
+      if (r0 + 3 >= r_last) break;     // (exits every four rows: one per row costs the kernel 100 registers more)
+      phase(ic<4>{}, r0 + 4);
+      phase(ic<5>{}, r0 + 5);
+      phase(ic<6>{}, r0 + 6);
+      phase(ic<7>{}, r0 + 7);
+      if (r0 + 7 >= r_last) break;
+      phase(ic<8>{}, r0 + 8);
+      phase(ic<9>{}, r0 + 9);
+      phase(ic<10>{}, r0 + 10);
+      phase(ic<11>{}, r0 + 11);
+      done = (r0 + 11 >= r_last);
+    } while (false);
     if (WATCH && __any(bad)) return true;
+    if (done) break;
   }
   return false;
 }
@@ -366,8 +371,7 @@ static int launch_ringc_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
     long long want = 1024 / ((long long)P.nwx * a.nbatch);
     if (want < 1) want = 1;
     H = (int)((nrows + want - 1) / want);
-    if (H < 2 * S) H = 2 * S;
-    H += (R - (H + 2 * S) % R) % R;
+    if (H < S) H = S;   // (no rounding to the ring period: see k_ring)
   }
   if (H > nrows) H = nrows;
   P.H = H;

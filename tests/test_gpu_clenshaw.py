@@ -64,7 +64,7 @@ def test_backward_evaluation_matches_the_reference_recurrence(grid, n_steps, kwa
     assert np.array_equal(np.isnan(got), np.isnan(want))
     assert np.nanmax(np.abs(got - want)) <= 1e-12 * np.nanmax(np.abs(want))
     if "nanwet" in kwargs and grid not in ("REGULAR", "REGULAR_AREA_WEIGHTED"):
-        assert 0 < nfb < 60      # the strips around the cells were redone inside the kernel (nan_to_num on the stencil operands)
+        assert 0 < nfb < 120     # the strips around the cells were redone inside the kernel (nan_to_num on the stencil operands): a few of the ~76 strips x 3 launches
     elif not (grid.startswith("MOM5") and kwargs.get("nanland")):   # MOM5: land cells with an open face keep their NaN in the state
         assert nfb == 0
 

@@ -27,7 +27,7 @@ def timed(sf, local, reps=10):
     return (time.perf_counter() - t0) / reps
 
 base = None
-for world in (1, 2, 4, 8):
+for world in ([int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else (1, 2, 4, 8)):
     rank = world // 2 if not grid.startswith("TRIPOLAR") else world - 1   # tripolar: the rank that also advances the fold band
     sf = SlabFilter(grid, gv, fk, ny, nx, rank=rank, world=world, device=0, exchange="torch")
     n_ex = [0]
