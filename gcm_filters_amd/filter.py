@@ -14,6 +14,7 @@ from typing import Iterable, NamedTuple
 
 import numpy as np
 
+from .kernels import kernels_cache_enabled
 from .kernels import (
     ALL_KERNELS,
     AreaWeightedMixin,
@@ -171,10 +172,11 @@ def _create_filter_func(filter_spec: FilterSpec, Laplacian, evaluation: str = "a
     axes are independent batches), then the grid variables in ``Laplacian.required_grid_args()`` order.
     ``evaluation``: see ``Filter``."""
     forward = _forward_only(evaluation)
+    memo = _LaplacianMemo(Laplacian)
 
     def filter_func(field, *args):
         assert len(args) == len(Laplacian.required_grid_args())
-        laplacian = Laplacian(*args)  # device plan: cached while the grid arrays are unchanged
+        laplacian = memo.get(args)  # device plan: cached while the grid arrays are unchanged
         return laplacian._run([field], spec=filter_spec, forward=forward)[0]
 
     return filter_func
@@ -183,14 +185,46 @@ def _create_filter_func(filter_spec: FilterSpec, Laplacian, evaluation: str = "a
 def _create_filter_func_vec(filter_spec: FilterSpec, Laplacian, evaluation: str = "auto"):
     """Returns ``filter_func_vec(u, v, *grid_args) -> (u_filtered, v_filtered)``."""
     forward = _forward_only(evaluation)
+    memo = _LaplacianMemo(Laplacian)
 
     def filter_func_vec(ufield, vfield, *args):
         assert len(args) == len(Laplacian.required_grid_args())
-        laplacian = Laplacian(*args)
+        laplacian = memo.get(args)
         u, v = laplacian._run([ufield, vfield], spec=filter_spec, forward=forward)
         return (u, v)
 
     return filter_func_vec
+
+
+class _LaplacianMemo:
+    """The Laplacian object of the last call, reused while the caller passes the SAME grid arrays, unchanged: numpy planes are
+    write-protected while their plan is cached (kernels.py: an edit raises), so "same object and still read-only" means
+    unchanged; torch tensors carry a version counter.  Anything else -- other objects, a plane that is writable again (its
+    plan left the cache), xarray wrappers -- takes the full path: a fresh Laplacian, fingerprints and validation like the
+    reference's per-call construction (gcm_filters/filter.py:183).  Saves ~8 us per grid plane and call: what a small grid
+    (BASELINE config 1: two 8-us launches) spends most of its time on."""
+
+    def __init__(self, Laplacian):
+        self.Laplacian = Laplacian
+        self._entry = (None, None)    # (key, Laplacian object): ONE attribute, so that dask worker threads see a consistent pair
+
+    @staticmethod
+    def _token(a):
+        if isinstance(a, np.ndarray):
+            return None if a.flags.writeable else (id(a), 0)
+        if _is_torch(a):
+            return (id(a), a._version)
+        return None
+
+    def get(self, args):
+        key = tuple(self._token(a) for a in args)
+        have_key, have = self._entry
+        if have is not None and key == have_key and None not in key and kernels_cache_enabled():
+            return have
+        lap = self.Laplacian(*args)
+        key = tuple(self._token(a) for a in args)    # (construction write-protects host planes)
+        self._entry = (key, lap) if None not in key else (None, None)
+        return lap
 
 
 EVALUATIONS = ("auto", "reference")
@@ -360,6 +394,16 @@ class Filter:
             dask="parallelized",
         )
 
+    def _operator(self, make):
+        """``make(filter_spec, Laplacian, evaluation)`` (one of the two factories above), built once per Filter: the closure
+        remembers the Laplacian object of its last call (_LaplacianMemo)."""
+        key = (make, id(self.filter_spec), self.Laplacian, self.evaluation)
+        hit = self.__dict__.get("_op")
+        if hit is None or hit[0] != key:
+            hit = (key, make(self.filter_spec, self.Laplacian, self.evaluation))
+            self.__dict__["_op"] = hit
+        return hit[1]
+
     def apply(self, ds, dims=None):
         """Filter an ``xarray.DataArray`` / ``xarray.Dataset`` with a scalar Laplacian across ``dims``
         (two names, latitude-like dimension first).
@@ -371,7 +415,7 @@ class Filter:
         if issubclass(self.Laplacian, BaseVectorLaplacian):
             raise ValueError(f"Provided Laplacian {self.Laplacian} is a vector Laplacian. "
                              f"The ``.apply`` method is only suitable for scalar Laplacians.")
-        filter_func = _create_filter_func(self.filter_spec, self.Laplacian, self.evaluation)
+        filter_func = self._operator(_create_filter_func)
         if _is_bare_array(ds):
             return filter_func(ds, *self._grid_args(as_xarray=False))
         xr = _xarray()
@@ -392,7 +436,7 @@ class Filter:
         if not issubclass(self.Laplacian, BaseVectorLaplacian):
             raise ValueError(f"Provided Laplacian {self.Laplacian} is a scalar Laplacian. "
                              f"The ``.apply_to_vector`` method is only suitable for vector Laplacians.")
-        filter_func_vec = _create_filter_func_vec(self.filter_spec, self.Laplacian, self.evaluation)
+        filter_func_vec = self._operator(_create_filter_func_vec)
         if _is_bare_array(ufield) and _is_bare_array(vfield):
             return filter_func_vec(ufield, vfield, *self._grid_args(as_xarray=False))
         u_filtered, v_filtered = self._through_apply_ufunc(filter_func_vec, [ufield, vfield], dims)

@@ -310,6 +310,17 @@ PLAN_CACHE = _PlanCache()
 def clear_plan_cache():
     """Drop every cached device plan (frees their HBM) and give the grid arrays they were built from back their writability."""
     PLAN_CACHE.clear()
+    global _CACHE_EPOCH
+    _CACHE_EPOCH += 1
+
+
+_CACHE_EPOCH = 0
+
+
+def kernels_cache_enabled() -> bool:
+    """Plans are cached (GCMF_PLAN_CACHE != 0) and sampled verification is in use: callers may then reuse a Laplacian object
+    for unchanged grid arrays (filter._LaplacianMemo); full verification re-hashes the planes on every call."""
+    return _CACHE_ON and not _VERIFY_FULL
 
 
 _VALUE_ERRORS = {_lib.ERR_KAPPA_W_GT1, _lib.ERR_KAPPA_S_GT1, _lib.ERR_KAPPA_NONE_ONE}
@@ -492,17 +503,18 @@ class _DeviceLaplacian:
             dev = fields[0].device.index
             plan = self._plan(dtype, (ny, nx), dev)
             tdt = torch.float64 if dtype == _lib.F64 else torch.float32
-            ins = [f.to(tdt).contiguous() for f in fields]
+            ins = [f if (f.dtype == tdt and f.is_contiguous()) else f.to(tdt).contiguous() for f in fields]
             outs = [torch.empty(shape, dtype=torch.float64 if out_np == np.float64 else torch.float32,
                                 device=fields[0].device) for _ in fields]
             if nbatch:
-                with torch.cuda.device(dev):
-                    stream = torch.cuda.current_stream().cuda_stream
-                    self._call(plan, spec, [t.data_ptr() for t in ins], [t.data_ptr() for t in outs], nbatch,
-                               True, out_f32, stream, forward)
-                    # inputs converted above may be temporaries: keep them alive until the stream is done
-                    for t in ins:
-                        t.record_stream(torch.cuda.current_stream())
+                # (the device index is passed explicitly: torch.cuda.current_stream() without one costs ~10 us per call, and
+                # libgcmf selects the plan's device itself -- no device context manager on this path)
+                cur = torch.cuda.current_stream(dev)
+                self._call(plan, spec, [t.data_ptr() for t in ins], [t.data_ptr() for t in outs], nbatch,
+                           True, out_f32, cur.cuda_stream, forward)
+                for t, f in zip(ins, fields):   # inputs converted above are temporaries: keep them alive until the stream is done
+                    if t is not f:
+                        t.record_stream(cur)
             return outs
         plan = self._plan(dtype, (ny, nx))
         host = [f.detach().cpu().numpy() if _is_torch(f) else np.asarray(f) for f in fields]
