@@ -437,8 +437,9 @@ static int launch_ring_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
     if (want < 1) want = 1;
     H = (int)((nrows + want - 1) / want);
     // (no rounding to the ring period: the march leaves its last period early, so the slab of one rank of an 8-GPU run marches
-    // 11 + 2 S rows, not 36.  At least S rows per strip: below that a strip marches more than three rows per row it owns)
-    if (H < S) H = S;
+    // 11 + 2 S rows, not 36.  Small grids get short strips -- a launch takes as long as ONE strip's march, and a grid that
+    // leaves wave slots idle lives in L2 anyway: 512x512 at H = 4 runs a filter in 26 us, at H = 16 in 40 us)
+    if (H < 4) H = 4;
   }
   if (H > nrows) H = nrows;
   P.H = H;

@@ -371,7 +371,7 @@ static int launch_ringc_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
     long long want = 1024 / ((long long)P.nwx * a.nbatch);
     if (want < 1) want = 1;
     H = (int)((nrows + want - 1) / want);
-    if (H < S) H = S;   // (no rounding to the ring period: see k_ring)
+    if (H < 4) H = 4;   // (no rounding to the ring period, short strips for small grids: see k_ring)
   }
   if (H > nrows) H = nrows;
   P.H = H;
