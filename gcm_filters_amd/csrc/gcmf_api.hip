@@ -531,13 +531,16 @@ static int clenshaw_cut(const gcmf_plan *pl, int n_steps, int *depths, int max_d
   if (!pl || pl->ncomp != 1 || !(pl->clenshaw >= 2 || (pl->clenshaw == 1 && pl->kind == K_FLUX))) return 0;
   // (tripolar: of the GRID, not of this slab -- every rank of a slab run must take the same decision)
   // (tripolar plans: the seam rows run k_fold_band's backward form beside every launch)
-  if (!pl->ring || !pl->zero_row || pl->d.dtype != GCMF_F64 || pl->multi_s < 8 || !multi_supported(pl, 8)) return 0;
+  // f32 state: the flux kinds only (four cells per lane; the whole polynomial is then carried in f32 -- Filter(evaluation="reference") /
+  // GCMF_FORWARD_RECURRENCE keep the reference's f64 running sum)
+  if (!pl->ring || !pl->zero_row || (pl->d.dtype != GCMF_F64 && pl->kind != K_FLUX) || pl->multi_s < 8 || !multi_supported(pl, 8)) return 0;
   if (pl->n_land > 0 && !land_ok(pl, n_steps)) return 0;
   if (!(n_steps >= 10 || (n_steps >= 5 && n_steps <= 8))) return 0;
   int n = 0, left = n_steps;
   while (left > 0) {
     int S = 0;
-    for (int cand = 8; cand >= 5 && !S; --cand) {
+    // (f32 state: the first launch -- it also carries the land bits of the rows that become b_n -- spills at eight levels)
+    for (int cand = (n == 0 && pl->d.dtype != GCMF_F64) ? 7 : 8; cand >= 5 && !S; --cand) {
       const int rest = left - cand;
       if (rest == 0 || (rest >= 5 && rest != 9)) S = cand;
     }
@@ -560,9 +563,11 @@ int gcmf_cheb_multi(gcmf_plan *pl, const void *u, const void *v, void *uo, void 
     // S levels of the backward evaluation on rows [row_lo, row_hi): (u, v) = (b_{k+1}, b_{k+2}) (FIRST: unused, the launch forms
     // b_n = p0 * f itself), fbar_in = the constant input f, pk[t] = coefficient of level t + 1, LAST: fbar_out = the result
     const bool first = mode & GCMF_STEP_FIRST, last = mode & GCMF_STEP_LAST;
-    int probe[1];
-    if (pl->d.dtype != GCMF_F64 || pl->ncomp != 1 || S < 5 || S > 8 || !pl->ring || !pl->zero_row ||
-        !(clenshaw_cut(pl, S, probe, 1) == 1)) {
+    int probe[2];
+    // (is the backward evaluation on offer for this plan at all: a 10-level polynomial can always be cut, [5, 5]; an f32 filter never
+    // starts with eight levels, see clenshaw_cut)
+    if (pl->ncomp != 1 || S < 5 || S > 8 || !pl->ring || !pl->zero_row || clenshaw_cut(pl, 10, probe, 2) != 2 ||
+        (first && S == 8 && pl->d.dtype != GCMF_F64)) {
       set_error("gcmf_cheb_multi: the backward evaluation is not available for this plan / depth %d", S);
       return GCMF_ERR_UNSUPPORTED;
     }
@@ -577,6 +582,7 @@ int gcmf_cheb_multi(gcmf_plan *pl, const void *u, const void *v, void *uo, void 
     m.u0 = u; m.v0 = v; m.uo = uo; m.vo = vo; m.fb_in = fbar_in; m.fb_out = fbar_out;
     for (int t = 0; t < S; ++t) m.pk[t] = pk[t];
     m.p0 = p0; m.c = c; m.S = S; m.first = first; m.last = last; m.nbatch = nbatch; m.row_lo = (int)row_lo; m.row_hi = (int)row_hi;
+    m.fb_is_f32 = (pl->d.dtype == GCMF_F32 && (flags & GCMF_OUT_F32)) ? 1 : 0;   // f32 state: the result is f64 unless asked otherwise
     return advance_multi(pl, m, (hipStream_t)stream, nullptr, true);
   }
   if (!pl || !u || !fbar_out || !pk) {
@@ -783,7 +789,7 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
     const void *x0[2] = {din[0], din[1]};
     int depths[1024];
     const bool fwd_only = flags & GCMF_FORWARD_RECURRENCE;   // the caller wants the reference's forward recurrence / accumulation
-    const int n_clen = (use_multi && !fb32 && !fwd_only) ? clenshaw_cut(pl, n_steps, depths, 1024) : 0;
+    const int n_clen = (use_multi && !fwd_only) ? clenshaw_cut(pl, n_steps, depths, 1024) : 0;
     if (n_clen > 0) {
       // Backward (Clenshaw) evaluation, gcmf_ringc_impl.hpp: state (b_{k+1}, b_{k+2}) in a pool of four planes, the constant
       // input read by every launch, no fbar planes.  The first launch forms b_n = p[n] f as it loads f; level l = 1..n uses
@@ -800,7 +806,7 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
         MultiArgs m{};
         m.u0 = u; m.v0 = v; m.uo = fr[0]; m.vo = fr[1];
         m.fb_in = din[0]; m.fb_out = dout[0];
-        m.first = (q == 0); m.last = (q == n_clen - 1); m.S = S; m.fb_is_f32 = 0;
+        m.first = (q == 0); m.last = (q == n_clen - 1); m.S = S; m.fb_is_f32 = fb32;
         for (int t = 0; t < S; ++t) m.pk[t] = p[n_steps - (lvl + t)];
         m.p0 = p[n_steps]; m.c = c; m.nbatch = nbatch; m.row_lo = 0; m.row_hi = rows;
         if ((rc = advance_multi(pl, m, s, &launches, true))) return rc;   // (+ the tripole band on tripolar plans)
@@ -809,7 +815,7 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
       }
       if (pl->n_land > 0) {  // the isolated cells' own polynomial (forward recurrence, as the reference computes it)
         if ((rc = ensure_dev_p(pl, p, n_steps, s))) return rc;
-        if ((rc = launch_land_fix(pl, din[0], dout[0], pl->dev_p, n_steps, c, 0, nbatch, s))) return rc;
+        if ((rc = launch_land_fix(pl, din[0], dout[0], pl->dev_p, n_steps, c, fb32 ? 1 : 0, nbatch, s))) return rc;
       }
     } else if (use_multi) {
       // Temporally blocked schedule (scalar kinds): each launch advances S steps and reads/writes every plane

@@ -98,6 +98,7 @@ template <typename T, typename FB> struct MultiP {
   T *vo;            // T_{k-2+S}          (unused when last)
   const FB *fb_in;  // running sum in     (unused when first)
   FB *fb_out;       // running sum out / finalised result when last
+  double *d_out;    // k_ringc, f32 state: the f64 result of the last launch (instead of fb_out) or NULL
   const T *cE, *cN, *ra;
   const T *zrow;    // nx zeros (k_ring: coefficient rows beyond a closed boundary)
   const uint8_t *mbits;

@@ -28,6 +28,12 @@
 
 namespace gcmf {
 
+// the VEC bytes (mask bits / land bits) of a lane's cells in one load
+template <int VEC> __device__ __forceinline__ unsigned cell_bytes(const uint8_t *p) {
+  if constexpr (VEC == 2) return *reinterpret_cast<const unsigned short *>(p);
+  else return *reinterpret_cast<const unsigned *>(p);
+}
+
 // one march of a strip; returns whether this wave met a non-finite value in its last level (wave-uniform)
 template <typename T, int KIND, int S, bool FIRST, bool SANI>
 __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid) {
@@ -126,7 +132,7 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
       mload<T, VEC>(G0[sl], lane_ptr(P.u0 + boff + rcur, colT));
     } else {
       mload<T, VEC>(G0[sl], lane_ptr(fplane + rcur, colT));
-      Zu[sl] = *reinterpret_cast<const unsigned short *>(lane_ptr(zbase + rcur, col));
+      Zu[sl] = cell_bytes<VEC>(lane_ptr(zbase + rcur, col));
       if constexpr (!FLUX) mload<T, VEC>(ARu[sl], lane_ptr(abase + rcur, colT));
     }
   };
@@ -145,10 +151,10 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
     }
     if constexpr (MASK) {
       const uint8_t *mp = lane_ptr(out_c ? (const uint8_t *)P.zrow : P.mbits + rc, col);
-      B[sl] = *reinterpret_cast<const unsigned short *>(mp);
+      B[sl] = cell_bytes<VEC>(mp);
     }
     mload<T, VEC>(Ff[sl], lane_ptr(fplane + rc, colT));
-    Zc[sl] = *reinterpret_cast<const unsigned short *>(lane_ptr(zbase + rc, col));
+    Zc[sl] = cell_bytes<VEC>(lane_ptr(zbase + rc, col));
     if constexpr (!FLUX) mload<T, VEC>(ARc[sl], lane_ptr(abase + rc, colT));
     if constexpr (!FIRST) mload<T, VEC>(V[vs], lane_ptr(P.v0 + boff + rc, colT));  // a first launch: b_{n+1} = 0
   };
@@ -276,7 +282,14 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
 #pragma unroll
             for (int k = 0; k < VEC; ++k) out_u[k] = out_u[k] / ar[k];
           }
-          mstore<T, VEC>(lane_ptr(P.fb_out + off, colT), out_u);
+          if (P.d_out) {   // (wave-uniform) f32 state, f64 result: NumPy >= 2 promotes p[k] * T
+            double dd[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) dd[k] = (double)out_u[k];
+            mstore<double, VEC>(lane_ptr(P.d_out + off, 2 * colT), dd);
+          } else {
+            mstore<T, VEC>(lane_ptr(P.fb_out + off, colT), out_u);
+          }
         }
       }
     }
@@ -351,6 +364,11 @@ static int launch_ringc_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   P.vo = (T *)a.vo;
   P.fb_in = (const T *)a.fb_in;   // the constant input f
   P.fb_out = (T *)a.fb_out;       // the result (last launch)
+  P.d_out = nullptr;
+  if (sizeof(T) == 4 && !a.fb_is_f32) {   // f32 state: the result is f64 unless the caller asked for f32 (GCMF_OUT_F32)
+    P.d_out = (double *)a.fb_out;
+    P.fb_out = nullptr;
+  }
   P.cE = (const T *)g.coef[0];
   P.cN = (const T *)g.coef[1];
   P.ra = (const T *)g.coef[2];
@@ -396,7 +414,19 @@ static int launch_ringc_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
 
 template <int KIND> static int launch_ringc_kind(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   if (pl->d.dtype != GCMF_F64) {
-    set_error("k_ringc: f64 plans only");
+    if constexpr (KIND == K_FLUX) {   // f32 state, four cells per lane: the flux kinds only (the others are bit-exact with numpy forward)
+      switch (a.S) {
+        case 5: return a.first ? launch_ringc_sf<float, KIND, 5, true>(pl, a, s) : launch_ringc_sf<float, KIND, 5, false>(pl, a, s);
+        case 6: return a.first ? launch_ringc_sf<float, KIND, 6, true>(pl, a, s) : launch_ringc_sf<float, KIND, 6, false>(pl, a, s);
+        case 7: return a.first ? launch_ringc_sf<float, KIND, 7, true>(pl, a, s) : launch_ringc_sf<float, KIND, 7, false>(pl, a, s);
+        case 8:   // (never a first launch: clenshaw_cut starts an f32 filter with at most seven levels -- eight spill there)
+          if (a.first) break;
+          return launch_ringc_sf<float, KIND, 8, false>(pl, a, s);
+      }
+      set_error("k_ringc<float>: depth %d%s is not offered", a.S, a.first ? " as a first launch" : "");
+      return GCMF_ERR_INVALID_ARG;
+    }
+    set_error("k_ringc: f32 plans of the flux kinds only");
     return GCMF_ERR_UNSUPPORTED;
   }
   switch (a.S) {

@@ -128,12 +128,12 @@ class _Block:
                 mode = _lib.STEP_CLENSHAW | (_lib.STEP_FIRST if q == 0 else 0) | (_lib.STEP_LAST if last else 0)
                 plan.cheb_multi(0 if u is None else u.data_ptr(), 0 if v is None else v.data_ptr(), free[0].data_ptr(),
                                 free[1].data_ptr(), self.X.data_ptr(), O.data_ptr(), p[n - lvl - S + 1: n - lvl + 1][::-1], p[n], c,
-                                mode, 1, lo, hi, stream=stream)
+                                mode, 1, lo, hi, out_f32=out_f32, stream=stream)
                 u, v = free[0], free[1]
                 valid = v_out
                 lvl += S
             if self.has_land:
-                plan.land_fix(p, c, [self.X.data_ptr()], [O.data_ptr()], 1, out_f32=False, stream=stream)
+                plan.land_fix(p, c, [self.X.data_ptr()], [O.data_ptr()], 1, out_f32=out_f32, stream=stream)
             return
         Fc, Fn = self.F
         u, v = self.X, None

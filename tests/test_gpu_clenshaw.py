@@ -98,13 +98,15 @@ def test_default_is_backward_for_flux_kinds_and_forward_for_the_rest():
     got = flt.apply(f)
     assert "k_ringc<" not in plan.last_kernel()
     assert np.nanmax(np.abs(got - want)) <= 1e-12 * np.nanmax(np.abs(want))
-    f32, gv = T.scalar_case("IRREGULAR_WITH_LAND", (120, 256))
-    gv = {k: v.astype("f4") for k, v in gv.items()}
-    dx = T.grid_dx_min("IRREGULAR_WITH_LAND", gv)
-    flt = Filter(filter_scale=4.0 * dx, dx_min=dx, n_steps=16, grid_type=GridType.IRREGULAR_WITH_LAND, grid_vars=gv)
-    flt.apply(f32.astype("f4"))
-    plan = ALL_KERNELS[GridType.IRREGULAR_WITH_LAND](**gv)._plan(_lib.F32, (120, 256))
-    assert plan.clenshaw_cut(16) == [] and "k_ringc<" not in plan.last_kernel()
+    # f32 state: backward for the flux kinds (four cells per lane), forward for the kinds that are bit-exact with numpy
+    for grid, backward in (("IRREGULAR_WITH_LAND", True), ("REGULAR_WITH_LAND", False)):
+        f32, gv = T.scalar_case(grid, (120, 256))
+        gv = {k: v.astype("f4") for k, v in gv.items()}
+        dx = T.grid_dx_min(grid, gv) if O.DIMENSIONAL[grid] else 1.0
+        flt = Filter(filter_scale=4.0 * dx, dx_min=dx, n_steps=16, grid_type=GridType[grid], grid_vars=gv)
+        flt.apply(f32.astype("f4"))
+        plan = ALL_KERNELS[GridType[grid]](**gv)._plan(_lib.F32, (120, 256))
+        assert bool(plan.clenshaw_cut(16)) == backward and ("k_ringc<float" in plan.last_kernel()) == backward
 
 
 @pytest.mark.parametrize("dt,nlev,n_steps", [("f4", 1, 9), ("f4", 5, 16), ("f4", 7, 23), ("f8", 1, 11), ("f8", 4, 16), ("f4", 50, 44)])
@@ -235,3 +237,52 @@ def test_evaluation_option_reaches_the_plan_for_scalar_grids_too():
         with pytest.raises(ValueError, match="evaluation must be one of"):
             Filter(filter_scale=4.0, dx_min=1.0, evaluation="fast")
     assert np.abs(outs["auto"] - outs["reference"]).max() <= 1e-13 * np.abs(outs["reference"]).max()
+
+
+@pytest.mark.parametrize("grid", ["IRREGULAR_WITH_LAND", "MOM5U", "MOM5T", "TRIPOLAR_POP_WITH_LAND"])
+@pytest.mark.parametrize("n_steps,kwargs", [(16, {}), (24, dict(nanland=True)), (63, {}), (21, dict(nanwet=True)), (15, dict(nb=3, nanland=True))])
+def test_f32_flux_kinds_backward_evaluation(grid, n_steps, kwargs):
+    """f32 state on the flux-form grids runs k_ringc<float> (four cells per lane, no f64 running-sum ring).  Against the
+    oracle's f64 arithmetic within the f32-state gate (SURVEY 8d: 1e-4; measured ~1e-6), f64 result dtype like the reference's
+    promotion, NaN pattern incl. NaN in a wet cell (the in-kernel redo), and Filter(evaluation="reference") takes the forward kernels."""
+    import warnings
+    shape = (150, 512)
+    f, gv = T.scalar_case(grid, shape)
+    nb = kwargs.get("nb", 1)
+    if nb > 1:
+        f = np.stack([f + 0.1 * i for i in range(nb)])
+    land = gv["wet_mask"] == 0
+    if kwargs.get("nanland"):
+        f = np.where(land, np.nan, f)
+    if kwargs.get("nanwet"):
+        f = f.copy()
+        j, i = np.argwhere(~land)[len(np.argwhere(~land)) // 2]
+        f[..., j, i] = np.nan
+    f4 = f.astype("f4")
+    gv4 = {k: v.astype("f4") for k, v in gv.items()}
+    dx = T.grid_dx_min(grid, gv4)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        flt = Filter(filter_scale=4.0 * dx, dx_min=dx, n_steps=n_steps, filter_shape=FilterShape.TAPER, grid_type=GridType[grid], grid_vars=gv4)
+        ref = Filter(filter_scale=4.0 * dx, dx_min=dx, n_steps=n_steps, filter_shape=FilterShape.TAPER, grid_type=GridType[grid], grid_vars=gv4,
+                     evaluation="reference")
+    fs = flt.filter_spec
+    with np.errstate(all="ignore"):
+        want = O.filter_func(O.FilterSpec(fs.n_steps, fs.s_max, np.asarray(fs.p), fs.dx_min_sq), grid, f4.astype("f8"),
+                             {k: v.astype("f8") for k, v in gv4.items()})
+    plan = ALL_KERNELS[GridType[grid]](**gv4)._plan(_lib.F32, shape)
+    plan.ring_fallbacks()
+    got = flt.apply(f4)
+    assert "k_ringc<float" in plan.last_kernel(), plan.last_kernel()
+    nfb = plan.ring_fallbacks()
+    fwd = ref.apply(f4)
+    assert "k_ringc<" not in plan.last_kernel()
+    assert got.dtype == np.float64 and fwd.dtype == np.float64
+    for g in (got, fwd):
+        assert np.array_equal(np.isnan(g), np.isnan(want))
+        assert np.nanmax(np.abs(g - want)) <= 1e-4 * np.nanmax(np.abs(want))
+    assert np.nanmax(np.abs(got - want)) <= 2.5 * np.nanmax(np.abs(fwd - want)) + 2e-6 * np.nanmax(np.abs(want))   # same accuracy class as the reference's scheme
+    if kwargs.get("nanwet"):
+        assert nfb > 0
+    elif not (grid.startswith("MOM5") and kwargs.get("nanland")):
+        assert nfb == 0
