@@ -310,19 +310,22 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
   load_centre(ic<2>{}, ic<2>{});
   load_u(ic<2>{});
   static_assert(D == 3, "prologue");
-  for (int r0 = r_begin;; r0 += R) {   // (the last period is left after the strip's last row, see k_ring)
+  // The flux kinds march whole periods: every early exit costs this kernel dozens of registers (146 -> 204 AGPRs with an exit
+  // every four rows), and on tripolar plans k_fold_band's waves have to fit on the SIMDs NEXT to these (gcmf_foldband.hip).
+  constexpr bool EARLY = (KIND != K_FLUX);
+  for (int r0 = r_begin;; r0 += R) {
     bool done = true;
     do {
       phase(ic<0>{}, r0);
       phase(ic<1>{}, r0 + 1);
       phase(ic<2>{}, r0 + 2);
       phase(ic<3>{}, r0 + 3);
-      if (r0 + 3 >= r_last) break;     // (exits every four rows: one per row costs the kernel 100 registers more)
+      if (EARLY && r0 + 3 >= r_last) break;     // (the last period is left after the strip's last row, see k_ring)
       phase(ic<4>{}, r0 + 4);
       phase(ic<5>{}, r0 + 5);
       phase(ic<6>{}, r0 + 6);
       phase(ic<7>{}, r0 + 7);
-      if (r0 + 7 >= r_last) break;
+      if (EARLY && r0 + 7 >= r_last) break;
       phase(ic<8>{}, r0 + 8);
       phase(ic<9>{}, r0 + 9);
       phase(ic<10>{}, r0 + 10);
@@ -389,7 +392,8 @@ static int launch_ringc_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
     long long want = 1024 / ((long long)P.nwx * a.nbatch);
     if (want < 1) want = 1;
     H = (int)((nrows + want - 1) / want);
-    if (H < 4) H = 4;   // (no rounding to the ring period, short strips for small grids: see k_ring)
+    if (H < 4) H = 4;   // (short strips for small grids: see k_ring)
+    if (KIND == K_FLUX) H += (R - (H + 2 * S) % R) % R;   // whole periods (no early exit here): let the padding carry real rows
   }
   if (H > nrows) H = nrows;
   P.H = H;
