@@ -157,15 +157,18 @@ __device__ __forceinline__ void cgrid_stream2_body(const CStream2P<T, FB> &P) {
   auto load_row = [&](Row &x, int r) {
     const long long ro = (long long)row_index(r) * nx + col;
     const long long rc = (long long)row_index(r - 1) * nx + col;
-    mload<T, VEC>(x.u, P.u0 + boff + ro);
-    mload<T, VEC>(x.v, P.v0 + boff + ro);
-    if (!first) {
-      mload<T, VEC>(x.up, P.up + boff + rc);
-      mload<T, VEC>(x.vp, P.vp + boff + rc);
-    }
-    if (!first || CLEN) {  // fbar -- or, backward evaluation, the row of the constant input
-      mload<FB, VEC>(x.fu, P.fu_in + boff + rc);
-      mload<FB, VEC>(x.fv, P.fv_in + boff + rc);
+    if (!shadow) {   // (wave-uniform) levels that pad the last workgroup of a tile are HELPER waves: they fetch and publish their
+      //               share of the coefficient rows, keep the barriers, and load / compute nothing else
+      mload<T, VEC>(x.u, P.u0 + boff + ro);
+      mload<T, VEC>(x.v, P.v0 + boff + ro);
+      if (!first) {
+        mload<T, VEC>(x.up, P.up + boff + rc);
+        mload<T, VEC>(x.vp, P.vp + boff + rc);
+      }
+      if (!first || CLEN) {  // fbar -- or, backward evaluation, the row of the constant input
+        mload<FB, VEC>(x.fu, P.fu_in + boff + rc);
+        mload<FB, VEC>(x.fv, P.fv_in + boff + rc);
+      }
     }
     if (PRIV) {
 #pragma unroll
@@ -214,6 +217,10 @@ __device__ __forceinline__ void cgrid_stream2_body(const CStream2P<T, FB> &P) {
     if (!PRIV) {
       publish(x);
       __syncthreads();
+      if (shadow) {   // a helper wave: its rows are published, nothing to compute
+        cur = (cur + 1 == NS) ? 0 : cur + 1;
+        return;
+      }
     }
 
     T cu[S + 1][VEC], cv[S + 1][VEC];  // newest row of every level this iteration
