@@ -480,8 +480,9 @@ def parse():
                          "weak = every GPU owns ny rows of an (N*ny, nx) grid")
     ap.add_argument("--no-weak", action="store_true", help="N>1: skip the second (weak-scaling) measurement")
     ap.add_argument("--halo", type=int, default=0, help="N>1: ghost rows per exchange (0 = auto)")
-    ap.add_argument("--exchange", choices=["auto", "native", "torch"], default="auto",
-                    help="N>1 halo exchange: native = issued by libgcmf (peer copies + events); torch = torch.distributed P2P")
+    ap.add_argument("--exchange", choices=["auto", "native", "torch", "p2p"], default="auto",
+                    help="N>1 halo exchange: native = RCCL send / recv issued by libgcmf on a side stream; torch = torch.distributed P2P; "
+                         "p2p = peer stores into IPC-mapped mailboxes + flags on the compute stream (csrc/gcmf_p2p.hip, one node)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (and the oracle parity check)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs measurements (configs 2, 4, 5)")
     ap.add_argument("--no-replan", action="store_true", help="keep ONE plan for all timed blocks (profiling runs: one placement)")
@@ -725,9 +726,28 @@ def main_multi(args, world, rank, local_rank):
             assert bool((m == 1).all()), "every probe must be owned by exactly one rank"
             chk["got"], chk["mine"] = g.cpu().numpy(), np.ones(chk["mine"].shape, dtype=bool)
             parity = dict(finish_probe_check(chk), tolerance=1e-6 if itemsize == 8 else 1e-4)
+        # what the halo exchanges cost this run: the same slabs once more with the exchange stubbed out (ghost rows go stale, the
+        # launches and their row ranges are the real ones) -- host + device cost per exchange = the difference / exchanges
+        sf.exchanges = 0
+        keep_o = {}
+        def one_real():
+            keep_o["o"] = sf.apply_local(local_main)
+        local_main = sf.scatter_from_global(wl["fields"])
+        one_real()
+        ex_per_app = sf.exchanges
+        real_start, real_finish = sf._exchange_start, sf._exchange_finish
+        sf._exchange_start, sf._exchange_finish = (lambda tensors: None), (lambda ticket: None)
+        el_stub = timed(one_real)
+        sf._exchange_start, sf._exchange_finish = real_start, real_finish
+        exchange_rec = {"kind": sf.exchange_kind, "halo_rows": sf.halo, "exchanges_per_application": ex_per_app,
+                        "ms_per_application_without_exchange": 1e3 * el_stub / args.steps,
+                        "us_per_exchange_host_and_device": (1e6 * (elapsed - el_stub) / args.steps / ex_per_app) if ex_per_app else None,
+                        "note": "max over ranks of the timed region with the exchange stubbed out, subtracted from the real run"}
+        one_real = None
+        keep_o.clear()
         weak = None
         if args.scaling == "strong" and not args.no_weak:
-            del sf, outs
+            del sf, outs, local_main
             free_gpu()
             wl2, sf2, _, el2 = measure(args.ny * world, "weak")
             weak = {"value": args.ny * world * args.nx * sf2.n_steps * args.steps / el2, "unit": "cell-steps/s",
@@ -745,7 +765,7 @@ def main_multi(args, world, rank, local_rank):
                                    + (f" x{args.nlev or 50} levels" if cfg == 5 else ""),
                        "filter": f"{fk['filter_shape']} filter_scale={fk['filter_scale']:.6g} dx_min={fk['dx_min']:.6g}",
                        "n_steps": n_steps, "global_grid": [ny_global, args.nx], "parallelism": par},
-            "parity": parity, "weak": weak, "cpu_baseline": None,
+            "parity": parity, "weak": weak, "exchange": exchange_rec if cfg not in (5, 6) else None, "cpu_baseline": None,
             "roofline": None if not launches else {
                 "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "kernel_ms_per_step_rank0": kernel_ms / args.steps,
                 "launches_per_step_rank0": launches / args.steps,

@@ -32,6 +32,7 @@ EXPORTS = [
     "gcmf_has_land", "gcmf_zero_land", "gcmf_land_fix", "gcmf_last_kernel", "gcmf_last_kernel_timing", "gcmf_ring_fallbacks", "gcmf_clenshaw_cut",
     "gcmf_comm_unique_id", "gcmf_comm_create", "gcmf_comm_destroy", "gcmf_halo_start", "gcmf_halo_finish",
     "gcmf_build_id", "gcmf_last_kernel_geometry",
+    "gcmf_p2p_create", "gcmf_p2p_export", "gcmf_p2p_connect", "gcmf_p2p_start", "gcmf_p2p_finish", "gcmf_p2p_status", "gcmf_p2p_destroy",
 ]
 PLAN_SELF_RING, PLAN_SKIP_KAPPA_ONE = 0x1, 0x2
 
@@ -140,6 +141,20 @@ def load() -> C.CDLL:
         lib.gcmf_halo_start.restype = C.c_int
         lib.gcmf_halo_finish.argtypes = [vp, vp]
         lib.gcmf_halo_finish.restype = C.c_int
+        lib.gcmf_p2p_create.argtypes = [C.c_int, C.c_int64, vpp]
+        lib.gcmf_p2p_create.restype = C.c_int
+        lib.gcmf_p2p_export.argtypes = [vp, C.c_char_p]
+        lib.gcmf_p2p_export.restype = C.c_int
+        lib.gcmf_p2p_connect.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+        lib.gcmf_p2p_connect.restype = C.c_int
+        lib.gcmf_p2p_start.argtypes = [vp, vpp, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, vp]
+        lib.gcmf_p2p_start.restype = C.c_int
+        lib.gcmf_p2p_finish.argtypes = [vp, vp]
+        lib.gcmf_p2p_finish.restype = C.c_int
+        lib.gcmf_p2p_status.argtypes = [vp, C.POINTER(C.c_int)]
+        lib.gcmf_p2p_status.restype = C.c_int
+        lib.gcmf_p2p_destroy.argtypes = [vp]
+        lib.gcmf_p2p_destroy.restype = None
         lib.gcmf_last_kernel_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float),
                                                 C.POINTER(C.c_float)]
         lib.gcmf_last_kernel_timing.restype = C.c_int
@@ -392,3 +407,46 @@ class Comm:
 
     def halo_finish(self, stream: int = 0):
         check(load().gcmf_halo_finish(self._h, C.c_void_p(stream or None)))
+
+
+class P2P:
+    """Owning handle of a gcmf_p2p: this rank's mailbox block + the mapped blocks of its two neighbours (csrc/gcmf_p2p.hip)."""
+
+    def __init__(self, device: int, mailbox_bytes: int):
+        self._h = None
+        out = C.c_void_p()
+        check(load().gcmf_p2p_create(int(device), int(mailbox_bytes), C.byref(out)))
+        self._h = out
+
+    def export(self) -> bytes:
+        buf = C.create_string_buffer(64)
+        check(load().gcmf_p2p_export(self._h, buf))
+        return buf.raw
+
+    def connect(self, south: Optional[bytes], north: Optional[bytes], south_is_self: bool = False, north_is_self: bool = False):
+        mk = lambda h: None if h is None else C.create_string_buffer(bytes(h), 64)
+        self._keep = (mk(south), mk(north))
+        check(load().gcmf_p2p_connect(self._h, self._keep[0], self._keep[1], int(bool(south_is_self)), int(bool(north_is_self))))
+
+    def start(self, states: Sequence[int], nblocks, rows_alloc, nx, first_owned, rows_owned, halo, dtype, stream: int = 0):
+        check(load().gcmf_p2p_start(self._h, _ptr_array(states), len(states), int(nblocks), int(rows_alloc), int(nx), int(first_owned),
+                                    int(rows_owned), int(halo), int(dtype), C.c_void_p(stream or None)))
+
+    def finish(self, stream: int = 0):
+        check(load().gcmf_p2p_finish(self._h, C.c_void_p(stream or None)))
+
+    def timed_out(self) -> bool:
+        v = C.c_int()
+        check(load().gcmf_p2p_status(self._h, C.byref(v)))
+        return bool(v.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().gcmf_p2p_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -93,7 +93,9 @@ class SlabFilter:
 
     ``exchange``: who issues the halo exchange -- ``"native"``: libgcmf itself (gcmf_halo_start / gcmf_halo_finish: RCCL
     send / recv on a side stream, a few microseconds of host time per exchange), ``"torch"``: torch.distributed P2P ops
-    (any backend; what the gloo tests use), ``"auto"``: native on one-GPU-per-rank RCCL groups, torch otherwise.
+    (any backend; what the gloo tests use), ``"auto"``: native on one-GPU-per-rank RCCL groups, torch otherwise,
+    ``"p2p"``: peer stores into the neighbours' IPC-mapped mailboxes + flags, two small kernels on the compute stream per
+    exchange and no RCCL at all (csrc/gcmf_p2p.hip; the ranks of ONE node; any backend carries the 64-byte handles once).
     ``self_ring`` (one rank, periodic grids): keep ghost rows and exchange with itself -- the whole slab choreography
     incl. the native exchange on a single GPU.
     """
@@ -170,13 +172,20 @@ class SlabFilter:
         self.south = ((r - 1) % P) if (self.multi and self.gs > 0) else None
         self.north = ((r + 1) % P) if (self.multi and self.gn > 0) else None
         # who issues the exchange
-        if exchange not in ("auto", "native", "torch"):
-            raise ValueError(f"exchange must be 'auto', 'native' or 'torch', not {exchange!r}")
+        if exchange not in ("auto", "native", "torch", "p2p"):
+            raise ValueError(f"exchange must be 'auto', 'native', 'torch' or 'p2p', not {exchange!r}")
         on_gpu = self.device.type == "cuda" and engine_factory is None
         rccl_group = self.self_ring or (dist.is_initialized() and dist.get_backend(group) == "nccl")
         if exchange == "native" and not (on_gpu and rccl_group):
             raise ValueError("exchange='native' needs one MI355X per rank (RCCL process group or self_ring)")
-        self.exchange_kind = "native" if (self.multi and on_gpu and rccl_group and exchange != "torch") else "torch"
+        self.exchange_kind = "native" if (self.multi and on_gpu and rccl_group and exchange not in ("torch", "p2p")) else "torch"
+        self.p2p = None
+        self._p2p_cap = 0
+        if exchange == "p2p":
+            if not on_gpu:
+                raise ValueError("exchange='p2p' needs the HIP engine on an MI355X")
+            if (self.nx * self.np_dtype.itemsize) % 16 == 0:   # (16-byte copies; every rank sees the same nx)
+                self.exchange_kind = "p2p" if self.multi else "torch"
         self.comm = None
         if self.exchange_kind == "native" and self.multi:
             # "auto" falls back to torch.distributed P2P if libgcmf cannot bring up its own communicator (all ranks agree)
@@ -281,6 +290,13 @@ class SlabFilter:
         enqueued on the compute stream AFTER this call (the interior of the slab) overlaps with the transfer."""
         if not self.multi or (self.south is None and self.north is None):
             return None
+        if self.exchange_kind == "p2p":   # peer stores into the neighbours' mailboxes, on the compute stream
+            x0 = tensors[0]
+            nblocks = x0.shape[0] * x0.shape[1]
+            self._p2p_ready(2 * nblocks * self.halo * self.nx * x0.element_size())   # (sized for two states)
+            self.p2p.start([x.data_ptr() for x in tensors], nblocks, self.rows_alloc, self.nx, self.first_owned, self.rows_owned,
+                           self.halo, self.dtype_code, stream=self.torch.cuda.current_stream().cuda_stream)
+            return "p2p"
         if self.comm is not None:  # libgcmf issues the RCCL send / recv pairs on its side stream
             x0 = tensors[0]
             self.comm.halo_start([x.data_ptr() for x in tensors], x0.shape[0] * x0.shape[1], self.rows_alloc, self.nx,
@@ -331,6 +347,10 @@ class SlabFilter:
     def _exchange_finish(self, ticket):
         if ticket is None:
             return
+        if ticket == "p2p":
+            self.p2p.finish(stream=self.torch.cuda.current_stream().cuda_stream)
+            self.exchanges += 1
+            return
         if ticket == "native":
             self.comm.halo_finish(stream=self.torch.cuda.current_stream().cuda_stream)
             self.exchanges += 1
@@ -346,6 +366,34 @@ class SlabFilter:
                 p.copy_(buf[off: off + p.numel()].view(p.shape))
                 off += p.numel()
         self.exchanges += 1
+
+    def _p2p_ready(self, nbytes: int):
+        """The mailbox block of this rank, mapped by its neighbours (collective: every rank calls it with the same size)."""
+        if self.p2p is not None and nbytes <= self._p2p_cap:
+            return
+        t, dist = self.torch, self.dist
+        if self.p2p is not None:
+            t.cuda.synchronize()
+            if self.world > 1:
+                dist.barrier(group=self.group)     # nobody may still be writing into a block that is about to go
+            self.p2p.close()
+        self.p2p = _lib.P2P(self.device.index, nbytes)
+        self._p2p_cap = nbytes
+        mine = self.p2p.export()
+        if self.world > 1:
+            handles = [None] * self.world
+            dist.all_gather_object(handles, mine, group=self.group)
+        else:
+            handles = [mine]
+        pick = lambda r: None if r is None else handles[r]
+        self.p2p.connect(pick(self.south), pick(self.north), south_is_self=(self.south == self.rank),
+                         north_is_self=(self.north == self.rank))
+        if self.world > 1:
+            dist.barrier(group=self.group)         # every block is mapped before the first post
+
+    def p2p_timed_out(self) -> bool:
+        """After a synchronisation: did a wait inside the p2p kernels time out (a neighbour that never posted)?"""
+        return self.p2p is not None and self.p2p.timed_out()
 
     def collect_kernel_times(self):
         """Fold the launch events recorded since the last call into ``kernel_ms`` / ``kernel_launches`` (synchronises)."""

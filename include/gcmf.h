@@ -286,6 +286,24 @@ int gcmf_last_kernel_geometry(gcmf_plan *plan, char *buf, int n);
  * count on ocean data means non-finite values in wet cells (NaN on land is masked on load and costs nothing). */
 int gcmf_ring_fallbacks(gcmf_plan *plan, int64_t *count);
 
+/* ---- peer-to-peer halo exchange for the ranks of one node (csrc/gcmf_p2p.hip; SURVEY 8e "latency escape hatch": direct peer stores
+ * into the neighbour's memory + flags instead of an RCCL group).  Every rank owns a mailbox block its two neighbours map through
+ * HIP IPC: gcmf_p2p_create (mailbox_bytes >= the largest message: nstate * nblocks * halo * nx * sizeof(T)), gcmf_p2p_export (64-byte
+ * hipIpcMemHandle_t, handed to the neighbours by the caller's own channel), gcmf_p2p_connect (south / north handles, NULL = a physical
+ * boundary; *_is_self: that neighbour is this very process), then per exchange gcmf_p2p_start (after the launches that produced the edge
+ * rows) ... interior launches ... gcmf_p2p_finish (before the next launch that reads the ghost rows), both enqueued on the caller's
+ * compute stream: two small kernels, no events, no host round trip.  Waits inside the kernels are bounded (2 s); gcmf_p2p_status
+ * reports a wait that timed out after the stream was synchronised.  Arguments of gcmf_p2p_start as gcmf_halo_start. */
+typedef struct gcmf_p2p gcmf_p2p;
+int gcmf_p2p_create(int device, int64_t mailbox_bytes, gcmf_p2p **out);
+int gcmf_p2p_export(gcmf_p2p *p, void *handle64);
+int gcmf_p2p_connect(gcmf_p2p *p, const void *south_handle64, const void *north_handle64, int south_is_self, int north_is_self);
+int gcmf_p2p_start(gcmf_p2p *p, void *const *states, int nstate, int64_t nblocks, int64_t rows_alloc, int64_t nx, int64_t first_owned,
+                   int64_t rows_owned, int halo, int dtype, void *stream);
+int gcmf_p2p_finish(gcmf_p2p *p, void *stream);
+int gcmf_p2p_status(gcmf_p2p *p, int *timed_out);
+void gcmf_p2p_destroy(gcmf_p2p *p);
+
 /* Tunables: rows marched per wave of the single-step kernel (0 keeps the default); XCD-aware tile order
  * (1 on, 0 off, <0 keep); temporal blocking: low byte = recurrence steps fused per HBM pass (1 = off,
  * 2..8), bits 8-23 = rows per wave strip (0 = auto), bits 24-27 = operand rows in flight of the general kernels, bits 28-29 =

@@ -32,7 +32,8 @@ def test_gpus_8_without_devices_fails_loudly():
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
-@pytest.mark.parametrize("cfg,extra", [(3, []), (4, ["--scaling", "weak"]), (5, ["--nlev", "5"])])
+@pytest.mark.parametrize("cfg,extra", [(3, []), (4, ["--scaling", "weak"]), (5, ["--nlev", "5"]), (3, ["--exchange", "p2p"]),
+                                       (4, ["--exchange", "p2p"])])
 def test_self_launch_two_ranks_sharing_the_gpu(cfg, extra):
     r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--config", str(cfg), "--ny", "256", "--nx", "256",
               "--no-weak", *extra], {"GCMF_BENCH_SHARE_GPU": "1"})
@@ -41,6 +42,10 @@ def test_self_launch_two_ranks_sharing_the_gpu(cfg, extra):
     assert line["n_gpus"] == 2 and line["value"] > 0
     assert line["scaling"] == ("weak" if "weak" in extra else "strong")
     assert line["config"]["global_grid"] == [512 if "weak" in extra else 256, 256]
+    if cfg != 5:   # the N > 1 line says what its halo exchanges cost (host + device, per exchange)
+        ex = line["exchange"]
+        assert ex["kind"] == ("p2p" if "p2p" in extra else "torch") and ex["exchanges_per_application"] >= 1
+        assert ex["ms_per_application_without_exchange"] > 0 and ex["us_per_exchange_host_and_device"] is not None
 
 
 def test_single_gpu_line_carries_parity_and_roofline():

@@ -49,7 +49,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, exchange="auto"):
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
     sys.path.insert(0, os.path.dirname(here))
@@ -77,11 +77,14 @@ def _worker(rank, world, port, q):
                 fields = [f.astype(np.float32) for f in fields]
             dx = T.grid_dx_min(grid, gv) if O.DIMENSIONAL[grid] else 1.0
             fk = dict(filter_scale=5.0 * dx, dx_min=dx, filter_shape="GAUSSIAN")
-            sf = SlabFilter(grid, gv, fk, shape[0], shape[1], halo=halo, dtype=np.dtype(dt), device=0)
+            sf = SlabFilter(grid, gv, fk, shape[0], shape[1], halo=halo, dtype=np.dtype(dt), device=0, exchange=exchange)
+            if exchange == "p2p":   # peer stores into IPC-mapped mailboxes (csrc/gcmf_p2p.hip); rows that are not a multiple of 16 bytes fall back
+                assert sf.exchange_kind == ("p2p" if (shape[1] * np.dtype(dt).itemsize) % 16 == 0 else "torch")
             sf.overlap = True   # small test slabs: force the overlapped (edge strips first) exchange where it fits
             sf.time_kernels = True
             got = sf.gather_to_global(sf.apply_local(sf.scatter_from_global(fields)))
             sf.collect_kernel_times()
+            assert not sf.p2p_timed_out(), grid
             if sf.backward_cut:   # f64 flux kinds, not tripolar: the slabs evaluate backwards like the one-GPU path (k_ringc)
                 assert "k_ringc<" in sf.engine.plan.last_kernel(), (grid, sf.engine.plan.last_kernel())
             if vec:   # the blocked vector kernels really ran on the slabs
@@ -104,13 +107,13 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3, 8])
-def test_slabs_on_one_gpu_match_single_domain(world):
+@pytest.mark.parametrize("world,exchange", [(2, "auto"), (3, "auto"), (8, "auto"), (2, "p2p"), (3, "p2p"), (8, "p2p")])
+def test_slabs_on_one_gpu_match_single_domain(world, exchange):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

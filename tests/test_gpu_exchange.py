@@ -44,8 +44,10 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("exchange", ["native", "p2p"])
 @pytest.mark.parametrize("grid,shape,halo,nbatch,dt", CASES)
-def test_self_ring_native_exchange_equals_single_domain(grid, shape, halo, nbatch, dt):
+def test_self_ring_native_exchange_equals_single_domain(grid, shape, halo, nbatch, dt, exchange):
+    """exchange="p2p": the same ring of one rank through the mailbox / flag kernels of csrc/gcmf_p2p.hip (its neighbours' blocks are its own)."""
     vec = grid in T.VECTOR_GRIDS
     gv = T.vector_grid_vars(grid, shape) if vec else T.scalar_grid_vars(grid, shape)
     fields = [np.stack([T.random_field(shape, 7 + 10 * c + b) for b in range(nbatch)]) for c in range(2 if vec else 1)]
@@ -57,11 +59,11 @@ def test_self_ring_native_exchange_equals_single_domain(grid, shape, halo, nbatc
     dx = T.grid_dx_min(grid, gv) if O.DIMENSIONAL[grid] else 1.0
     fk = dict(filter_scale=6.0 * dx, dx_min=dx, filter_shape="GAUSSIAN")
     sf = SlabFilter(grid, gv, fk, shape[0], shape[1], halo=halo, dtype=np.dtype(dt), device=0, rank=0, world=1,
-                    self_ring=True, exchange="native")
+                    self_ring=True, exchange=exchange)
     sf.overlap = True
-    assert sf.exchange_kind == "native" and sf.halo == halo and sf.rows_alloc == shape[0] + 2 * halo
+    assert sf.exchange_kind == exchange and sf.halo == halo and sf.rows_alloc == shape[0] + 2 * halo
     got = [t.cpu().numpy() for t in sf.apply_local(sf.scatter_from_global(fields))]
-    assert sf.exchanges >= (sf.n_steps - 1) // halo
+    assert sf.exchanges >= (sf.n_steps - 1) // halo and not sf.p2p_timed_out()
     flt = Filter(filter_scale=fk["filter_scale"], dx_min=dx, grid_type=GridType[grid], grid_vars=gv)
     one = flt.apply_to_vector(*fields) if vec else (flt.apply(fields[0]),)
     for g, o in zip(got, one):
