@@ -254,8 +254,13 @@ def run_single(cfg, args, dev, steps, warmup, scale=0.0, levels=None, tuned=Fals
     d_in = [torch.from_numpy(f).to(dev) for f in wl["fields"]]
     run = (lambda: flt.apply_to_vector(d_in[0], d_in[1])) if len(d_in) == 2 else (lambda: (flt.apply(d_in[0]),))
     outs = None
+    t_w = time.perf_counter()
     for _ in range(warmup):
         outs = run()
+    torch.cuda.synchronize()
+    while time.perf_counter() - t_w < 0.05:   # (a GPU that idled while the host folded the plan needs tens of ms to clock up again)
+        outs = run()
+        torch.cuda.synchronize()
     plan.last_kernel()  # reset
     torch.cuda.synchronize()
     # The timed region: EXACTLY K applications, enqueued back to back with no host synchronisation between the applications of a
@@ -638,20 +643,40 @@ def main_multi(args, world, rank, local_rank):
         dist.init_process_group("nccl", device_id=dev)
     cpu_dev = "cpu" if share_gpu else dev
 
+    spread = {}
+
     def timed(fn, barrier=True):
+        """W warm-up applications (and at least 50 ms of them: a GPU that idled while the host folded plans takes tens of milliseconds
+        to clock up again -- a one-off 35 ms stall was seen in exactly this spot), then EXACTLY K applications timed as up to five
+        blocks, each bracketed by barrier + synchronize on both sides, MAX over ranks per block.  Returns K x the median block's time
+        per application (what `value` is computed from); min / max of the blocks go to `spread`."""
+        t_w = time.perf_counter()
         for _ in range(args.warmup):
             fn()
-        dist.barrier()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
+        while time.perf_counter() - t_w < 0.05:
             fn()
-        torch.cuda.synchronize()
-        dist.barrier()
-        el = time.perf_counter() - t0
-        tt = torch.tensor([el], device=cpu_dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return float(tt.item())
+            torch.cuda.synchronize()
+        nblocks = max(1, min(5, args.steps))
+        per_block = [args.steps // nblocks + (1 if b < args.steps % nblocks else 0) for b in range(nblocks)]
+        per_app = []
+        for nb_ in per_block:
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(nb_):
+                fn()
+            torch.cuda.synchronize()
+            dist.barrier()
+            el = time.perf_counter() - t0
+            tt = torch.tensor([el], device=cpu_dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            per_app.append(float(tt.item()) / nb_)
+        srt = sorted(per_app)
+        med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+        spread["last"] = {"blocks": nblocks, "applications_per_block": per_block, "ms_per_application_min": 1e3 * srt[0],
+                          "ms_per_application_max": 1e3 * srt[-1], "ms_per_application_median": 1e3 * med}
+        return med * args.steps
 
     failed = []
     cfg = args.config
@@ -672,6 +697,7 @@ def main_multi(args, world, rank, local_rank):
         def one():
             keep["o"] = flt.apply_to_vector(d_in[0], d_in[1]) if hi > lo else None
         elapsed = timed(one)
+        main_spread = dict(spread["last"])
         itemsize = wl["fields"][0].dtype.itemsize
         cells = nlev * args.ny * args.nx
         scaling, par = "strong", f"levels x{world} ({nlev} levels in all, {hi - lo} on rank 0; no communication)"
@@ -709,6 +735,7 @@ def main_multi(args, world, rank, local_rank):
 
         ny_global = args.ny * world if args.scaling == "weak" else args.ny
         wl, sf, outs, elapsed = measure(ny_global, args.scaling)
+        main_spread = dict(spread["last"])
         grid, fk, n_steps = wl["grid"], wl["fk"], sf.n_steps
         itemsize = wl["fields"][0].dtype.itemsize
         cells = ny_global * args.nx
@@ -765,6 +792,8 @@ def main_multi(args, world, rank, local_rank):
                                    + (f" x{args.nlev or 50} levels" if cfg == 5 else ""),
                        "filter": f"{fk['filter_shape']} filter_scale={fk['filter_scale']:.6g} dx_min={fk['dx_min']:.6g}",
                        "n_steps": n_steps, "global_grid": [ny_global, args.nx], "parallelism": par},
+            "timing": main_spread, "value_min": cells * n_steps / (main_spread["ms_per_application_max"] * 1e-3),
+            "value_max": cells * n_steps / (main_spread["ms_per_application_min"] * 1e-3),
             "parity": parity, "weak": weak, "exchange": exchange_rec if cfg not in (5, 6) else None, "cpu_baseline": None,
             "roofline": None if not launches else {
                 "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "kernel_ms_per_step_rank0": kernel_ms / args.steps,

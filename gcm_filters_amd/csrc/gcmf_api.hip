@@ -156,7 +156,10 @@ static int launch_ringc(gcmf_plan *pl, const MultiArgs &m, hipStream_t s) {
   switch (pl->kind) {
     case K_REG: return launch_ringc_reg(pl, m, s);
     case K_MASK: return launch_ringc_maskz(pl, m, s);
-    case K_FLUX: return launch_ringc_flux(pl, m, s);
+    case K_FLUX:
+      // a slab that owns no tripole seam: short strips, nothing has to fit beside the waves -> the early-exit form
+      if (!pl->full && !pl->g.fold && pl->d.dtype == GCMF_F64) return launch_ringc_flux_slab(pl, m, s);
+      return launch_ringc_flux(pl, m, s);
     default: break;
   }
   set_error("k_ringc: plan is not a scalar kind");

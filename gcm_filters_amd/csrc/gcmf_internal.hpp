@@ -201,6 +201,7 @@ bool ring_supported(const gcmf_plan *pl, const MultiArgs &a);
 int launch_ringc_reg(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_ringc_maskz(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_ringc_flux(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
+int launch_ringc_flux_slab(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);   // f64, slabs without a tripole seam: early exits (k_ringcs)
 int launch_flux_multi2(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_cgrid_stream(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 bool cgrid_stream_supported(const gcmf_plan *pl, const StepArgs &a);

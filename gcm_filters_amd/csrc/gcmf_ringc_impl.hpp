@@ -35,7 +35,8 @@ template <int VEC> __device__ __forceinline__ unsigned cell_bytes(const uint8_t 
 }
 
 // one march of a strip; returns whether this wave met a non-finite value in its last level (wave-uniform)
-template <typename T, int KIND, int S, bool FIRST, bool SANI>
+// XE: early exits also for the flux kinds (k_ringcs: slabs that do not own a tripole seam, see below)
+template <typename T, int KIND, int S, bool FIRST, bool SANI, bool XE = false>
 __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int W = 64 * VEC;
@@ -312,7 +313,7 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
   static_assert(D == 3, "prologue");
   // The flux kinds march whole periods: every early exit costs this kernel dozens of registers (146 -> 204 AGPRs with an exit
   // every four rows), and on tripolar plans k_fold_band's waves have to fit on the SIMDs NEXT to these (gcmf_foldband.hip).
-  constexpr bool EARLY = (KIND != K_FLUX);
+  constexpr bool EARLY = (KIND != K_FLUX) || XE;
   for (int r0 = r_begin;; r0 += R) {
     bool done = true;
     do {
@@ -352,7 +353,22 @@ __global__ __launch_bounds__(256, 1) void k_ringc(const MultiP<T, T> P) {
   }
 }
 
-template <typename T, int KIND, int S, bool FIRST>
+// The flux kinds with early exits: for ROW SLABS that own no tripole seam (the ranks of a multi-GPU run, the row blocks of the host
+// pipeline).  Their strips are short -- 300 rows of an 8-way slab: 11 + 2 S rows per strip -- so rows up to the next whole ring period
+// are a third of the march, and nothing has to fit beside these waves (the extra ~60 registers of the exits are free here).
+template <typename T, int S, bool FIRST>
+__global__ __launch_bounds__(256, 1) void k_ringcs(const MultiP<T, T> P) {
+  int bx = blockIdx.x;
+  if (P.xcd_per > 0 && bx < 8 * P.xcd_per) bx = (bx & 7) * P.xcd_per + (bx >> 3);
+  const int wid = bx * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wid >= P.nwaves) return;
+  if (ringc_march<T, K_FLUX, S, FIRST, false, true>(P, wid)) {
+    if (P.nfb && (threadIdx.x & 63) == 0) atomicAdd(P.nfb, 1u);
+    ringc_march<T, K_FLUX, S, FIRST, true, true>(P, wid);
+  }
+}
+
+template <typename T, int KIND, int S, bool FIRST, bool XE = false>
 static int launch_ringc_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int W = 64 * VEC;
@@ -393,7 +409,7 @@ static int launch_ringc_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
     if (want < 1) want = 1;
     H = (int)((nrows + want - 1) / want);
     if (H < 4) H = 4;   // (short strips for small grids: see k_ring)
-    if (KIND == K_FLUX) H += (R - (H + 2 * S) % R) % R;   // whole periods (no early exit here): let the padding carry real rows
+    if (KIND == K_FLUX && !XE) H += (R - (H + 2 * S) % R) % R;   // whole periods (no early exit here): let the padding carry real rows
   }
   if (H > nrows) H = nrows;
   P.H = H;
@@ -409,6 +425,13 @@ static int launch_ringc_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   P.c = a.c;
   dim3 block(256), grid((P.nwaves + 3) / 4, (unsigned)a.nbatch);
   P.xcd_per = pl->xcd_remap ? (int)(grid.x / 8) : 0;
+  if constexpr (XE) {
+    hipLaunchKernelGGL((k_ringcs<T, S, FIRST>), grid, block, 0, s, P);
+    GCMF_HIP(hipGetLastError());
+    note_kernel(pl, std::string("gcmf::k_ringcs<") + tyname<T>() + ", " + std::to_string(S) + ", " + (FIRST ? "true" : "false") + ">", S,
+                launch_geom(P.H, P.nstrips, P.nwx, P.xcd_per > 0, grid.x, grid.y, nrows));
+    return GCMF_OK;
+  }
   hipLaunchKernelGGL((k_ringc<T, KIND, S, FIRST>), grid, block, 0, s, P);
   GCMF_HIP(hipGetLastError());
   note_kernel(pl, std::string("gcmf::k_ringc<") + tyname<T>() + ", " + std::to_string(KIND) + ", " + std::to_string(S) + ", " +

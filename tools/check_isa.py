@@ -160,7 +160,7 @@ def main():
         names = demangle([k["name"] for k in kernels])
         for k, d in zip(kernels, names):
             k["dname"] = d.replace("void ", "").split("(")[0]
-        watched = [k for k in kernels if re.search(r"gcmf::k_(ring|ringc|fold_band|cgrid_stream2c?|bgrid_stream2)<", k["dname"])]
+        watched = [k for k in kernels if re.search(r"gcmf::k_(ring|ringc|ringcs|fold_band|cgrid_stream2c?|bgrid_stream2)<", k["dname"])]
         for k in sorted(watched, key=lambda k: k["dname"]):
             total = k["vgpr"]   # gfx90a and later: .vgpr_count is the unified total (architected + accumulation registers)
             alloc = (total + 7) // 8 * 8
@@ -172,15 +172,15 @@ def main():
                 failures.append(f"{k['dname']}: {alloc} registers > {BAND_BUDGET}: its waves no longer fit beside a k_ringc wave")
             if re.search(r"k_ringc<(double|float), 2,", k["dname"]) and alloc > RING_FLUX_BUDGET:
                 failures.append(f"{k['dname']}: {alloc} registers > {RING_FLUX_BUDGET}: no room for k_fold_band's waves on its SIMD (tripolar plans)")
-            if re.search(r"k_ringc?<", k["dname"]) and alloc > 512:
+            if re.search(r"k_ringc?s?<", k["dname"]) and alloc > 512:
                 failures.append(f"{k['dname']}: {alloc} registers > 512")
-        n_ring = sum(1 for k in watched if re.search(r"k_ringc?<", k["dname"]))
+        n_ring = sum(1 for k in watched if re.search(r"k_ringc?s?<", k["dname"]))
         n_band = sum(1 for k in watched if "k_fold_band<" in k["dname"])
         print(f"{len(kernels)} gfx950 kernels, {n_ring} k_ring / k_ringc and {n_band} k_fold_band instantiations checked for scratch and register budgets")
         if n_ring < 20 or n_band < 6:
             failures.append("fewer ring / band kernels found than the library instantiates: the metadata parser is out of date")
         if args.waitcnt or args.waitcnt_only:
-            todo = [k for k in watched if re.search(r"k_(ring|ringc|fold_band)<", k["dname"]) and args.waitcnt_only in k["dname"]]
+            todo = [k for k in watched if re.search(r"k_(ring|ringc|ringcs|fold_band)<", k["dname"]) and args.waitcnt_only in k["dname"]]
             for k in todo:
                 bad, nl, nw = check_waitcnt(k["path"], k["name"])
                 if args.v or bad:
