@@ -887,8 +887,10 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
         if ((rc = ensure_dev_p(pl, p, n_steps, s))) return rc;
         if ((rc = launch_land_fix(pl, din[0], dout[0], pl->dev_p, n_steps, c, fb32 ? 1 : 0, nbatch, s))) return rc;
       }
-    } else if (use_vmulti && pl->kind == K_CGRID && pl->clenshaw >= 1 && !fwd_only && n_steps >= 2 && vec_multi_supported(pl, nbatch, 2)) {
-      // C-grid, batched levels: the polynomial evaluated backwards (k_cgrid_stream2c): state (b_{k+1}, b_{k+2}) in a pool of four
+    } else if (use_vmulti && ((pl->kind == K_CGRID && pl->clenshaw >= 1) || (pl->kind == K_BGRID && pl->clenshaw >= 2)) && !fwd_only &&
+               n_steps >= 2 && vec_multi_supported(pl, nbatch, 2)) {
+      // C-grid (B-grid with GCMF_CLENSHAW=2: it is bit-exact with numpy forward, so backward is an option there like for the land-mask
+      // kinds): the polynomial evaluated backwards (k_cgrid_stream2c / k_bgrid_stream2c): state (b_{k+1}, b_{k+2}) in a pool of four
       // plane pairs, the constant input (u, v) read by every launch, no fbar planes.  Level l = 1..n uses p[n - l]; the first
       // launch forms b_n = p[n] f as it loads f, the last one writes the result.
       const void *u[2] = {x0[0], x0[1]}, *v[2] = {nullptr, nullptr};

@@ -9,7 +9,13 @@
 // A pass reads T_{k-1}, T_{k-2}, fbar and 1/4 of the coefficient rows and writes T_{k+S-1}, T_{k+S-2}, fbar:
 // 8w + 4f + 8w/4 bytes per cell.level whatever S is.  Batches that do not fill the 4 levels are padded with shadow waves.
 // Per level the summation order is the reference's, term by term: bit-identical to S single steps and to numpy.
+//
+// CLEN (round 3, opt-in with GCMF_CLENSHAW=2 like the other grid types that are bit-exact with numpy forward): the polynomial evaluated
+// backwards, b_k = p_k f + 2 A(b_{k+1}) - b_{k+2} (gcmf_ringc_impl.hpp) -- the conveyor that carries fbar from level to level carries the
+// row of the constant input instead, nothing is accumulated, only the last launch writes a result: 4w + 2w (+ coefficients) read and 4w
+// written per cell and level instead of 4w + 2f / 4w + 2f, every multiply-add pair one fma.  Not bit-identical with numpy (<= 1e-14).
 #include "gcmf_multi_common.hpp"
+#include "gcmf_recurrence.hpp"
 #include <cstdlib>
 
 namespace gcmf {
@@ -26,6 +32,9 @@ template <typename T, typename FB> struct BStream2P {
   int H, nwx, ngroups, nlev, nlev4, wrap, first, last;
   long long bstride;
   double p0, pk[6], c;
+  // backward (Clenshaw) evaluation: fu_in / fv_in = the constant input fields, p0 = p_n (first launch); last launch: the result goes
+  // to du_out / dv_out as f64 (f32 state, default output) or to fu_out / fv_out (state dtype)
+  double *du_out, *dv_out;
 };
 
 template <typename T> __device__ __forceinline__ T b2san(T x) {
@@ -75,8 +84,9 @@ template <typename T, int VEC> struct BgLevel {
 // PRIV (single-level fields): one-wave workgroups, each an independent (window, strip) group; the wave fetches all 8
 // coefficient rows itself, level 1 uses them straight from registers and levels 2..S read them back from the wave's own
 // LDS ring of S-1 slots, refilled at the end of the iteration (no barrier, no shadow waves).
-template <typename T, typename FB, int VEC, int S, int D, bool PRIV>
-__global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) == 8 && (S > 3 || (PRIV && S > 2)) ? 1 : 2)) void k_bgrid_stream2(const BStream2P<T, FB> P) {
+template <typename T, typename FB, int VEC, int S, int D, bool PRIV, bool CLEN>
+__device__ __forceinline__ void bgrid_stream2_body(const BStream2P<T, FB> &P) {
+  static_assert(!CLEN || std::is_same<FB, T>::value, "backward evaluation: the conveyor has the state's type");
   constexpr int M = (S + VEC - 1) / VEC * VEC;
   constexpr int W = 64 * VEC, WI = W - 2 * M;
   constexpr int NS = PRIV ? S - 1 : S + 1;
@@ -131,6 +141,8 @@ __global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) == 8 && (S > 3 || (PR
     if (!first) {
       mload<T, VEC>(x.up, P.up + boff + rc);
       mload<T, VEC>(x.vp, P.vp + boff + rc);
+    }
+    if (!first || CLEN) {   // fbar -- or, backward evaluation, the row of the constant input
       mload<FB, VEC>(x.fu, P.fu_in + boff + rc);
       mload<FB, VEC>(x.fv, P.fv_in + boff + rc);
     }
@@ -176,7 +188,11 @@ __global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) == 8 && (S > 3 || (PR
     T cu[S + 1][VEC], cv[S + 1][VEC];  // newest row of every level this iteration
     FB nau[S + 1][VEC], nav[S + 1][VEC];
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) { cu[0][k] = x.u[k]; cv[0][k] = x.v[k]; }
+    for (int k = 0; k < VEC; ++k) {
+      // (backward evaluation, first launch: the delivered rows of f become rows of b_n = p_n f)
+      cu[0][k] = (CLEN && first) ? (T)P.p0 * x.u[k] : x.u[k];
+      cv[0][k] = (CLEN && first) ? (T)P.p0 * x.v[k] : x.v[k];
+    }
 
 #pragma unroll
     for (int j = 1; j <= S; ++j) {
@@ -206,7 +222,18 @@ __global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) == 8 && (S > 3 || (PR
       for (int k = 0; k < VEC; ++k) {
         const T xu = o1u[j - 1][k], xv = o1v[j - 1][k];
         const T avu = -xu - c * lu[k], avv = -xv - c * lv[k];
-        if (j == 1 && first) {
+        if constexpr (CLEN) {
+          const T x2u = (j == 1) ? (first ? T(0) : x.up[k]) : o2u[j >= 2 ? j - 2 : 0][k];
+          const T x2v = (j == 1) ? (first ? T(0) : x.vp[k]) : o2v[j >= 2 ? j - 2 : 0][k];
+          const T fiu = (T)((j == 1) ? x.fu[k] : accu[j - 1][k]);
+          const T fiv = (T)((j == 1) ? x.fv[k] : accv[j - 1][k]);
+          const T two = (last && j == S) ? T(1) : T(2);  // the last level of the last launch is the result: A, not 2 A
+          const T afu = rfma(-c, lu[k], -xu), afv = rfma(-c, lv[k], -xv);
+          cu[j][k] = rfma((T)pkj, fiu, rfma(two, afu, -x2u));
+          cv[j][k] = rfma((T)pkj, fiv, rfma(two, afv, -x2v));
+          nau[j][k] = (FB)fiu;   // the row of f travels on with its row of the state
+          nav[j][k] = (FB)fiv;
+        } else if (j == 1 && first) {
           cu[j][k] = avu;
           cv[j][k] = avv;
           if (std::is_same<FB, T>::value) {
@@ -238,9 +265,23 @@ __global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) == 8 && (S > 3 || (PR
           mstore<T, VEC>((j == S ? P.u2o : P.u1o) + off, cu[j]);
           mstore<T, VEC>((j == S ? P.v2o : P.v1o) + off, cv[j]);
         }
-        if (j == S) {
+        if (j == S && !CLEN) {
           mstore<FB, VEC>(P.fu_out + off, nau[j]);
           mstore<FB, VEC>(P.fv_out + off, nav[j]);
+        }
+        if (CLEN && j == S && last) {
+          if (P.du_out) {  // wave-uniform: f64 result from f32 state
+            double dd[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) dd[k] = (double)cu[j][k];
+            mstore<double, VEC>(P.du_out + off, dd);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) dd[k] = (double)cv[j][k];
+            mstore<double, VEC>(P.dv_out + off, dd);
+          } else {
+            mstore<T, VEC>(reinterpret_cast<T *>(P.fu_out) + off, cu[j]);
+            mstore<T, VEC>(reinterpret_cast<T *>(P.fv_out) + off, cv[j]);
+          }
         }
       }
     }
@@ -288,6 +329,15 @@ __global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) == 8 && (S > 3 || (PR
   }
 }
 
+template <typename T, typename FB, int VEC, int S, int D, bool PRIV>
+__global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) == 8 && (S > 3 || (PRIV && S > 2)) ? 1 : 2)) void k_bgrid_stream2(const BStream2P<T, FB> P) {
+  bgrid_stream2_body<T, FB, VEC, S, D, PRIV, false>(P);
+}
+template <typename T, int VEC, int S, int D, bool PRIV>
+__global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) == 8 && (S > 3 || (PRIV && S > 2)) ? 1 : 2)) void k_bgrid_stream2c(const BStream2P<T, T> P) {
+  bgrid_stream2_body<T, T, VEC, S, D, PRIV, true>(P);
+}
+
 static bool b2al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 bool bgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
@@ -300,7 +350,7 @@ bool bgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
   return true;
 }
 
-template <typename T, typename FB, int VEC, int S, int D, bool PRIV> static int launch_b2(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
+template <typename T, typename FB, int VEC, int S, int D, bool PRIV, bool CLEN = false> static int launch_b2(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
   constexpr int M = (S + VEC - 1) / VEC * VEC, W = 64 * VEC, WI = W - 2 * M;
   const Geom &g = pl->g;
   BStream2P<T, FB> P;
@@ -310,6 +360,11 @@ template <typename T, typename FB, int VEC, int S, int D, bool PRIV> static int 
   P.u1o = (T *)a.u1o[0];  P.v1o = (T *)a.u1o[1];
   P.u2o = (T *)a.u2o[0];  P.v2o = (T *)a.u2o[1];
   P.fu_out = (FB *)a.fb_out[0];  P.fv_out = (FB *)a.fb_out[1];
+  P.du_out = P.dv_out = nullptr;
+  if (CLEN && a.last && sizeof(T) == 4 && !a.fb_is_f32) {  // f32 state, f64 result (NumPy >= 2 promotion of the reference)
+    P.du_out = (double *)a.fb_out[0];
+    P.dv_out = (double *)a.fb_out[1];
+  }
   for (int k = 0; k < 8; ++k) P.coef[k] = (const T *)g.coef[k];
   P.nx = g.nx;
   P.rows = g.rows;
@@ -350,6 +405,13 @@ template <typename T, typename FB, int VEC, int S, int D, bool PRIV> static int 
   const long long blocks_per_xcd = PRIV ? groups_per_xcd * P.nlev : (groups_per_xcd * P.nlev4 + 3) / 4;
   dim3 block(PRIV ? 64 : 256), grid((unsigned)(blocks_per_xcd * 8));
   const size_t lds = (size_t)(PRIV ? S - 1 : S + 1) * 8 * 64 * sizeof(MPack<T, VEC>);
+  if constexpr (CLEN) {
+    hipLaunchKernelGGL((k_bgrid_stream2c<T, VEC, S, D, PRIV>), grid, block, lds, s, P);
+    note_kernel(pl, std::string("gcmf::k_bgrid_stream2c<") + tyname<T>() + ", " + std::to_string(VEC) + ", " + std::to_string(S) + ", " +
+                        std::to_string(D) + ", " + (PRIV ? "true" : "false") + ">", S);
+    GCMF_HIP(hipGetLastError());
+    return GCMF_OK;
+  }
   hipLaunchKernelGGL((k_bgrid_stream2<T, FB, VEC, S, D, PRIV>), grid, block, lds, s, P);
   note_kernel(pl, std::string("gcmf::k_bgrid_stream2<") + tyname<T>() + ", " + tyname<FB>() + ", " + std::to_string(VEC) + ", " +
                       std::to_string(S) + ", " + std::to_string(D) + ", " + (PRIV ? "true" : "false") + ">", S);
@@ -366,6 +428,24 @@ template <typename T, typename FB, int S, int DMAX> static int launch_b2_sel(gcm
 }
 
 int launch_bgrid_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
+  if (a.clen) {  // backward evaluation (opt-in): the conveyor has the state's type; single-level fields: private coefficient rings
+    static const bool priv_ok = !(getenv("GCMF_VEC_PRIV") && atoi(getenv("GCMF_VEC_PRIV")) == 0);
+    const bool priv = a.nbatch == 1 && priv_ok;
+    if (pl->d.dtype == GCMF_F64) {
+      switch (a.S) {
+        case 2: return priv ? launch_b2<double, double, 2, 2, 1, true, true>(pl, a, s) : launch_b2<double, double, 2, 2, 2, false, true>(pl, a, s);
+        case 3: return priv ? launch_b2<double, double, 2, 3, 1, true, true>(pl, a, s) : launch_b2<double, double, 2, 3, 1, false, true>(pl, a, s);
+        case 4: return priv ? launch_b2<double, double, 2, 4, 1, true, true>(pl, a, s) : launch_b2<double, double, 2, 4, 2, false, true>(pl, a, s);
+      }
+      return GCMF_ERR_INVALID_ARG;
+    }
+    switch (a.S) {
+      case 2: return priv ? launch_b2<float, float, 2, 2, 1, true, true>(pl, a, s) : launch_b2<float, float, 2, 2, 2, false, true>(pl, a, s);
+      case 3: return priv ? launch_b2<float, float, 2, 3, 1, true, true>(pl, a, s) : launch_b2<float, float, 2, 3, 2, false, true>(pl, a, s);
+      case 4: return priv ? launch_b2<float, float, 2, 4, 1, true, true>(pl, a, s) : launch_b2<float, float, 2, 4, 2, false, true>(pl, a, s);
+    }
+    return GCMF_ERR_INVALID_ARG;
+  }
   if (pl->d.dtype == GCMF_F64) {
     switch (a.S) {
       case 2: return launch_b2_sel<double, double, 2, 2>(pl, a, s);

@@ -286,3 +286,44 @@ def test_f32_flux_kinds_backward_evaluation(grid, n_steps, kwargs):
         assert nfb > 0
     elif not (grid.startswith("MOM5") and kwargs.get("nanland")):
         assert nfb == 0
+
+
+@pytest.mark.parametrize("dt,nlev,n_steps", [("f8", 1, 11), ("f8", 4, 16), ("f8", 7, 23), ("f4", 1, 9), ("f4", 5, 16), ("f4", 12, 21)])
+def test_bgrid_backward_evaluation_is_an_option(dt, nlev, n_steps):
+    """VECTOR_B_GRID (reference kernels.py:702-840) is bit-exact with numpy on the forward recurrence, which therefore stays its default;
+    GCMF_CLENSHAW=2 / set_tuning(clenshaw=2) evaluates it backwards too (k_bgrid_stream2c: no fbar planes, fused multiply-adds) --
+    against the oracle in f64 arithmetic <= 1e-12 (f32 state: the 1e-4 gate), f64 result dtype, NaN pattern, batch == single level."""
+    import warnings
+    shape = (96, 160)
+    gv = {k: v.astype(dt) for k, v in T.vector_grid_vars("VECTOR_B_GRID", shape).items()}
+    u = np.stack([T.random_field(shape, 42 + 2 * l).astype(dt) for l in range(nlev)])
+    v = np.stack([T.random_field(shape, 43 + 2 * l).astype(dt) for l in range(nlev)])
+    u[nlev // 2, 5, 7] = np.nan
+    dx = T.grid_dx_min("VECTOR_B_GRID", gv)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        flt = Filter(filter_scale=10 * dx, dx_min=dx, n_steps=n_steps, grid_type=GridType.VECTOR_B_GRID, grid_vars=gv)
+    fs = flt.filter_spec
+    spec = O.FilterSpec(fs.n_steps, fs.s_max, np.asarray(fs.p), fs.dx_min_sq)
+    with np.errstate(all="ignore"):
+        wu, wv = O.filter_func_vec(spec, "VECTOR_B_GRID", u.astype("f8"), v.astype("f8"), {k: x.astype("f8") for k, x in gv.items()})
+        ru, rv = O.filter_func_vec(spec, "VECTOR_B_GRID", u, v, gv)          # the reference's own path for this dtype
+    plan = ALL_KERNELS[GridType.VECTOR_B_GRID](**gv)._plan(_lib.dtype_code(dt), shape)
+    fu, fv = flt.apply_to_vector(u, v)                                        # default: forward, bit-exact with numpy
+    assert "k_bgrid_stream2<" in plan.last_kernel()
+    assert np.array_equal(fu, ru, equal_nan=True) and np.array_equal(fv, rv, equal_nan=True)
+    try:
+        plan.set_tuning(multi_s=8, clenshaw=2)
+        gu, gw = flt.apply_to_vector(u, v)
+        assert "k_bgrid_stream2c<" in plan.last_kernel(), plan.last_kernel()
+        if nlev > 1:
+            l = nlev - 1
+            a1, b1 = flt.apply_to_vector(u[l:l + 1], v[l:l + 1])
+            assert np.array_equal(a1[0], gu[l], equal_nan=True) and np.array_equal(b1[0], gw[l], equal_nan=True)
+    finally:
+        plan.set_tuning(multi_s=8, clenshaw=1)
+    assert gu.dtype == np.float64 and gw.dtype == np.float64
+    tol = 1e-4 if dt == "f4" else 1e-12
+    for g, w in ((gu, wu), (gw, wv)):
+        assert np.array_equal(np.isnan(g), np.isnan(w))
+        assert np.nanmax(np.abs(g - w)) <= tol * np.nanmax(np.abs(w))
