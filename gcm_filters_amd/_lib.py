@@ -32,7 +32,7 @@ EXPORTS = [
     "gcmf_has_land", "gcmf_zero_land", "gcmf_land_fix", "gcmf_last_kernel", "gcmf_last_kernel_timing", "gcmf_ring_fallbacks", "gcmf_clenshaw_cut",
     "gcmf_comm_unique_id", "gcmf_comm_create", "gcmf_comm_destroy", "gcmf_halo_start", "gcmf_halo_finish",
     "gcmf_build_id", "gcmf_last_kernel_geometry",
-    "gcmf_p2p_create", "gcmf_p2p_export", "gcmf_p2p_connect", "gcmf_p2p_start", "gcmf_p2p_finish", "gcmf_p2p_status", "gcmf_p2p_destroy",
+    "gcmf_slab_apply_backward", "gcmf_p2p_create", "gcmf_p2p_export", "gcmf_p2p_connect", "gcmf_p2p_start", "gcmf_p2p_finish", "gcmf_p2p_status", "gcmf_p2p_destroy",
 ]
 PLAN_SELF_RING, PLAN_SKIP_KAPPA_ONE = 0x1, 0x2
 
@@ -141,6 +141,9 @@ def load() -> C.CDLL:
         lib.gcmf_halo_start.restype = C.c_int
         lib.gcmf_halo_finish.argtypes = [vp, vp]
         lib.gcmf_halo_finish.restype = C.c_int
+        lib.gcmf_slab_apply_backward.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_double,
+                                                 C.POINTER(C.c_int), C.c_int, vp, vpp, vp, C.c_int64, C.c_int, C.c_int, C.c_uint32, vp]
+        lib.gcmf_slab_apply_backward.restype = C.c_int
         lib.gcmf_p2p_create.argtypes = [C.c_int, C.c_int64, vpp]
         lib.gcmf_p2p_create.restype = C.c_int
         lib.gcmf_p2p_export.argtypes = [vp, C.c_char_p]
@@ -290,6 +293,17 @@ class Plan:
                                      pk.ctypes.data_as(C.POINTER(C.c_double)), len(pk), float(p0), float(c), int(mode),
                                      OUT_F32 if out_f32 else 0, int(nbatch), int(row_lo), int(row_hi),
                                      C.c_void_p(stream or None)))
+
+    def slab_apply_backward(self, comm, p2p, south, north, p, c, cut, X, pool, out, nbatch, halo, overlap, *, out_f32=False, stream=0):
+        """One whole backward (Clenshaw) application on this slab incl. its halo exchanges, enqueued by libgcmf in one call
+        (gcmf_slab_apply_backward).  comm / p2p: a Comm / P2P object or None; X / out: device pointers, pool: four of them."""
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        cut = (C.c_int * len(cut))(*[int(x) for x in cut])
+        check(load().gcmf_slab_apply_backward(
+            self._h, None if comm is None else comm._h, None if p2p is None else p2p._h, -1 if south is None else int(south),
+            -1 if north is None else int(north), p.ctypes.data_as(C.POINTER(C.c_double)), len(p) - 1, float(c), cut, len(cut),
+            C.c_void_p(X), _ptr_array(pool), C.c_void_p(out), int(nbatch), int(halo), int(bool(overlap)), OUT_F32 if out_f32 else 0,
+            C.c_void_p(stream or None)))
 
     def clenshaw_cut(self, n_steps: int):
         """Launch depths of the backward evaluation gcmf_apply uses for this polynomial length ([] = forward recurrence)."""

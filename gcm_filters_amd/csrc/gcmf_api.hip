@@ -692,6 +692,107 @@ int gcmf_land_fix(gcmf_plan *pl, const double *p, int n_steps, double c, const v
   return launch_land_fix(pl, in[0], out[0], pl->dev_p, n_steps, c, fb32, nbatch, (hipStream_t)stream);
 }
 
+// One whole filter application on this rank's slab, backward (Clenshaw) evaluation, scalar kinds: the choreography of
+// gcm_filters_amd/distributed.py (SlabFilter._apply_backward) in C++ -- launches, ghost-zone bookkeeping, the overlapped edge / interior
+// split and the halo exchanges through a gcmf_comm (RCCL) or a gcmf_p2p (mailboxes) -- enqueued on `stream` in ONE call.  The Python
+// driver costs ~15 us of host time per launch and 13-33 us per exchange: 0.25-0.35 ms per application, more than the 0.25 ms an
+// 8-way slab of a 2400x3600 grid computes, so a multi-GPU run was bound by its host.
+//   X     the input with its own rows filled in (ghost rows are exchanged here), (nbatch, rows_alloc, nx)
+//   pool  four state planes, out  the result (f64, or the state dtype with GCMF_OUT_F32); all (nbatch, rows_alloc, nx)
+//   cut   the launch depths (gcmf_clenshaw_cut), halo  ghost rows per side (>= the deepest launch), south / north  peer ranks or -1
+//   comm / p2p: at most one non-NULL (both NULL: a single slab without neighbours)
+int gcmf_slab_apply_backward(gcmf_plan *pl, gcmf_comm *comm, gcmf_p2p *p2p, int south, int north, const double *p, int n_steps, double c,
+                             const int *cut, int ncut, void *X, void *const *pool, void *out, int64_t nbatch, int halo, int overlap,
+                             uint32_t flags, void *stream) {
+  if (!pl || !p || !cut || ncut < 1 || !X || !pool || !out || nbatch < 1 || pl->ncomp != 1) {
+    set_error("gcmf_slab_apply_backward: bad argument");
+    return GCMF_ERR_INVALID_ARG;
+  }
+  int total = 0, deepest = 0;
+  for (int q = 0; q < ncut; ++q) { total += cut[q]; deepest = std::max(deepest, cut[q]); }
+  const bool multi = (south >= 0 || north >= 0);
+  if (total != n_steps || (multi && (halo < deepest || !(comm || p2p))) || (comm && p2p)) {
+    set_error("gcmf_slab_apply_backward: the cut does not add up to n_steps, the halo is shallower than a launch, or no exchange was given");
+    return GCMF_ERR_INVALID_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t fo = pl->first_owned, ro = pl->rows_owned, ra = pl->rows_alloc;
+  const bool gs = fo > 0, gn = ra - fo - ro > 0;
+  const int hs = multi ? halo : 0;
+  const int dtype = pl->d.dtype;
+  const int nx = (int)pl->d.nx;
+  auto exchange_start = [&](void *const *st, int nst) -> int {
+    if (!multi) return GCMF_OK;
+    if (p2p) return gcmf_p2p_start(p2p, st, nst, nbatch, ra, nx, fo, ro, hs, dtype, stream);
+    return gcmf_halo_start(comm, st, nst, nbatch, ra, nx, fo, ro, hs, dtype, south, north, stream);
+  };
+  auto exchange_finish = [&]() -> int {
+    if (!multi) return GCMF_OK;
+    return p2p ? gcmf_p2p_finish(p2p, stream) : gcmf_halo_finish(comm, stream);
+  };
+  int rc;
+  {  // f's ghost rows: the first launch forms b_n = p_n f on them, the later ones read f on the rows they compute
+    void *st[1] = {X};
+    if ((rc = exchange_start(st, 1)) || (rc = exchange_finish())) return rc;
+  }
+  const bool fb32 = (dtype == GCMF_F32) && (flags & GCMF_OUT_F32);
+  void *u = nullptr, *v = nullptr;
+  int valid = hs, lvl = 1;
+  for (int q = 0; q < ncut; ++q) {
+    const int S = cut[q];
+    if (multi && valid < S) {
+      void *st[2] = {u, v};
+      if ((rc = exchange_start(st, 2)) || (rc = exchange_finish())) return rc;
+      valid = hs;
+    }
+    void *fr[2] = {nullptr, nullptr};
+    int nf = 0;
+    for (int k = 0; k < 4 && nf < 2; ++k)
+      if (pool[k] != u && pool[k] != v) fr[nf++] = pool[k];
+    int v_out = multi ? valid - S : 0;
+    const int lo = (int)(fo - (gs ? v_out : 0)), hi = (int)(fo + ro + (gn ? v_out : 0));
+    const bool last = (q == ncut - 1);
+    MultiArgs m{};
+    m.u0 = u; m.v0 = v; m.uo = fr[0]; m.vo = fr[1]; m.fb_in = X; m.fb_out = out;
+    for (int t = 0; t < S; ++t) m.pk[t] = p[n_steps - (lvl + t)];
+    m.p0 = p[n_steps]; m.c = c; m.S = S; m.first = (q == 0); m.last = last; m.nbatch = nbatch; m.fb_is_f32 = fb32 ? 1 : 0;
+    const int nxt = last ? 0 : cut[q + 1];
+    const bool ovl = overlap && multi && !last && v_out < nxt && ro >= 4 * (int64_t)hs;
+    auto launch = [&](int r0, int r1) -> int {
+      if (r1 <= r0) return GCMF_OK;
+      std::lock_guard<std::mutex> lk(pl->mu);
+      GCMF_HIP(hipSetDevice(pl->d.device));
+      MultiArgs mm = m;
+      mm.row_lo = r0; mm.row_hi = r1;
+      return advance_multi(pl, mm, s, nullptr, true);
+    };
+    if (ovl) {
+      // the next launch needs fresh ghost rows: advance the rows the neighbours need first, post the exchange of the NEW state, and
+      // let the interior rows run while the messages are in flight (the edge launches reach to the inner end of what is sent)
+      const int ilo = gs ? (int)(fo + hs) : lo, ihi = gn ? (int)(fo + ro - hs) : hi;
+      if (gs && (rc = launch(lo, ilo))) return rc;
+      if (gn && (rc = launch(ihi, hi))) return rc;
+      void *st[2] = {fr[0], fr[1]};
+      if ((rc = exchange_start(st, 2))) return rc;
+      if ((rc = launch(ilo, ihi))) return rc;
+      if ((rc = exchange_finish())) return rc;
+      v_out = hs;
+    } else if ((rc = launch(lo, hi))) {
+      return rc;
+    }
+    u = fr[0]; v = fr[1];
+    valid = v_out;
+    lvl += S;
+  }
+  if (land_ok(pl, n_steps)) {
+    std::lock_guard<std::mutex> lk(pl->mu);
+    GCMF_HIP(hipSetDevice(pl->d.device));
+    if ((rc = ensure_dev_p(pl, p, n_steps, s))) return rc;
+    if ((rc = launch_land_fix(pl, X, out, pl->dev_p, n_steps, c, fb32 ? 1 : 0, nbatch, s))) return rc;
+  }
+  return GCMF_OK;
+}
+
 int gcmf_prepare(gcmf_plan *pl, const void *const *in, void *const *out, int64_t nbatch, int64_t row_lo,
                  int64_t row_hi, void *stream) {
   if (!pl || !in || !out) return GCMF_ERR_INVALID_ARG;

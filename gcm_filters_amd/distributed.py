@@ -231,6 +231,9 @@ class SlabFilter:
         # edge strips + interior costs two small launches that march 2S warm-up rows for `halo` useful ones (~35 us
         # each); worth it only when the interior is long enough to hide an exchange behind (tall slabs)
         self.overlap = self.rows_owned >= 1000
+        # backward scalar applications with a library-issued exchange ("native" RCCL or "p2p"): the whole choreography in ONE call into
+        # libgcmf (gcmf_slab_apply_backward) instead of a Python loop of C calls
+        self.native_driver = True
 
     # -- data movement helpers -----------------------------------------------------------------
     def scatter_from_global(self, fields: Sequence[np.ndarray]):
@@ -403,6 +406,43 @@ class SlabFilter:
             self.kernel_launches += sum(n for _, _, n in self._pending_events)
             self._pending_events = []
 
+    def _apply_backward_native(self, cut, st, p, nbatch):
+        """The same application in ONE call into libgcmf (gcmf_slab_apply_backward: the choreography below in C++, exchanges through the
+        library's own gcmf_comm / gcmf_p2p): ~30 us of host time instead of 250-350."""
+        t = self.torch
+        X, O = st["X"], st["O"]
+        if self.exchange_kind == "p2p" and self.multi:
+            self._p2p_ready(2 * nbatch * self.halo * self.nx * X.element_size())
+        if self.time_kernels:
+            e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+            e0.record()
+        self.engine.plan.slab_apply_backward(
+            self.comm if self.exchange_kind == "native" else None, self.p2p if self.exchange_kind == "p2p" else None,
+            self.south, self.north, p, self.c, cut, X[0].data_ptr(), [st[k][0].data_ptr() for k in "ABCD"], O[0].data_ptr(), nbatch,
+            self.halo, self.overlap, stream=t.cuda.current_stream().cuda_stream)
+        if self.multi:
+            self.exchanges += 1 + sum(1 for _ in self._exchange_points(cut))
+        if self.time_kernels:
+            e1.record()
+            self._pending_events.append((e0, e1, len(cut)))
+        fo, ro = self.first_owned, self.rows_owned
+        return [O[0][:, fo: fo + ro, :]]
+
+    def _exchange_points(self, cut):
+        """Launches of a backward application that are followed (or preceded) by an exchange of the state: the bookkeeping of
+        _apply_backward without the launches (for the `exchanges` counter)."""
+        s, valid = self.halo, self.halo
+        for q, S in enumerate(cut):
+            if valid < S:
+                yield q
+                valid = s
+            v_out = valid - S
+            nxt = cut[q + 1] if q + 1 < len(cut) else 0
+            if self.overlap and q + 1 < len(cut) and v_out < nxt and self.rows_owned >= 4 * s:
+                yield q
+                v_out = s
+            valid = v_out
+
     def _apply_backward(self, cut, st, p, nbatch):
         """The backward (Clenshaw) evaluation libgcmf uses on one GPU for this plan, on the slab: the state is
         (b_{k+1}, b_{k+2}), the constant input keeps its ghost rows from ONE exchange at the start, a launch of S levels uses
@@ -491,6 +531,8 @@ class SlabFilter:
         keep_land_out = can_multi and hasattr(self.engine, "has_land") and self.engine.has_land()
         land_zeroed = False
         if self.backward_cut:
+            if self.native_driver and self.ncomp == 1 and isinstance(self.engine, HipSlabEngine) and self.exchange_kind in ("native", "p2p"):
+                return self._apply_backward_native(self.backward_cut, st, p, nbatch)
             return self._apply_backward(self.backward_cut, st, p, nbatch)
         u, v = X, None          # T_{k-1}, T_{k-2}
         valid = 0               # ghost rows of u (and at least valid-1 of v) that are up to date

@@ -304,6 +304,18 @@ int gcmf_p2p_finish(gcmf_p2p *p, void *stream);
 int gcmf_p2p_status(gcmf_p2p *p, int *timed_out);
 void gcmf_p2p_destroy(gcmf_p2p *p);
 
+/* ---- one whole filter application on this rank's slab, backward (Clenshaw) evaluation, scalar kinds, in ONE call: launches,
+ * ghost-zone bookkeeping, the edge / interior split that overlaps the exchange, and the halo exchanges themselves (through `comm` --
+ * RCCL -- or `p2p` -- mailboxes; both NULL for a slab without neighbours), all enqueued on `stream`.  X: this rank's input with its own rows
+ * filled in, pool: four state planes, out: the result (f64; the state dtype with GCMF_OUT_F32), all (nbatch, rows_alloc, nx) device
+ * arrays; cut / ncut: gcmf_clenshaw_cut; halo: ghost rows per side (>= the deepest launch); south / north: peer ranks or -1; overlap != 0:
+ * post the exchange between the edge strips and the interior of the launch that uses up the ghost zone (slabs of >= 4 halo rows).
+ * What gcm_filters_amd/distributed.py otherwise does from Python, ~15 us of host time per launch and 13-33 us per exchange. */
+int gcmf_slab_apply_backward(gcmf_plan *plan, gcmf_comm *comm, gcmf_p2p *p2p, int south, int north, const double *p, int n_steps, double c,
+                             const int *cut, int ncut, void *X, void *const *pool, void *out, int64_t nbatch, int halo, int overlap,
+                             uint32_t flags, void *stream);
+
+
 /* Tunables: rows marched per wave of the single-step kernel (0 keeps the default); XCD-aware tile order
  * (1 on, 0 off, <0 keep); temporal blocking: low byte = recurrence steps fused per HBM pass (1 = off,
  * 2..8), bits 8-23 = rows per wave strip (0 = auto), bits 24-27 = operand rows in flight of the general kernels, bits 28-29 =
