@@ -180,8 +180,10 @@ int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launche
     return GCMF_OK;
   }
   const int blo = rows - S;  // first band row
-  if (m.row_lo > rows - 2 * S - 1) {
-    set_error("advance_multi: row range too short for the tripole band");
+  // k_fold_band reads rows [rows - 2S, rows) of the input planes (valid: the caller's ghost zone covers [row_lo - S, ...)) and owns
+  // [rows - S, rows); the blocked launch gets [row_lo, rows - S), possibly nothing
+  if (m.row_lo > blo || rows < 2 * S) {
+    set_error("advance_multi: row range [%d, %d) too short for the tripole band of %d rows", m.row_lo, m.row_hi, S);
     return GCMF_ERR_INVALID_ARG;
   }
   MultiArgs mm = m;

@@ -287,7 +287,7 @@ static int launch_fb(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
 }
 
 bool fold_band_supported(const gcmf_plan *pl, const MultiArgs &a) {
-  return pl && pl->g.fold && (pl->kind == K_MASK || pl->kind == K_FLUX) && a.S >= 1 && a.S <= MAX_S && pl->g.rows >= 2 * a.S + 1 &&
+  return pl && pl->g.fold && (pl->kind == K_MASK || pl->kind == K_FLUX) && a.S >= 1 && a.S <= MAX_S && pl->g.rows >= 2 * a.S &&
          a.nbatch <= 65535;
 }
 

@@ -21,7 +21,7 @@ def make_cases(seed, n, world):
         ny = int(rng.integers(12 * world, 60 * world)); nx = int(rng.integers(2, 40)) * 4
         if grid.startswith("TRIPOLAR"):
             nx += nx % 2
-        halo = int(rng.integers(1, 10))
+        halo = int(rng.integers(1, 20))   # (>= 8: the backward path and, with a library-issued exchange, the C++ slab driver)
         nb = int(rng.choice([1, 1, 2, 3, 4, 5]))
         dt = "f8" if rng.random() < 0.6 else "f4"
         nanland = bool(rng.random() < 0.5)
@@ -43,8 +43,10 @@ def worker(rank, world, port, cases, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     bad = []
     try:
-        for case in cases:
+        for ci, case in enumerate(cases):
             grid, shape, halo, nb, dt, nanland, nsteps, depth, overlap = case
+            if rank == 0 and "-v" in sys.argv:
+                print("CASE", ci, case, flush=True)
             vec = grid in T.VECTOR_GRIDS
             gv = T.vector_grid_vars(grid, shape) if vec else T.scalar_grid_vars(grid, shape)
             fields = [np.stack([T.random_field(shape, 7 + 10 * c + b) for b in range(nb)]) for c in range(2 if vec else 1)]
@@ -55,11 +57,16 @@ def worker(rank, world, port, cases, q):
             dx = T.grid_dx_min(grid, gv) if O.DIMENSIONAL[grid] else 1.0
             fk = dict(filter_scale=3.0 * dx, dx_min=dx, filter_shape="TAPER", n_steps=nsteps)
             try:
-                sf = SlabFilter(grid, gv, fk, shape[0], shape[1], halo=halo, dtype=np.dtype(dt), device=0)
+                sf = SlabFilter(grid, gv, fk, shape[0], shape[1], halo=halo, dtype=np.dtype(dt), device=0,
+                                exchange=(sys.argv[4] if len(sys.argv) > 4 else "auto"))
                 sf.overlap = True   # small test slabs: force the overlapped (edge strips first) exchange where it fits
                 sf.multi_depth, sf.overlap = depth, overlap
                 got = sf.gather_to_global(sf.apply_local(sf.scatter_from_global(fields)))
+                if sf.p2p_timed_out():
+                    bad.append((case, "P2P TIMEOUT"))
             except Exception as e:
+                if "-v" in sys.argv:
+                    import traceback; traceback.print_exc()
                 bad.append((case, "EXC " + repr(e)[:150])); continue
             if rank == 0:
                 flt = Filter(filter_scale=fk["filter_scale"], dx_min=dx, n_steps=nsteps, filter_shape=FilterShape.TAPER,
@@ -84,6 +91,8 @@ if __name__ == "__main__":
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     world = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     cases = make_cases(seed, n, world)
+    if "--only" in sys.argv:
+        cases = [cases[int(sys.argv[sys.argv.index("--only") + 1])]]
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = free_port()
