@@ -97,13 +97,13 @@ class SlabFilter:
     ``"p2p"``: peer stores into the neighbours' IPC-mapped mailboxes + flags, two small kernels on the compute stream per
     exchange and no RCCL at all (csrc/gcmf_p2p.hip; the ranks of ONE node; any backend carries the 64-byte handles once).
     ``self_ring`` (one rank, periodic grids): keep ghost rows and exchange with itself -- the whole slab choreography
-    incl. the native exchange on a single GPU.
+    incl. the native exchange on a single GPU.  ``evaluation``: as in ``Filter`` ("reference" = forward recurrence everywhere).
     """
 
     def __init__(self, grid_type, grid_vars: Dict[str, np.ndarray], filter_kwargs: dict, ny: int, nx: int, *,
                  halo: Optional[int] = None, dtype=np.float64, group=None, device=None, engine_factory=None,
                  rank: Optional[int] = None, world: Optional[int] = None, exchange: str = "auto",
-                 self_ring: bool = False):
+                 self_ring: bool = False, evaluation: str = "auto"):
         import torch
         import torch.distributed as dist
 
@@ -211,7 +211,10 @@ class SlabFilter:
                     self.comm.close()
                 self.comm, self.exchange_kind = None, "torch"
         # the backward (Clenshaw) evaluation libgcmf uses on one GPU: every rank must take the same decision
-        cut = self.engine.clenshaw_cut(self.n_steps) if hasattr(self.engine, "clenshaw_cut") else []
+        if evaluation not in ("auto", "reference"):
+            raise ValueError(f"evaluation must be 'auto' or 'reference', not {evaluation!r}")
+        # evaluation="reference" (as in Filter): the forward recurrence with the reference's accumulation scheme on every rank
+        cut = self.engine.clenshaw_cut(self.n_steps) if (hasattr(self.engine, "clenshaw_cut") and evaluation == "auto") else []
         use = 1 if (cut and (not self.multi or self.halo >= max(cut))) else 0
         if self.world > 1 and dist.is_initialized():
             flag = torch.tensor([use], dtype=torch.int32,

@@ -72,6 +72,13 @@ def test_self_ring_native_exchange_equals_single_domain(grid, shape, halo, nbatc
         again = [t.cpu().numpy() for t in sf.apply_local(sf.scatter_from_global(fields))]
         assert sf.exchanges == n_native
         assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(got, again))
+        # evaluation="reference": the forward recurrence on the slab (bit-identical with the single-domain forward filter)
+        sfr = SlabFilter(grid, gv, fk, shape[0], shape[1], halo=halo, dtype=np.dtype(dt), device=0, rank=0, world=1, self_ring=True,
+                         exchange=exchange, evaluation="reference")
+        assert not sfr.backward_cut
+        fwd = [t.cpu().numpy() for t in sfr.apply_local(sfr.scatter_from_global(fields))]
+        ref = Filter(filter_scale=fk["filter_scale"], dx_min=dx, grid_type=GridType[grid], grid_vars=gv, evaluation="reference").apply(fields[0])
+        assert np.array_equal(fwd[0], ref, equal_nan=True)
     flt = Filter(filter_scale=fk["filter_scale"], dx_min=dx, grid_type=GridType[grid], grid_vars=gv)
     one = flt.apply_to_vector(*fields) if vec else (flt.apply(fields[0]),)
     for g, o in zip(got, one):
