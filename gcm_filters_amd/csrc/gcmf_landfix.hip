@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) void k_land_fix(const T *in, FB *out, const ui
     if ((m & 0x01010101u) == 0x01010101u) continue;
     T xm2[4], xm1[4];
     FB fb[4];
+    bool finite = true;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       T x = in[q4 + j];
@@ -34,16 +35,28 @@ __global__ __launch_bounds__(256) void k_land_fix(const T *in, FB *out, const ui
       fb[j] = cheb_acc_first<FUSED, T, FB>(sp[0], sp[1], x, a);
       xm2[j] = x;
       xm1[j] = a;
+      finite = finite && (__builtin_fabs((double)x) <= 1.7976931348623157e308);
     }
-    for (int k = 2; k <= n_steps; ++k) {
-      const double pk = sp[k];
+    if (finite) {
+      // With L = 0 and a finite x every step is exact up to the running sum: A(T) = -T, T_k = 2 A(T_{k-1}) - T_{k-2} = (-1)^k x, so only
+      // fbar's chain is left (one dependent operation per step instead of three) -- the SAME bits: p_k * (-x) = -(p_k * x), fused or not.
+      // (an infinite x makes T_2 = inf - inf = NaN in the recurrence: those cells take the general loop below)
+      for (int k = 2; k <= n_steps; ++k) {
+        const double pk = sp[k];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const T a = cheb_a<FUSED>(xm1[j], c, T(0));
-        const T tk = cheb_t<FUSED>(a, xm2[j]);
-        fb[j] = cheb_acc<FUSED, T, FB>(fb[j], pk, tk);
-        xm2[j] = xm1[j];
-        xm1[j] = tk;
+        for (int j = 0; j < 4; ++j) fb[j] = cheb_acc<FUSED, T, FB>(fb[j], pk, (k & 1) ? xm1[j] : xm2[j]);   // xm1 = -x, xm2 = x
+      }
+    } else {
+      for (int k = 2; k <= n_steps; ++k) {
+        const double pk = sp[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const T a = cheb_a<FUSED>(xm1[j], c, T(0));
+          const T tk = cheb_t<FUSED>(a, xm2[j]);
+          fb[j] = cheb_acc<FUSED, T, FB>(fb[j], pk, tk);
+          xm2[j] = xm1[j];
+          xm1[j] = tk;
+        }
       }
     }
 #pragma unroll
