@@ -142,11 +142,12 @@ class SlabFilter:
         if not self.multi:
             self.halo = 0
         else:
-            # default: 8 ghost rows (one blocked launch) per ~300 owned rows, at least 16, at most 64: an exchange costs
-            # tens of microseconds of host + RCCL latency -- as much as a whole blocked 8-step launch on a 300-row slab
-            # (~50 us) -- while the redundant ghost-zone work of a 16-row halo is ~10 % there and ~2 % for 64 rows on a
-            # 2400-row slab
-            auto = max(16, 8 * min(8, min_rows // 300))
+            # default: 32 ghost rows (four blocked launches between exchanges), 64 on slabs of 2400 rows and more.  An un-overlapped
+            # exchange costs 24-33 us of the stream -- as much as a whole blocked 8-level launch on a 300-row slab -- while deeper
+            # ghost zones cost almost nothing there (the strips of a short slab are latency-bound, not work-bound).  Measured as a
+            # ring of one rank (tools/measure_exchange.py), ms per application at halo 16 / 24 / 32 / 48: 300 rows 0.410 / 0.373 /
+            # 0.323 / 0.333 (RCCL), 0.364 / 0.345 / 0.309 / 0.326 (p2p); 600 rows 0.485 / - / 0.410 / 0.415 (RCCL)
+            auto = max(32, 8 * min(8, min_rows // 300))
             self.halo = int(halo) if halo else auto
             self.halo = max(1, min(self.halo, min_rows))
         planes = [np.ascontiguousarray(np.asarray(grid_vars[k]), dtype=self.np_dtype)
