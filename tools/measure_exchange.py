@@ -21,6 +21,8 @@ f = w["fields"][0]
 for exchange in ("none", "native", "p2p", "none", "native", "p2p"):
     sf = SlabFilter(w["grid"], w["grid_vars"], fk, rows, nx, halo=halo, device=0, rank=0, world=1, self_ring=True,
                     exchange="p2p" if exchange == "none" else exchange)
+    if len(sys.argv) > 3:
+        sf.overlap = bool(int(sys.argv[3]))       # force the edge / interior split on or off
     if exchange == "none":
         sf.native_driver = False                    # (the Python choreography: its exchange hooks can be stubbed out)
         sf._exchange_start = lambda tensors: None
