@@ -772,6 +772,9 @@ def main_multi(args, world, rank, local_rank):
                         "note": "max over ranks of the timed region with the exchange stubbed out, subtracted from the real run"}
         one_real = None
         keep_o.clear()
+        torch.cuda.synchronize()
+        if sf.p2p_timed_out():    # a wait inside the p2p exchange kernels ran into its 2 s bound: the numbers above mean nothing
+            failed.append(f"rank {rank}: a p2p exchange wait timed out")
         weak = None
         if args.scaling == "strong" and not args.no_weak:
             del sf, outs, local_main
