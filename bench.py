@@ -706,6 +706,7 @@ def main_multi(args, world, rank, local_rank):
         weak = None
         ny_global = args.ny
         kernel_ms = launches = 0
+        kernel_apps, backward_slabs = 1, False
     else:
         from gcm_filters_amd.distributed import SlabFilter
 
@@ -728,7 +729,7 @@ def main_multi(args, world, rank, local_rank):
             for _ in range(args.warmup):
                 one()
             sf.collect_kernel_times()
-            sf.kernel_ms, sf.kernel_launches = 0.0, 0
+            sf.kernel_ms, sf.kernel_launches, sf.kernel_apps = 0.0, 0, 0
             elapsed = timed(one)
             sf.collect_kernel_times()
             return wl, sf, keep["o"], elapsed
@@ -741,7 +742,8 @@ def main_multi(args, world, rank, local_rank):
         cells = ny_global * args.nx
         scaling = args.scaling
         par = f"row-slabs x{world}, halo {sf.halo} rows exchanged every {sf.halo} steps ({sf.exchange_kind})"
-        kernel_ms, launches = sf.kernel_ms, sf.kernel_launches
+        kernel_ms, launches, kernel_apps = sf.kernel_ms, sf.kernel_launches, max(sf.kernel_apps, 1)
+        backward_slabs = bool(sf.backward_cut)
         # parity of the timed (strong) workload against the reference's probes: every rank checks the probes it owns
         parity = None
         chk = golden_probe_check(cfg, args.filter_scale, (ny_global, args.nx), outs, sf.row_begin, sf.row_end)
@@ -798,13 +800,17 @@ def main_multi(args, world, rank, local_rank):
             "timing": main_spread, "value_min": cells * n_steps / (main_spread["ms_per_application_max"] * 1e-3),
             "value_max": cells * n_steps / (main_spread["ms_per_application_min"] * 1e-3),
             "parity": parity, "weak": weak, "exchange": exchange_rec if cfg not in (5, 6) else None, "cpu_baseline": None,
-            "roofline": None if not launches else {
-                "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "kernel_ms_per_step_rank0": kernel_ms / args.steps,
-                "launches_per_step_rank0": launches / args.steps,
-                "achieved": b_alg(grid, itemsize, 8, 1) * (cells / world) * n_steps * args.steps / (kernel_ms * 1e-3) / 1e9,
-                "frac": b_alg(grid, itemsize, 8, 1) * (cells / world) * n_steps * args.steps / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "traffic": None, "note": "per GPU, rank 0: algorithmic bytes of its slab / time between its first and last launch "
-                                         "(includes exchange waits); see the N=1 line for the kernel-level roofline"},
+            # physical, like the N = 1 line: algorithmic bytes of ONE launch (every operand plane read once, every result written once)
+            # x the launches of an application over the time between rank 0's first and last launch of it
+            "roofline": None if not launches else (lambda per_launch, ms_app: {
+                "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "kernel_ms_per_step_rank0": ms_app,
+                "launches_per_step_rank0": launches / kernel_apps,
+                "achieved": per_launch * (launches / kernel_apps) / (ms_app * 1e-3) / 1e9,
+                "frac": per_launch * (launches / kernel_apps) / (ms_app * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "alg_bytes_per_launch": per_launch,
+                "traffic": None, "note": "per GPU, rank 0: algorithmic bytes of one launch on its slab x launches / time between the first and "
+                                         "the last launch of an application (includes exchange waits); see the N=1 line for the kernel-level roofline"})(
+                min_bytes_per_cell_launch(grid, itemsize, 8, 1, backward=backward_slabs) * (cells / world), kernel_ms / kernel_apps),
         }
         print(json.dumps(out))
         if failed:

@@ -227,6 +227,7 @@ class SlabFilter:
         self._bufs = {}
         self.kernel_ms = 0.0
         self.kernel_launches = 0
+        self.kernel_apps = 0       # applications behind kernel_ms / kernel_launches
         self._pending_events = []
         self.exchanges = 0
         self.time_kernels = False  # bench.py: bracket every step launch with events on the launch stream
@@ -408,6 +409,7 @@ class SlabFilter:
             self.torch.cuda.synchronize()
             self.kernel_ms += sum(a.elapsed_time(b) for a, b, _ in self._pending_events)
             self.kernel_launches += sum(n for _, _, n in self._pending_events)
+            self.kernel_apps += len(self._pending_events)
             self._pending_events = []
 
     def _apply_backward_native(self, cut, st, p, nbatch):

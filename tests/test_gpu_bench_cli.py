@@ -42,6 +42,8 @@ def test_self_launch_two_ranks_sharing_the_gpu(cfg, extra):
     assert line["n_gpus"] == 2 and line["value"] > 0
     assert line["scaling"] == ("weak" if "weak" in extra else "strong")
     assert line["config"]["global_grid"] == [512 if "weak" in extra else 256, 256]
+    if cfg != 5:
+        assert 0 < line["roofline"]["frac"] < 1      # physical: algorithmic bytes of a launch x launches / time, like the N = 1 line
     if cfg != 5:   # the N > 1 line says what its halo exchanges cost (host + device, per exchange)
         ex = line["exchange"]
         assert ex["kind"] == ("p2p" if "p2p" in extra else "torch") and ex["exchanges_per_application"] >= 1
