@@ -210,6 +210,8 @@ class _LaplacianMemo:
 
     @staticmethod
     def _token(a):
+        if hasattr(a, "dims") and hasattr(a, "data"):    # an xarray.DataArray grid variable: its (numpy / torch) payload
+            a = a.data
         if isinstance(a, np.ndarray):
             return None if a.flags.writeable else (id(a), 0)
         if _is_torch(a):
