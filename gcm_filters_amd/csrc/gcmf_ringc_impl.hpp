@@ -22,7 +22,8 @@
 //   * rounding differs from the forward recurrence in the last bits (measured <= 3e-15 relative): results are NOT bit-identical
 //     with the single-step kernels; they are bit-identical across different cuts of the levels into launches.
 //
-// f64 state only (the BASELINE scalar configs); not for tripolar plans (the fold band runs forward single steps).
+// f64 state (all scalar kinds) and f32 state of the flux kinds (four cells per lane, f64 result).  On tripolar plans the launch stops S rows
+// below the seam and k_fold_band's backward form (gcmf_foldband.hip) advances those rows beside it.
 #pragma once
 #include "gcmf_ring_impl.hpp"
 
