@@ -20,7 +20,9 @@ The run FAILS (exit 1) if the timed workload's output differs from the oracle / 
 """
 import argparse
 import json
+import math
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -465,7 +467,27 @@ def self_launch(args):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
-    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+    # Watchdog: this parent never touches a GPU, so it is the one place that may kill a hung multi-rank run (an unmatched RCCL recv
+    # waits for ever).  The children run in their own process group; on time-out the whole group is killed and the exit code says so.
+    limit = float(os.environ.get("GCMF_BENCH_TIMEOUT_S", "1500"))
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        raise SystemExit(child.wait(timeout=limit))
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: the {args.gpus}-rank run did not finish within {limit:.0f} s (GCMF_BENCH_TIMEOUT_S): killing its process group",
+              file=sys.stderr)
+        try:
+            os.killpg(child.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        child.wait()
+        raise SystemExit(124)
+    except KeyboardInterrupt:
+        try:
+            os.killpg(child.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        raise
 
 
 def parse():
@@ -644,19 +666,39 @@ def main_multi(args, world, rank, local_rank):
     cpu_dev = "cpu" if share_gpu else dev
 
     spread = {}
+    calls = {"warmup": 0, "timed": 0}   # applications of the collective workload this rank has run (checked equal across ranks)
+
+    def agree_max(x):
+        """MAX over ranks of a host-side number: the only way a rank may turn its own clock into a decision about a collective."""
+        tt = torch.tensor([float(x)], device=cpu_dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
 
     def timed(fn, barrier=True):
         """W warm-up applications (and at least 50 ms of them: a GPU that idled while the host folded plans takes tens of milliseconds
         to clock up again -- a one-off 35 ms stall was seen in exactly this spot), then EXACTLY K applications timed as up to five
         blocks, each bracketed by barrier + synchronize on both sides, MAX over ranks per block.  Returns K x the median block's time
-        per application (what `value` is computed from); min / max of the blocks go to `spread`."""
+        per application (what `value` is computed from); min / max of the blocks go to `spread`.
+
+        `fn` is a COLLECTIVE (halo exchanges): every rank must call it the same number of times.  Round 3 let every rank extend its
+        warm-up by its own clock; a rank that started a little later ran one application more, its exchanges met a neighbour sitting
+        in the barrier (p2p: a chain of 2 s time-outs and stale ghost rows; RCCL: an unmatched recv = a hang).  The number of extra
+        warm-up applications is now derived from the all-reduced MAX of the elapsed time, i.e. identical on every rank, and bounded."""
+        skew_ms = float(os.environ.get("GCMF_BENCH_SKEW_MS", "0") or 0)   # test hook: rank 1 arrives late (tests/test_gpu_bench_cli.py)
+        if skew_ms and rank == 1:
+            time.sleep(skew_ms * 1e-3)
         t_w = time.perf_counter()
         for _ in range(args.warmup):
             fn()
         torch.cuda.synchronize()
-        while time.perf_counter() - t_w < 0.05:
+        calls["warmup"] += args.warmup
+        spent = agree_max(time.perf_counter() - t_w)
+        per_app_est = spent / max(args.warmup, 1)
+        extra = 0 if spent >= 0.05 else int(min(200, math.ceil((0.05 - spent) / max(per_app_est, 1e-4))))
+        for _ in range(extra):        # the same count on every rank (derived from an all-reduced figure)
             fn()
-            torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        calls["warmup"] += extra
         nblocks = max(1, min(5, args.steps))
         per_block = [args.steps // nblocks + (1 if b < args.steps % nblocks else 0) for b in range(nblocks)]
         per_app = []
@@ -669,9 +711,8 @@ def main_multi(args, world, rank, local_rank):
             torch.cuda.synchronize()
             dist.barrier()
             el = time.perf_counter() - t0
-            tt = torch.tensor([el], device=cpu_dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            per_app.append(float(tt.item()) / nb_)
+            calls["timed"] += nb_
+            per_app.append(agree_max(el) / nb_)
         srt = sorted(per_app)
         med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
         spread["last"] = {"blocks": nblocks, "applications_per_block": per_block, "ms_per_application_min": 1e3 * srt[0],
@@ -775,8 +816,18 @@ def main_multi(args, world, rank, local_rank):
         one_real = None
         keep_o.clear()
         torch.cuda.synchronize()
-        if sf.p2p_timed_out():    # a wait inside the p2p exchange kernels ran into its 2 s bound: the numbers above mean nothing
-            failed.append(f"rank {rank}: a p2p exchange wait timed out")
+        if sf.p2p_timed_out():    # a wait inside the p2p exchange kernels failed: the numbers above mean nothing (results are NaN)
+            failed.append(f"rank {rank}: a p2p halo exchange failed (time-out or a neighbour's abort)")
+        # every rank must have run the same number of (collective) applications and exchanges
+        mine = [calls["warmup"], calls["timed"], sf.exchanges, sf.p2p.seq() if sf.p2p is not None else -1]
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        matched = all(e == every[0] for e in every)
+        if not matched:
+            failed.append(f"ranks ran different numbers of collective calls [warm-up, timed, exchanges, p2p seq]: {every}")
+        exchange_rec.update({"collective_calls_rank0": {"warmup": mine[0], "timed": mine[1], "exchanges": mine[2], "p2p_seq": mine[3]},
+                             "matched_across_ranks": matched, "backend": dist.get_backend(),
+                             "rccl": sf.comm.describe() if getattr(sf, "comm", None) is not None else None})
         weak = None
         if args.scaling == "strong" and not args.no_weak:
             del sf, outs, local_main

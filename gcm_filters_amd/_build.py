@@ -71,7 +71,24 @@ def _stale(target: str, deps) -> bool:
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile every .hip source to an object (in parallel) and link csrc/libgcmf.so.  Returns its path."""
+    """Compile every .hip source to an object (in parallel) and link csrc/libgcmf.so.  Returns its path.
+
+    Serialised between processes by a lock file (the ranks of a torchrun / `bench.py --gpus N` job all find a stale binary at
+    once): whoever gets the lock builds, the others wait and then find the binary fresh.  The link goes to a temporary name and
+    is moved into place, so no process ever dlopens a half-written library."""
+    import fcntl
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and binary_build_id() == source_build_id() and not any(
+                    _stale(os.path.join(CSRC, s.replace(".hip", ".o")), [os.path.join(CSRC, s)] + HEADERS) for s in SOURCES):
+                return LIB          # another process built it while this one waited for the lock
+            return _build_library_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_library_locked(force: bool, verbose: bool) -> str:
     objs, procs = [], []
     want_id = source_build_id()
     if not force and os.path.exists(LIB) and binary_build_id() != want_id and not any(
@@ -101,14 +118,22 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + r.stdout)
-        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, ido]
+        tmp = os.path.join(CSRC, f"libgcmf.tmp{os.getpid()}.so")
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs, ido]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        for junk in glob.glob(tmp + ".*") + glob.glob(LIB + ".*"):      # offload-bundler by-products of the link
+            try:
+                os.remove(junk)
+            except FileNotFoundError:
+                pass
         if r.returncode != 0:
+            if os.path.exists(tmp):
+                os.remove(tmp)
             raise RuntimeError("link failed:\n" + r.stdout)
-        for junk in glob.glob(LIB + ".*"):      # offload-bundler by-products of the link
-            os.remove(junk)
-        if binary_build_id() != want_id:
+        if binary_build_id(tmp) != want_id:
+            os.remove(tmp)
             raise RuntimeError("libgcmf.so does not carry the build id it was linked with")
+        os.replace(tmp, LIB)
     return LIB
 
 

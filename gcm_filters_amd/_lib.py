@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgcmf.so")
 
 # status codes (include/gcmf.h)
-OK, ERR_INVALID_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
+OK, ERR_INVALID_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_P2P_TIMEOUT = 0, 1, 2, 3, 4, 5
 ERR_KAPPA_W_GT1, ERR_KAPPA_S_GT1, ERR_KAPPA_NONE_ONE = 16, 17, 18
 ERR_WET_SOUTH_ROW, ERR_DXN_FOLD, ERR_DYN_FOLD = 19, 20, 21
 F32, F64 = 0, 1
@@ -30,9 +30,9 @@ EXPORTS = [
     "gcmf_last_timing", "gcmf_set_timing", "gcmf_set_tuning", "gcmf_last_error", "gcmf_version",
     "gcmf_multi_supported", "gcmf_cheb_multi", "gcmf_multi_supported_vec", "gcmf_cheb_multi_vec",
     "gcmf_has_land", "gcmf_zero_land", "gcmf_land_fix", "gcmf_last_kernel", "gcmf_last_kernel_timing", "gcmf_ring_fallbacks", "gcmf_clenshaw_cut",
-    "gcmf_comm_unique_id", "gcmf_comm_create", "gcmf_comm_destroy", "gcmf_halo_start", "gcmf_halo_finish",
+    "gcmf_comm_unique_id", "gcmf_comm_create", "gcmf_comm_destroy", "gcmf_halo_start", "gcmf_halo_finish", "gcmf_comm_info",
     "gcmf_build_id", "gcmf_last_kernel_geometry",
-    "gcmf_slab_apply_backward", "gcmf_p2p_create", "gcmf_p2p_export", "gcmf_p2p_connect", "gcmf_p2p_start", "gcmf_p2p_finish", "gcmf_p2p_status", "gcmf_p2p_destroy",
+    "gcmf_slab_apply_backward", "gcmf_p2p_create", "gcmf_p2p_export", "gcmf_p2p_connect", "gcmf_p2p_start", "gcmf_p2p_finish", "gcmf_p2p_status", "gcmf_p2p_destroy", "gcmf_p2p_guard", "gcmf_p2p_seq", "gcmf_p2p_set_timeout_ms", "gcmf_p2p_debug_skip_post",
 ]
 PLAN_SELF_RING, PLAN_SKIP_KAPPA_ONE = 0x1, 0x2
 
@@ -130,6 +130,8 @@ def load() -> C.CDLL:
         lib.gcmf_prepare.restype = C.c_int
         lib.gcmf_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         lib.gcmf_last_timing.restype = C.c_int
+        lib.gcmf_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.gcmf_comm_info.restype = C.c_int
         lib.gcmf_comm_unique_id.argtypes = [C.c_char_p]
         lib.gcmf_comm_unique_id.restype = C.c_int
         lib.gcmf_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, vpp]
@@ -158,6 +160,14 @@ def load() -> C.CDLL:
         lib.gcmf_p2p_status.restype = C.c_int
         lib.gcmf_p2p_destroy.argtypes = [vp]
         lib.gcmf_p2p_destroy.restype = None
+        lib.gcmf_p2p_guard.argtypes = [vp, vp, C.c_int64, vp]
+        lib.gcmf_p2p_guard.restype = C.c_int
+        lib.gcmf_p2p_seq.argtypes = [vp, C.POINTER(C.c_int64)]
+        lib.gcmf_p2p_seq.restype = C.c_int
+        lib.gcmf_p2p_set_timeout_ms.argtypes = [vp, C.c_int64]
+        lib.gcmf_p2p_set_timeout_ms.restype = C.c_int
+        lib.gcmf_p2p_debug_skip_post.argtypes = [vp, C.c_int]
+        lib.gcmf_p2p_debug_skip_post.restype = C.c_int
         lib.gcmf_last_kernel_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float),
                                                 C.POINTER(C.c_float)]
         lib.gcmf_last_kernel_timing.restype = C.c_int
@@ -412,6 +422,12 @@ class Comm:
         except Exception:
             pass
 
+    def describe(self) -> dict:
+        """What RCCL reports about this communicator (version code, ranks, this rank)."""
+        v, n, r = C.c_int(), C.c_int(), C.c_int()
+        check(load().gcmf_comm_info(self._h, C.byref(v), C.byref(n), C.byref(r)))
+        return {"rccl_version_code": v.value, "nranks": n.value, "rank": r.value}
+
     def halo_start(self, states: Sequence[int], nblocks, rows_alloc, nx, first_owned, rows_owned, halo, dtype, south, north,
                    stream: int = 0):
         check(load().gcmf_halo_start(self._h, _ptr_array(states), len(states), int(nblocks), int(rows_alloc), int(nx),
@@ -449,10 +465,29 @@ class P2P:
     def finish(self, stream: int = 0):
         check(load().gcmf_p2p_finish(self._h, C.c_void_p(stream or None)))
 
-    def timed_out(self) -> bool:
+    def guard(self, out_ptr: int, nbytes: int, stream: int = 0):
+        """After the last launch of an application: a failed exchange turns `nbytes` of the result into NaN."""
+        check(load().gcmf_p2p_guard(self._h, C.c_void_p(out_ptr), int(nbytes), C.c_void_p(stream or None)))
+
+    def failed(self) -> int:
+        """0 = healthy, 1 = a wait of this rank timed out, 2 = a neighbour aborted the exchange (mapped host word: no device call)."""
         v = C.c_int()
         check(load().gcmf_p2p_status(self._h, C.byref(v)))
-        return bool(v.value)
+        return int(v.value)
+
+    def timed_out(self) -> bool:
+        return self.failed() != 0
+
+    def seq(self) -> int:
+        v = C.c_int64()
+        check(load().gcmf_p2p_seq(self._h, C.byref(v)))
+        return int(v.value)
+
+    def set_timeout_ms(self, ms: int):
+        check(load().gcmf_p2p_set_timeout_ms(self._h, int(ms)))
+
+    def debug_skip_post(self, seq: int):
+        check(load().gcmf_p2p_debug_skip_post(self._h, int(seq)))
 
     def close(self):
         if getattr(self, "_h", None):

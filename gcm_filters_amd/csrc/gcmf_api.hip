@@ -792,6 +792,10 @@ int gcmf_slab_apply_backward(gcmf_plan *pl, gcmf_comm *comm, gcmf_p2p *p2p, int 
     if ((rc = ensure_dev_p(pl, p, n_steps, s))) return rc;
     if ((rc = launch_land_fix(pl, X, out, pl->dev_p, n_steps, c, fb32 ? 1 : 0, nbatch, s))) return rc;
   }
+  if (p2p && multi) {   // a failed exchange must not leave a plausible result (the stencils take NaN ghost rows as zero)
+    const size_t obytes = (size_t)nbatch * ra * nx * ((dtype == GCMF_F32 && fb32) ? 4 : 8);
+    if ((rc = gcmf_p2p_guard(p2p, out, (int64_t)(obytes / 16 * 16), stream))) return rc;
+  }
   return GCMF_OK;
 }
 

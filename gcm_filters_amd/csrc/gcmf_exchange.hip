@@ -34,6 +34,10 @@ struct Rccl {
   int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
   int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
+  // optional (gcmf_comm_info): what RCCL itself says about the communicator
+  int (*GetVersion)(int *) = nullptr;
+  int (*CommCount)(void *, int *) = nullptr;
+  int (*CommUserRank)(void *, int *) = nullptr;
 };
 static std::mutex g_rccl_mu;
 static Rccl g_rccl;
@@ -66,6 +70,9 @@ static bool rccl_load() {
   GCMF_SYM(Recv, "ncclRecv")
   GCMF_SYM(GetErrorString, "ncclGetErrorString")
 #undef GCMF_SYM
+  r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(h, "ncclGetVersion"));
+  r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(h, "ncclCommCount"));
+  r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
   g_rccl = r;
   return true;
 }
@@ -156,6 +163,18 @@ void gcmf_comm_destroy(gcmf_comm *c) {
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
   if (c->pack) (void)hipFree(c->pack);
   delete c;
+}
+
+// What RCCL reports about the communicator libgcmf's exchanges run on: library version (ncclGetVersion), ranks (ncclCommCount) and this
+// rank (ncclCommUserRank); -1 where the entry point is missing.  bench.py --gpus N prints it with the N > 1 line.
+int gcmf_comm_info(gcmf_comm *c, int *version, int *nranks, int *rank) {
+  if (!c || !version || !nranks || !rank) return GCMF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(c->mu);
+  *version = *nranks = *rank = -1;
+  if (g_rccl.GetVersion) (void)g_rccl.GetVersion(version);
+  if (g_rccl.CommCount) (void)g_rccl.CommCount(c->comm, nranks);
+  if (g_rccl.CommUserRank) (void)g_rccl.CommUserRank(c->comm, rank);
+  return GCMF_OK;
 }
 
 int gcmf_comm_create(const void *id128, int world, int rank, int device, gcmf_comm **out) {

@@ -253,6 +253,8 @@ class SlabFilter:
     def gather_to_global(self, local: Sequence):
         """All-gather filtered slabs back into GLOBAL (nbatch, ny, nx) host arrays (every rank gets them)."""
         res = []
+        if self.device.type == "cuda":
+            self.synchronize()
         for t in local:
             nb = t.shape[0]
             full = np.empty((nb, self.ny, self.nx), dtype=np.float64 if t.dtype == self.torch.float64 else np.float32)
@@ -400,8 +402,34 @@ class SlabFilter:
             dist.barrier(group=self.group)         # every block is mapped before the first post
 
     def p2p_timed_out(self) -> bool:
-        """After a synchronisation: did a wait inside the p2p kernels time out (a neighbour that never posted)?"""
+        """Has a peer-to-peer exchange of this rank failed (a wait that timed out, or a neighbour's abort)?  Definitive for
+        everything enqueued before the last synchronisation; reads a mapped host word, no device call."""
         return self.p2p is not None and self.p2p.timed_out()
+
+    def check_exchange(self):
+        """Raise if a peer-to-peer exchange of this rank has failed.  Called at the start of every application, by ``synchronize``,
+        ``gather_to_global`` and ``collect_kernel_times``: a failed exchange is never silent (its results are NaN on the device,
+        gcmf_p2p_guard, and the host raises here)."""
+        if self.p2p is not None:
+            why = self.p2p.failed()
+            if why:
+                raise _lib.GcmfError(_lib.ERR_P2P_TIMEOUT,
+                                     "the peer-to-peer halo exchange of rank %d failed (%s): ghost rows and results since then are NaN; "
+                                     "rebuild the SlabFilter on every rank" % (
+                                         self.rank, "a wait for a neighbour ran into GCMF_P2P_TIMEOUT_MS -- a rank out of step or gone"
+                                         if why == 1 else "a neighbour's wait failed and it raised abort"))
+
+    def synchronize(self):
+        """Wait for everything this rank has enqueued and raise if one of its halo exchanges failed."""
+        self.torch.cuda.synchronize(self.device)
+        self.check_exchange()
+
+    def _p2p_guard(self, outs):
+        """After the last launch of an application (Python choreography): NaN over the result if an exchange has failed."""
+        if self.p2p is not None and self.multi:
+            stream = self.torch.cuda.current_stream().cuda_stream
+            for o in outs:
+                self.p2p.guard(o.data_ptr(), o.numel() * o.element_size() // 16 * 16, stream=stream)
 
     def collect_kernel_times(self):
         """Fold the launch events recorded since the last call into ``kernel_ms`` / ``kernel_launches`` (synchronises)."""
@@ -411,6 +439,7 @@ class SlabFilter:
             self.kernel_launches += sum(n for _, _, n in self._pending_events)
             self.kernel_apps += len(self._pending_events)
             self._pending_events = []
+            self.check_exchange()
 
     def _apply_backward_native(self, cut, st, p, nbatch):
         """The same application in ONE call into libgcmf (gcmf_slab_apply_backward: the choreography below in C++, exchanges through the
@@ -503,6 +532,7 @@ class SlabFilter:
             nlaunch += 1
         if self.engine.has_land():
             self.engine.land_fix(p, self.c, comps(X), comps(O), nbatch)
+        self._p2p_guard([O])
         if self.time_kernels:
             e1.record()
             self._pending_events.append((e0, e1, nlaunch))
@@ -520,6 +550,7 @@ class SlabFilter:
         step), the rest with single steps on a row range that shrinks by one per step."""
         t = self.torch
         assert len(local) == self.ncomp
+        self.check_exchange()
         nbatch = int(local[0].shape[0])
         st = self._state(nbatch)
         X, F, O = st["X"], st["F"], st["O"]
@@ -619,6 +650,7 @@ class SlabFilter:
             k += S
         if land_zeroed:
             self.engine.land_fix(p, self.c, comps(X), comps(O), nbatch)
+        self._p2p_guard([O])
         if events:  # read back later (collect_kernel_times): a synchronisation here would serialise consecutive calls
             self._pending_events.extend(events)
         return [O[k][:, fo: fo + ro, :] for k in range(self.ncomp)]

@@ -38,6 +38,7 @@ typedef enum gcmf_status {
   GCMF_ERR_HIP = 2,         /* a HIP runtime call failed; text in gcmf_last_error()           */
   GCMF_ERR_NO_DEVICE = 3,   /* no gfx950 device visible                                       */
   GCMF_ERR_UNSUPPORTED = 4,
+  GCMF_ERR_P2P_TIMEOUT = 5, /* a peer-to-peer halo exchange of this rank failed (a neighbour never posted, or aborted): results NaN */
   /* Validation failures of the reference's Laplacian constructors.  The Python layer turns
    * them into the reference's exception type and message.                                   */
   GCMF_ERR_KAPPA_W_GT1 = 16,    /* ValueError  kernels.py:262-266                             */
@@ -256,6 +257,8 @@ typedef struct gcmf_comm gcmf_comm;
 int gcmf_comm_unique_id(void *id128);
 int gcmf_comm_create(const void *id128, int world, int rank, int device, gcmf_comm **out);
 void gcmf_comm_destroy(gcmf_comm *comm);
+/* What RCCL itself reports about the communicator: ncclGetVersion, ncclCommCount, ncclCommUserRank (-1 where unavailable). */
+int gcmf_comm_info(gcmf_comm *comm, int *version, int *nranks, int *rank);
 int gcmf_halo_start(gcmf_comm *comm, void *const *states, int nstate, int64_t nblocks, int64_t rows_alloc, int64_t nx,
                     int64_t first_owned, int64_t rows_owned, int halo, int dtype, int south, int north, void *stream);
 int gcmf_halo_finish(gcmf_comm *comm, void *stream);
@@ -292,8 +295,15 @@ int gcmf_ring_fallbacks(gcmf_plan *plan, int64_t *count);
  * hipIpcMemHandle_t, handed to the neighbours by the caller's own channel), gcmf_p2p_connect (south / north handles, NULL = a physical
  * boundary; *_is_self: that neighbour is this very process), then per exchange gcmf_p2p_start (after the launches that produced the edge
  * rows) ... interior launches ... gcmf_p2p_finish (before the next launch that reads the ghost rows), both enqueued on the caller's
- * compute stream: two small kernels, no events, no host round trip.  Waits inside the kernels are bounded (2 s); gcmf_p2p_status
- * reports a wait that timed out after the stream was synchronised.  Arguments of gcmf_p2p_start as gcmf_halo_start. */
+ * compute stream: two small kernels, no events, no host round trip.  Arguments of gcmf_p2p_start as gcmf_halo_start.
+ * The block is fine-grained device memory (coherent between agents while kernels run); remote memory is only written.
+ * FAILURE IS LOUD: waits inside the kernels are bounded (GCMF_P2P_TIMEOUT_MS, default 30000; gcmf_p2p_set_timeout_ms).  A wait that runs
+ * out marks this rank failed (sticky), raises `abort` in both neighbours (the failure travels round the ring at once), delivers NaN
+ * ghost rows instead of stale ones, and gcmf_p2p_guard -- enqueued by the slab drivers after the last launch of an application --
+ * turns the application's result into NaN.  gcmf_p2p_status reads the failure word from mapped host memory (0 ok, 1 timed out, 2
+ * aborted by a neighbour; no device call); gcmf_p2p_start and gcmf_slab_apply_backward return GCMF_ERR_P2P_TIMEOUT on a failed
+ * exchange.  gcmf_p2p_seq: exchanges started so far (equal on every rank of a healthy run).  gcmf_p2p_debug_skip_post: test hook,
+ * drops the post of exchange number `seq` on this rank. */
 typedef struct gcmf_p2p gcmf_p2p;
 int gcmf_p2p_create(int device, int64_t mailbox_bytes, gcmf_p2p **out);
 int gcmf_p2p_export(gcmf_p2p *p, void *handle64);
@@ -301,7 +311,11 @@ int gcmf_p2p_connect(gcmf_p2p *p, const void *south_handle64, const void *north_
 int gcmf_p2p_start(gcmf_p2p *p, void *const *states, int nstate, int64_t nblocks, int64_t rows_alloc, int64_t nx, int64_t first_owned,
                    int64_t rows_owned, int halo, int dtype, void *stream);
 int gcmf_p2p_finish(gcmf_p2p *p, void *stream);
-int gcmf_p2p_status(gcmf_p2p *p, int *timed_out);
+int gcmf_p2p_guard(gcmf_p2p *p, void *out, int64_t bytes, void *stream);
+int gcmf_p2p_status(gcmf_p2p *p, int *failed);
+int gcmf_p2p_seq(gcmf_p2p *p, int64_t *seq);
+int gcmf_p2p_set_timeout_ms(gcmf_p2p *p, int64_t ms);
+int gcmf_p2p_debug_skip_post(gcmf_p2p *p, int seq);
 void gcmf_p2p_destroy(gcmf_p2p *p);
 
 /* ---- one whole filter application on this rank's slab, backward (Clenshaw) evaluation, scalar kinds, in ONE call: launches,

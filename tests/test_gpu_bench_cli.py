@@ -50,6 +50,30 @@ def test_self_launch_two_ranks_sharing_the_gpu(cfg, extra):
         assert ex["ms_per_application_without_exchange"] > 0 and ex["us_per_exchange_host_and_device"] is not None
 
 
+@pytest.mark.parametrize("cfg,exchange", [(3, "torch"), (3, "p2p"), (4, "p2p")])
+def test_two_ranks_with_skewed_clocks_run_matched_collectives(cfg, exchange):
+    """Round 3's bench let every rank extend its warm-up by its OWN clock: a rank that arrived late ran one collective application
+    more than its neighbour (p2p: a chain of time-outs; RCCL: an unmatched recv = a hang).  Rank 1 is held back 30 ms before every
+    timed() here; the ranks must still run identical numbers of applications and exchanges, and nothing may time out."""
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--config", str(cfg), "--ny", "256", "--nx", "256", "--no-weak",
+              "--exchange", exchange], {"GCMF_BENCH_SHARE_GPU": "1", "GCMF_BENCH_SKEW_MS": "30", "GCMF_P2P_TIMEOUT_MS": "5000"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    ex = _json_line(r.stdout)["exchange"]
+    assert ex["kind"] == exchange and ex["matched_across_ranks"] is True
+    calls = ex["collective_calls_rank0"]
+    assert calls["timed"] == 2 * 3 and calls["warmup"] >= 2 and calls["exchanges"] > 0
+    if exchange == "p2p":
+        assert calls["p2p_seq"] > 0
+
+
+def test_hung_multi_rank_run_is_killed_by_the_parent():
+    """The un-initialised parent of `bench.py --gpus N` is the watchdog: a run that exceeds GCMF_BENCH_TIMEOUT_S is killed as a
+    process group and reported with exit code 124 (never a hang until the driver's own limit)."""
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "3", "--ny", "256", "--nx", "256", "--no-weak"],
+             {"GCMF_BENCH_SHARE_GPU": "1", "GCMF_BENCH_TIMEOUT_S": "0.5"}, timeout=120)
+    assert r.returncode == 124 and "killing its process group" in r.stderr
+
+
 def test_single_gpu_line_carries_parity_and_roofline():
     r = _run(["--steps", "2", "--warmup", "1", "--no-extra", "--cpu-steps", "3"])
     assert r.returncode == 0, r.stderr[-2000:]

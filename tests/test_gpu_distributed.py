@@ -134,3 +134,82 @@ def test_slabs_on_one_gpu_match_single_domain(world, exchange):
         f32 = name.endswith("f4")
         assert e_one <= (1e-5 if f32 else 1e-13), (name, e_one)   # slab run == single-domain GPU run
         assert e_ref <= (1e-4 if f32 else 1e-11), (name, e_ref)   # and == the reference
+
+
+def _worker_skipped_post(rank, world, port, q, native_driver):
+    """Rank 1 "forgets" the post of its second exchange (gcmf_p2p_debug_skip_post): the ranks that wait for it must not carry on
+    with stale ghost rows.  Every rank reports what its host saw and how long that took."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    import time
+    import torch
+    import torch.distributed as dist
+    from gcm_filters_amd import _lib, testing as T
+    from gcm_filters_amd.distributed import SlabFilter
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["GCMF_P2P_TIMEOUT_MS"] = "1000"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        grid, shape = "IRREGULAR_WITH_LAND", (96, 64)
+        gv = T.scalar_grid_vars(grid, shape)
+        dx = T.grid_dx_min(grid, gv)
+        fk = dict(filter_scale=12.0 * dx, dx_min=dx, filter_shape="GAUSSIAN")
+        sf = SlabFilter(grid, gv, fk, shape[0], shape[1], halo=8, dtype=np.float64, device=0, exchange="p2p")
+        sf.native_driver = native_driver
+        assert sf.exchange_kind == "p2p" and sf.backward_cut
+        local = sf.scatter_from_global([T.random_field(shape, 3)[None]])
+        good = sf.apply_local(local)[0].clone()          # a healthy application first (brings the mailboxes up)
+        sf.synchronize()
+        assert torch.isfinite(good).all()
+        seqs = [None] * world
+        dist.all_gather_object(seqs, sf.p2p.seq())
+        assert len(set(seqs)) == 1 and seqs[0] >= 2, seqs    # every rank has started the same number of exchanges
+        if rank == 1:
+            sf.p2p.debug_skip_post(2 * sf.p2p.seq())     # the last exchange of the next application never leaves rank 1
+        dist.barrier()
+        t0 = time.perf_counter()
+        status, last = [], None
+        for _ in range(2):      # the application with the dropped post, and one more
+            try:
+                last = sf.apply_local(local)[0]
+                sf.synchronize()
+                status.append(None)
+            except _lib.GcmfError as e:
+                status.append(e.status)
+        el = time.perf_counter() - t0
+        q.put((rank, status, el, bool(torch.isnan(last).all()), sf.p2p.failed()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("native_driver", [True, False])
+def test_p2p_rank_that_skips_a_post_fails_every_rank_loudly(native_driver):
+    """a timed-out wait used to copy stale mailbox rows and carry on.  Now the waiting rank fails within the
+    time-out (1 s here), its neighbours are aborted at once, every result is NaN and every host raises GCMF_ERR_P2P_TIMEOUT at its
+    next synchronisation and at its next application."""
+    import torch.multiprocessing as mp
+    from gcm_filters_amd import _lib
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_skipped_post, args=(r, world, port, q, native_driver)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    for p in procs:
+        assert p.exitcode == 0, f"worker exit code {p.exitcode}"
+    got = sorted(q.get() for _ in range(world))
+    for rank, status, el, all_nan, why in got:
+        # the ranks that waited for the dropped rows fail in that very application; rank 1 itself received everything it needed (its
+        # result of that application is right) and fails in the next one, when its neighbours' abort reaches its first wait
+        assert status[1] == _lib.ERR_P2P_TIMEOUT and (rank == 1 or status[0] == _lib.ERR_P2P_TIMEOUT), got
+        assert el < 3.0, got                      # one time-out (1 s) + the abort going round, not a time-out per rank and exchange
+        assert all_nan and why in (1, 2), got     # the last result is NaN on the device as well
+    assert any(why == 1 for *_, why in got)       # somebody's wait ran out; the others may have been aborted by it
