@@ -269,10 +269,15 @@ def make_gridbatched(rf, rk, outdir):
     print("reference_gridbatched.npz:", len(out), "arrays")
 
 
-# full-size cases: key -> (BASELINE config, filter scale in dx_min units (0 = the config's own), NaN on land?)
+# full-size cases: key -> (BASELINE config, filter scale in dx_min units (0 = the config's own), NaN on land?[, options])
+# options: level = the vertical level of config 5 (its fields are seeded per level); f32 = field AND grid variables cast to float32
+# before the reference sees them (its f32-input path: f32 recurrence, f64 running sum and result)
 FULLSIZE_CASES = {
     "cfg2_n11": (2, 10.0, False), "cfg2_n56": (2, 50.0, False), "cfg2_n11_nanland": (2, 10.0, True),
     "cfg3_n63": (3, 0.0, False), "cfg4_n56": (4, 0.0, False), "cfg5_lev0_n44": (5, 0.0, False),
+    # round 4: two more levels of config 5 and the f32-state path of configs 3 / 4
+    "cfg5_lev24_n44": (5, 0.0, False, {"level": 24}), "cfg5_lev49_n44": (5, 0.0, False, {"level": 49}),
+    "cfg3_f32_n63": (3, 0.0, False, {"f32": True}), "cfg4_f32_n56": (4, 0.0, False, {"f32": True}),
 }
 
 
@@ -282,10 +287,20 @@ def make_fullsize(rf, rk, outdir):
     from gcm_filters_amd import testing as T
 
     out = {}
-    for key, (cfg, scale, nanland) in FULLSIZE_CASES.items():
-        wl = T.baseline_workload(cfg, T.BASELINE_SHAPE, scale=scale, levels=[0] if cfg == 5 else None)
+    only = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else None
+    if only:   # regenerate some cases, keep the others as they are in the committed file
+        with np.load(os.path.join(outdir, "reference_fullsize.npz")) as z:
+            out = {k: z[k] for k in z.files}
+    for key, (cfg, scale, nanland, *rest) in FULLSIZE_CASES.items():
+        if only and key not in only:
+            continue
+        opt = rest[0] if rest else {}
+        wl = T.baseline_workload(cfg, T.BASELINE_SHAPE, scale=scale, levels=[opt.get("level", 0)] if cfg == 5 else None)
         grid, gv, fk = wl["grid"], wl["grid_vars"], wl["fk"]
         fields = [f[0] if f.ndim == 3 else f for f in wl["fields"]]
+        if opt.get("f32"):
+            gv = {k: v.astype(np.float32) for k, v in gv.items()}
+            fields = [f.astype(np.float32) for f in fields]
         if nanland:
             fields = [np.where(gv["wet_mask"] == 0, np.nan, f) for f in fields]
         cls = rk.ALL_KERNELS[rk.GridType[grid]]

@@ -36,11 +36,11 @@ def test_bench_workload_blocked_equals_single_steps(irregular, monkeypatch):
         assert "k_ring<" in plan.last_kernel()
         plan.set_tuning(multi_s=4)
         got4 = flt.apply(f)
-        plan.set_tuning(multi_s=8, clenshaw=1)     # the default: backward evaluation (k_ringc)
+        plan.set_tuning(multi_s=8, clenshaw=2)     # the default: backward evaluation (k_ringc)
         gotc = flt.apply(f)
         assert "k_ringc<" in plan.last_kernel()
     finally:
-        plan.set_tuning(multi_s=8, clenshaw=1)
+        plan.set_tuning(multi_s=8, clenshaw=2)
     assert np.array_equal(ref, got) and np.array_equal(ref, got4)
     assert np.abs(gotc - ref).max() <= 1e-13 * np.abs(ref).max()   # same polynomial, other rounding (measured 2e-15)
     assert np.isfinite(got).all() and got.min() > -0.2 and got.max() < 1.2   # stable: dx_min is the true minimum
@@ -88,11 +88,11 @@ def test_tripolar_pop_fullsize_fold_band(monkeypatch):
         plan.set_tuning(multi_s=8, clenshaw=0)    # the forward recurrence: blocked launches + the seam rows by k_fold_band
         got = flt.apply(f)
         assert "k_ring<" in plan.last_kernel()
-        plan.set_tuning(multi_s=8, clenshaw=1)    # the default: backward evaluation, the seam rows by k_fold_band's backward form
+        plan.set_tuning(multi_s=8, clenshaw=2)    # the default: backward evaluation, the seam rows by k_fold_band's backward form
         back = flt.apply(f)
         assert "k_ringc<" in plan.last_kernel()
     finally:
-        plan.set_tuning(multi_s=8, clenshaw=1)
+        plan.set_tuning(multi_s=8, clenshaw=2)
     assert np.array_equal(ref, got)                # bit-identical with 56 single steps, seam included
     assert np.abs(back - ref).max() <= 1e-13 * np.abs(ref).max()
     for o in (got, back):
@@ -148,18 +148,24 @@ def test_config2_regular_with_land_fullsize(fullsize, scale, key):
     assert flt.n_steps == int(fullsize[key + "/meta"][0])
     np.testing.assert_allclose(flt.filter_spec.p, fullsize[key + "/p"], rtol=0, atol=5e-14)
     plan = ALL_KERNELS[GridType.REGULAR_WITH_LAND](**gv)._plan(_lib.F64, SHAPE)
+    fk = wl["fk"]
+    fwd = Filter(filter_scale=fk["filter_scale"], dx_min=fk["dx_min"], filter_shape=FilterShape[fk["filter_shape"]],
+                 grid_type=GridType[wl["grid"]], grid_vars=gv, evaluation="reference")   # the reference's forward recurrence
     try:
         plan.set_tuning(multi_s=1)
-        ref = flt.apply(f)
+        ref = fwd.apply(f)
         plan.set_tuning(multi_s=8)
-        got = flt.apply(f)
+        got = fwd.apply(f)
     finally:
         plan.set_tuning(multi_s=8)
     assert np.array_equal(ref, got)                        # 8 steps per pass == single steps, bit for bit
-    # n 56: the K_MASKZ static-ring kernel (8 steps per pass) after the first launch; n 11 = one general 8-step launch + 3
     # n 56: the static-ring kernels (8 steps per pass; K_MASKZ -- land zeroed as the first launch loads the field); n 11: one
     # 8-step launch + 3
     assert "k_ring<double, double, 5, 8, " in plan.last_kernel()
+    _check_against_fixture(fullsize, key, [got], 1e-11, 1e-11)
+    # the default since round 4: the polynomial evaluated backwards (k_ringc, fused multiply-adds): same probes, same gate
+    got = flt.apply(f)
+    assert "k_ringc<double, 5, " in plan.last_kernel(), plan.last_kernel()
     _check_against_fixture(fullsize, key, [got], 1e-11, 1e-11)
     # ocean-like input: NaN exactly on land, wet cells unchanged (the stencil sees nan_to_num * mask: kernels.py:163-187)
     fn = np.where(gv["wet_mask"] == 0, np.nan, f)
@@ -200,11 +206,15 @@ def test_config5_cgrid_50_levels_fullsize(fullsize):
     assert u.shape == (50, 2400, 3600) and u.dtype == torch.float32
     plan = ALL_KERNELS[GridType.VECTOR_C_GRID](**gv)._plan(_lib.F32, SHAPE)
     try:
-        plan.set_tuning(multi_s=8, clenshaw=1)    # the default: backward evaluation, four levels per launch
+        plan.set_tuning(multi_s=8, clenshaw=2)    # the default: backward evaluation, four levels per launch
         cu_, cw_ = flt.apply_to_vector(u, v)
         assert "k_cgrid_stream2c<float, 2, 4" in plan.last_kernel()
         cu0, cw0 = cu_[0].cpu().numpy(), cw_[0].cpu().numpy()
         assert cu0.dtype == np.float64
+        # levels 24 and 49 of the batch against the reference's own outputs for those levels (round 4: the fixture used to pin level 0 only)
+        for lev in (24, 49):
+            assert int(fullsize[f"cfg5_lev{lev}_n44/meta"][0]) == 44
+            _check_against_fixture(fullsize, f"cfg5_lev{lev}_n44", [cu_[lev].cpu().numpy(), cw_[lev].cpu().numpy()], 1e-4, 1e-4)
         c1u, c1w = flt.apply_to_vector(u[:1], v[:1])           # a level filtered alone gives the same bits as in the batch
         assert np.array_equal(c1u[0].cpu().numpy(), cu0) and np.array_equal(c1w[0].cpu().numpy(), cw0)
         del cu_, cw_, c1u, c1w
@@ -214,6 +224,8 @@ def test_config5_cgrid_50_levels_fullsize(fullsize):
         assert "k_cgrid_stream2<float, double, 2, 5" in plan.last_kernel()
         gu0, gw0 = gu[0].cpu().numpy(), gw[0].cpu().numpy()
         gu_l, gw_l = gu[-1].clone(), gw[-1].clone()
+        for lev in (24, 49):   # the reference's scheme (forward, f64 fbar) on the same levels
+            _check_against_fixture(fullsize, f"cfg5_lev{lev}_n44", [gu[lev].cpu().numpy(), gw[lev].cpu().numpy()], 1e-4, 1e-4)
         del gu, gw
         plan.set_tuning(multi_s=1)
         ru, rw = flt.apply_to_vector(u[-2:], v[-2:])       # single steps on the last two levels
@@ -221,7 +233,7 @@ def test_config5_cgrid_50_levels_fullsize(fullsize):
         ru0, rw0 = flt.apply_to_vector(u[:1], v[:1])
         assert np.array_equal(ru0[0].cpu().numpy(), gu0) and np.array_equal(rw0[0].cpu().numpy(), gw0)
     finally:
-        plan.set_tuning(multi_s=8, clenshaw=1)
+        plan.set_tuning(multi_s=8, clenshaw=2)
     assert gu0.dtype == np.float64                         # NumPy >= 2 promotion of p[k] * T
     _check_against_fixture(fullsize, "cfg5_lev0_n44", [gu0, gw0], 1e-4, 1e-4)
 
@@ -251,3 +263,13 @@ def test_f32_state_of_the_flux_configs_at_full_size(fullsize, cfg, key, monkeypa
         err = np.abs(o[jj, ii] - want).max() / np.abs(want).max()
         assert err <= 1e-5, (ev, err)
     assert np.array_equal(np.isnan(outs["auto"]), np.isnan(outs["reference"]))
+    # ... and against what the reference ITSELF returns for these f32 inputs (its f32 recurrence with the f64 running sum; fixture
+    # cfgN_f32_*, round 4): the forward scheme here differs from it by the plan-time folding of the coefficients in f32 only
+    k32 = key.replace("_n", "_f32_n")
+    want32 = np.atleast_2d(fullsize[k32 + "/probe"])[0]
+    assert int(fullsize[k32 + "/meta"][0]) == int(fullsize[key + "/meta"][0])
+    assert np.abs(want32 - want).max() / np.abs(want).max() <= 1e-5          # the reference's own f32 path against its f64 path
+    for ev, o in outs.items():
+        err = np.abs(o[jj, ii] - want32).max() / np.abs(want32).max()
+        assert err <= 1e-5, (ev, err)
+    _check_against_fixture(fullsize, k32, [outs["reference"]], 1e-5, 1e-5)

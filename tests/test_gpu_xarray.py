@@ -30,7 +30,8 @@ def test_application_to_dataset(xr):
                                    temporal=(("time",), rng.normal(size=(10,))),
                                    spatiotemporal=(("time", "y", "x"), rng.normal(size=(10, 100, 120))),
                                    transposed=(("y", "time", "x"), rng.normal(size=(100, 10, 120)))))
-    flt = Filter(filter_scale=4, dx_min=1, filter_shape=FilterShape.GAUSSIAN, grid_type=GridType.REGULAR)
+    # (evaluation="reference": the forward recurrence, bit-exact with numpy on REGULAR -- this test is about the adapter)
+    flt = Filter(filter_scale=4, dx_min=1, filter_shape=FilterShape.GAUSSIAN, grid_type=GridType.REGULAR, evaluation="reference")
     out = flt.apply(ds, ["y", "x"])
     # the same Chebyshev coefficients on both sides (Filter's own fit agrees with the reference's to 5e-14, not to the bit)
     fs = flt.filter_spec
@@ -117,8 +118,12 @@ def test_depth_dependent_mask_through_xarray(xr):
     import make_golden as MG
     fields, gv, fk = MG.build_gridbatched_case("REGULAR_WITH_LAND")
     gvx = {"wet_mask": xr.DataArray(gv["wet_mask"], dims=["z", "y", "x"])}
-    flt = Filter(filter_scale=fk["filter_scale"], dx_min=fk["dx_min"], grid_type=GridType.REGULAR_WITH_LAND, grid_vars=gvx)
+    flt = Filter(filter_scale=fk["filter_scale"], dx_min=fk["dx_min"], grid_type=GridType.REGULAR_WITH_LAND, grid_vars=gvx,
+                 evaluation="reference")
     out = flt.apply(xr.DataArray(fields[0], dims=["time", "z", "y", "x"]), dims=["y", "x"])
     fs = flt.filter_spec
     want = O.filter_func(O.FilterSpec(fs.n_steps, fs.s_max, np.asarray(fs.p), fs.dx_min_sq), "REGULAR_WITH_LAND", fields[0], gv)
     assert out.dims == ("time", "z", "y", "x") and np.array_equal(out.data, want)
+    auto = Filter(filter_scale=fk["filter_scale"], dx_min=fk["dx_min"], grid_type=GridType.REGULAR_WITH_LAND, grid_vars=gvx)
+    got = auto.apply(xr.DataArray(fields[0], dims=["time", "z", "y", "x"]), dims=["y", "x"]).data    # the default (backward evaluation)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.nanmax(np.abs(got - want)) <= 1e-13 * np.nanmax(np.abs(want))

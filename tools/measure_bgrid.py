@@ -24,5 +24,5 @@ for dt, nlev in (("f8", 20), ("f4", 40), ("f8", 1)):
         torch.cuda.synchronize()
         dtm = (time.perf_counter() - t0) / 3
         print(f"{dt} x{nlev}: clenshaw={cl} {nlev*shape[0]*shape[1]*24/dtm/1e9:7.1f} G cell-steps/s  {plan.last_kernel()}", flush=True)
-    plan.set_tuning(multi_s=8, clenshaw=1)
+    plan.set_tuning(multi_s=8, clenshaw=2)
     del u, v

@@ -26,6 +26,6 @@ for n, scale in ((44, 40), (63, 57), (98, 90), (125, 114)):
         plan.set_tuning(multi_s=8, clenshaw=cl)
         g = flt.apply_to_vector(u, v)
         res[name] = (rel(g, (ru, rv)), rel(g, (tu, tv)), plan.last_kernel()[:28])
-    plan.set_tuning(multi_s=8, clenshaw=1)
+    plan.set_tuning(multi_s=8, clenshaw=2)
     print(f"n={n:4d} scale {scale}: reference f32 path vs f64 truth {rel((ru, rv), (tu, tv)):.2e} | " +
           " | ".join(f"{k}: vs reference {a:.2e}, vs f64 truth {b:.2e} ({kn})" for k, (a, b, kn) in res.items()), flush=True)
