@@ -21,7 +21,7 @@ OK, ERR_INVALID_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_P2P_TIMEOUT = 
 ERR_KAPPA_W_GT1, ERR_KAPPA_S_GT1, ERR_KAPPA_NONE_ONE = 16, 17, 18
 ERR_WET_SOUTH_ROW, ERR_DXN_FOLD, ERR_DYN_FOLD = 19, 20, 21
 F32, F64 = 0, 1
-DEVICE_PTRS, OUT_F32, FORWARD_RECURRENCE = 0x1, 0x2, 0x4
+DEVICE_PTRS, OUT_F32, FORWARD_RECURRENCE, NO_RESIDENT = 0x1, 0x2, 0x4, 0x8
 STEP_FIRST, STEP_LAST, STEP_LAND_ZERO, STEP_LAND_FIXED, STEP_CLENSHAW = 0x1, 0x2, 0x4, 0x8, 0x10
 
 EXPORTS = [
@@ -32,7 +32,7 @@ EXPORTS = [
     "gcmf_has_land", "gcmf_zero_land", "gcmf_land_fix", "gcmf_last_kernel", "gcmf_last_kernel_timing", "gcmf_ring_fallbacks", "gcmf_clenshaw_cut",
     "gcmf_comm_unique_id", "gcmf_comm_create", "gcmf_comm_destroy", "gcmf_halo_start", "gcmf_halo_finish", "gcmf_comm_info",
     "gcmf_build_id", "gcmf_last_kernel_geometry",
-    "gcmf_slab_apply_backward", "gcmf_p2p_create", "gcmf_p2p_export", "gcmf_p2p_connect", "gcmf_p2p_start", "gcmf_p2p_finish", "gcmf_p2p_status", "gcmf_p2p_destroy", "gcmf_p2p_guard", "gcmf_p2p_seq", "gcmf_p2p_set_timeout_ms", "gcmf_p2p_debug_skip_post",
+    "gcmf_slab_apply_backward", "gcmf_resident_supported", "gcmf_resident_levels", "gcmf_p2p_create", "gcmf_p2p_export", "gcmf_p2p_connect", "gcmf_p2p_start", "gcmf_p2p_finish", "gcmf_p2p_status", "gcmf_p2p_destroy", "gcmf_p2p_guard", "gcmf_p2p_seq", "gcmf_p2p_set_timeout_ms", "gcmf_p2p_debug_skip_post",
 ]
 PLAN_SELF_RING, PLAN_SKIP_KAPPA_ONE = 0x1, 0x2
 
@@ -130,6 +130,11 @@ def load() -> C.CDLL:
         lib.gcmf_prepare.restype = C.c_int
         lib.gcmf_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         lib.gcmf_last_timing.restype = C.c_int
+        lib.gcmf_resident_supported.argtypes = [vp, C.c_int64, C.c_int64, C.c_int]
+        lib.gcmf_resident_supported.restype = C.c_int
+        lib.gcmf_resident_levels.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_double), C.c_int, C.c_double, C.c_double, C.c_uint32,
+                                             C.c_int64, C.c_int64, vp]
+        lib.gcmf_resident_levels.restype = C.c_int
         lib.gcmf_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         lib.gcmf_comm_info.restype = C.c_int
         lib.gcmf_comm_unique_id.argtypes = [C.c_char_p]
@@ -304,16 +309,29 @@ class Plan:
                                      OUT_F32 if out_f32 else 0, int(nbatch), int(row_lo), int(row_hi),
                                      C.c_void_p(stream or None)))
 
-    def slab_apply_backward(self, comm, p2p, south, north, p, c, cut, X, pool, out, nbatch, halo, overlap, *, out_f32=False, stream=0):
+    def slab_apply_backward(self, comm, p2p, south, north, p, c, cut, X, pool, out, nbatch, halo, overlap, *, out_f32=False, stream=0,
+                            resident=True):
         """One whole backward (Clenshaw) application on this slab incl. its halo exchanges, enqueued by libgcmf in one call
-        (gcmf_slab_apply_backward).  comm / p2p: a Comm / P2P object or None; X / out: device pointers, pool: four of them."""
+        (gcmf_slab_apply_backward).  comm / p2p: a Comm / P2P object or None; X / out: device pointers, pool: four of them.
+        resident=False: never the on-chip kernel (the strip-marching launches instead: same bits)."""
         p = np.ascontiguousarray(p, dtype=np.float64)
         cut = (C.c_int * len(cut))(*[int(x) for x in cut])
         check(load().gcmf_slab_apply_backward(
             self._h, None if comm is None else comm._h, None if p2p is None else p2p._h, -1 if south is None else int(south),
             -1 if north is None else int(north), p.ctypes.data_as(C.POINTER(C.c_double)), len(p) - 1, float(c), cut, len(cut),
-            C.c_void_p(X), _ptr_array(pool), C.c_void_p(out), int(nbatch), int(halo), int(bool(overlap)), OUT_F32 if out_f32 else 0,
-            C.c_void_p(stream or None)))
+            C.c_void_p(X), _ptr_array(pool), C.c_void_p(out), int(nbatch), int(halo), int(bool(overlap)),
+            (OUT_F32 if out_f32 else 0) | (0 if resident else NO_RESIDENT), C.c_void_p(stream or None)))
+
+    def resident_supported(self, row_lo: int, row_hi: int, L: int) -> bool:
+        """Can L levels of the backward evaluation with output rows [row_lo, row_hi) run in one on-chip launch (gcmf_resident.hip)?"""
+        return bool(load().gcmf_resident_supported(self._h, int(row_lo), int(row_hi), int(L)))
+
+    def resident_levels(self, u, v, uo, vo, f, out, pk, p0, c, mode, row_lo, row_hi, *, stream: int = 0):
+        """len(pk) levels of the backward evaluation in ONE on-chip launch (gcmf_resident_levels); device pointers or None."""
+        pk = np.ascontiguousarray(pk, dtype=np.float64)
+        vp = lambda x: C.c_void_p(x) if x else None
+        check(load().gcmf_resident_levels(self._h, vp(u), vp(v), vp(uo), vp(vo), vp(f), vp(out), pk.ctypes.data_as(C.POINTER(C.c_double)),
+                                          len(pk), float(p0), float(c), int(mode), int(row_lo), int(row_hi), C.c_void_p(stream or None)))
 
     def clenshaw_cut(self, n_steps: int):
         """Launch depths of the backward evaluation gcmf_apply uses for this polynomial length ([] = forward recurrence)."""

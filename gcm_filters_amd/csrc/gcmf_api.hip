@@ -266,6 +266,7 @@ void gcmf_plan_destroy(gcmf_plan *pl) {
   }
   if (pl->stage) (void)hipFree(pl->stage);
   if (pl->dev_p) (void)hipFree(pl->dev_p);
+  resident_free(pl);
   if (pl->stream) (void)hipStreamDestroy(pl->stream);
   delete pl;
 }
@@ -621,6 +622,38 @@ int gcmf_cheb_multi(gcmf_plan *pl, const void *u, const void *v, void *uo, void 
   return advance_multi(pl, m, (hipStream_t)stream, nullptr);
 }
 
+// ---- the on-chip (resident) kernel, gcmf_resident.hip --------------------------------------------------------------------------
+// Whether L levels of the backward evaluation with output rows [row_lo, row_hi) of this plan can run in ONE resident launch (f64 scalar
+// plans whose rows [row_lo - L, row_hi + L) fit the register files + LDS of the chip, no tripole seam in that range, L <= 64).
+int gcmf_resident_supported(const gcmf_plan *pl, int64_t row_lo, int64_t row_hi, int L) {
+  if (!pl) return 0;
+  (void)hipSetDevice(pl->d.device);
+  return resident_supported(pl, (int)row_lo, (int)row_hi, L) ? 1 : 0;
+}
+
+// L levels of the backward evaluation in one launch on rows [row_lo, row_hi) (their dependency cone [row_lo - L, row_hi + L) must hold
+// valid data): (u, v) = (b_{k+1}, b_{k+2}) (GCMF_STEP_FIRST: unused, b_n = p0 * f is formed on load), f = the constant input, pk[l] =
+// the coefficient of level l + 1; GCMF_STEP_LAST: `out` receives the result, otherwise (uo, vo) the new states.  Same bits as the
+// same levels run through gcmf_cheb_multi(GCMF_STEP_CLENSHAW) in launches of 5..8.
+int gcmf_resident_levels(gcmf_plan *pl, const void *u, const void *v, void *uo, void *vo, const void *f, void *out, const double *pk, int L,
+                         double p0, double c, uint32_t mode, int64_t row_lo, int64_t row_hi, void *stream) {
+  if (!pl || !pk || !f || L < 1) {
+    set_error("gcmf_resident_levels: null argument");
+    return GCMF_ERR_INVALID_ARG;
+  }
+  const bool first = mode & GCMF_STEP_FIRST, last = mode & GCMF_STEP_LAST;
+  if ((!first && (!u || !v)) || (!last && (!uo || !vo)) || (last && !out) || (uo && (uo == u || uo == v)) || (vo && (vo == u || vo == v))) {
+    set_error("gcmf_resident_levels: missing or aliased buffers");
+    return GCMF_ERR_INVALID_ARG;
+  }
+  std::lock_guard<std::mutex> lk(pl->mu);
+  GCMF_HIP(hipSetDevice(pl->d.device));
+  MultiArgs m{};
+  m.u0 = u; m.v0 = v; m.uo = uo; m.vo = vo; m.fb_in = f; m.fb_out = out;
+  m.p0 = p0; m.c = c; m.S = L; m.first = first; m.last = last; m.nbatch = 1; m.row_lo = (int)row_lo; m.row_hi = (int)row_hi;
+  return launch_resident(pl, m, pk, L, (hipStream_t)stream);
+}
+
 int gcmf_multi_supported_vec(const gcmf_plan *pl, int S, int64_t nbatch) {
   if (!pl || nbatch < 1) return 0;
   if (pl->ncomp == 1) return multi_supported(pl, S) ? 1 : 0;
@@ -740,6 +773,48 @@ int gcmf_slab_apply_backward(gcmf_plan *pl, gcmf_comm *comm, gcmf_p2p *p2p, int 
   const bool fb32 = (dtype == GCMF_F32) && (flags & GCMF_OUT_F32);
   void *u = nullptr, *v = nullptr;
   int valid = hs, lvl = 1;
+  // ---- the slab fits on the chip: every stretch between two exchanges is ONE resident launch (gcmf_resident.hip) -- as many levels as
+  // there are ghost rows (no exchange: all of them, 64 at a time).  Same bits as the launches of 5..8 below.
+  {
+    const int per = multi ? std::min(hs, 64) : 64;
+    bool fits = nbatch == 1 && !(flags & GCMF_NO_RESIDENT) && per >= 1;
+    for (int done = 0; fits && done < n_steps;) {
+      const int L = std::min(per, n_steps - done);
+      const int vo_ = multi ? hs - L : 0;
+      std::lock_guard<std::mutex> lk(pl->mu);
+      GCMF_HIP(hipSetDevice(pl->d.device));
+      fits = resident_supported(pl, (int)(fo - (gs ? vo_ : 0)), (int)(fo + ro + (gn ? vo_ : 0)), L);
+      done += L;
+    }
+    if (fits) {
+      std::vector<double> pk(64);
+      for (int done = 0; done < n_steps;) {
+        const int L = std::min(per, n_steps - done);
+        if (multi && done > 0) {   // the ghost zone is used up: refresh it
+          void *st[2] = {u, v};
+          if ((rc = exchange_start(st, 2)) || (rc = exchange_finish())) return rc;
+        }
+        void *fr[2] = {nullptr, nullptr};
+        int nf = 0;
+        for (int k = 0; k < 4 && nf < 2; ++k)
+          if (pool[k] != u && pool[k] != v) fr[nf++] = pool[k];
+        const int vo_ = multi ? hs - L : 0;
+        MultiArgs m{};
+        m.u0 = u; m.v0 = v; m.uo = fr[0]; m.vo = fr[1]; m.fb_in = X; m.fb_out = out;
+        for (int t = 0; t < L; ++t) pk[t] = p[n_steps - (done + 1 + t)];
+        m.p0 = p[n_steps]; m.c = c; m.S = L; m.first = (done == 0); m.last = (done + L == n_steps); m.nbatch = 1;
+        m.row_lo = (int)(fo - (gs ? vo_ : 0)); m.row_hi = (int)(fo + ro + (gn ? vo_ : 0));
+        {
+          std::lock_guard<std::mutex> lk(pl->mu);
+          GCMF_HIP(hipSetDevice(pl->d.device));
+          if ((rc = launch_resident(pl, m, pk.data(), L, s))) return rc;
+        }
+        u = fr[0]; v = fr[1];
+        done += L;
+      }
+      goto land_and_guard;
+    }
+  }
   for (int q = 0; q < ncut; ++q) {
     const int S = cut[q];
     if (multi && valid < S) {
@@ -786,6 +861,7 @@ int gcmf_slab_apply_backward(gcmf_plan *pl, gcmf_comm *comm, gcmf_p2p *p2p, int 
     valid = v_out;
     lvl += S;
   }
+land_and_guard:
   if (land_ok(pl, n_steps)) {
     std::lock_guard<std::mutex> lk(pl->mu);
     GCMF_HIP(hipSetDevice(pl->d.device));
@@ -900,7 +976,41 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
     int depths[1024];
     const bool fwd_only = flags & GCMF_FORWARD_RECURRENCE;   // the caller wants the reference's forward recurrence / accumulation
     const int n_clen = (use_multi && !fwd_only) ? clenshaw_cut(pl, n_steps, depths, 1024) : 0;
-    if (n_clen > 0) {
+    // Small fields: the whole polynomial on the chip in ONE launch (64 levels at a time; gcmf_resident.hip) -- the field, both states
+    // and the coefficients live in registers / LDS, nothing but the result goes back to memory.  Same bits as the launches below.
+    bool resident = false;
+    if (n_clen > 0 && nbatch == 1 && !(flags & GCMF_NO_RESIDENT)) {
+      static const long long max_cells = getenv("GCMF_RESIDENT_MAX_CELLS") ? atoll(getenv("GCMF_RESIDENT_MAX_CELLS")) : 700000LL;
+      resident = (long long)rows * pl->g.nx <= max_cells && resident_supported(pl, 0, rows, std::min(n_steps, 64));
+    }
+    if (resident) {
+      void *pool[4] = {A[0], B[0], Cb[0], Db[0]};
+      const void *u = nullptr, *v = nullptr;
+      double pkk[64];
+      for (int done = 0; done < n_steps;) {
+        const int L = std::min(64, n_steps - done);
+        void *fr[2] = {nullptr, nullptr};
+        int nf = 0;
+        for (int q = 0; q < 4 && nf < 2; ++q)
+          if (pool[q] != u && pool[q] != v) fr[nf++] = pool[q];
+        MultiArgs m{};
+        m.u0 = u; m.v0 = v; m.uo = fr[0]; m.vo = fr[1];
+        m.fb_in = din[0]; m.fb_out = dout[0];
+        m.first = (done == 0); m.last = (done + L == n_steps); m.S = L; m.fb_is_f32 = fb32;
+        for (int t = 0; t < L; ++t) pkk[t] = p[n_steps - (done + 1 + t)];
+        m.p0 = p[n_steps]; m.c = c; m.nbatch = 1; m.row_lo = 0; m.row_hi = rows;
+        if ((rc = dom_begin(pl, s))) return rc;
+        if ((rc = launch_resident(pl, m, pkk, L, s))) return rc;
+        if ((rc = dom_end(pl, s))) return rc;
+        ++launches;
+        u = fr[0]; v = fr[1];
+        done += L;
+      }
+      if (pl->n_land > 0) {
+        if ((rc = ensure_dev_p(pl, p, n_steps, s))) return rc;
+        if ((rc = launch_land_fix(pl, din[0], dout[0], pl->dev_p, n_steps, c, fb32 ? 1 : 0, nbatch, s))) return rc;
+      }
+    } else if (n_clen > 0) {
       // Backward (Clenshaw) evaluation, gcmf_ringc_impl.hpp: state (b_{k+1}, b_{k+2}) in a pool of four planes, the constant
       // input read by every launch, no fbar planes.  The first launch forms b_n = p[n] f as it loads f; level l = 1..n uses
       // p[n - l]; the last launch writes the result.

@@ -166,6 +166,7 @@ struct gcmf_plan {
   const void *zero_row = nullptr;  // nx zeros: what rows beyond a closed boundary read as coefficients / mask bits (k_ring)
   int clenshaw = 2;       // backward (Clenshaw) evaluation: 0 off, 1 the flux kinds + C-grid, 2 (default since round 4) every kind that has a
                           // backward kernel (f64 REGULAR / land-mask kinds, B-grid too); env GCMF_CLENSHAW.  Per call: GCMF_FORWARD_RECURRENCE
+  void *resident = nullptr;  // state of the on-chip (resident) kernel: exchange planes, tile flags (gcmf_resident.hip)
   double *dev_p = nullptr;   // p[0..n_steps] of the last filter, for k_land_fix
   size_t dev_p_n = 0;
   std::vector<double> host_p;
@@ -204,6 +205,11 @@ int launch_ringc_maskz(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_ringc_flux(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_ringc_flux_slab(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);   // f64, slabs without a tripole seam: early exits (k_ringcs)
 int launch_flux_multi2(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
+// the on-chip kernel (gcmf_resident.hip): L <= 64 levels of the backward evaluation in ONE launch on a field that fits the register
+// files + LDS of the chip (short slabs, small grids); pk = the L coefficients (a.S / a.pk are ignored)
+bool resident_supported(const gcmf_plan *pl, int row_lo, int row_hi, int L);
+int launch_resident(gcmf_plan *pl, const MultiArgs &a, const double *pk, int L, hipStream_t s);
+void resident_free(gcmf_plan *pl);
 int launch_cgrid_stream(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 bool cgrid_stream_supported(const gcmf_plan *pl, const StepArgs &a);
 int launch_bgrid_stream(gcmf_plan *pl, const StepArgs &a, hipStream_t s);

@@ -1,0 +1,639 @@
+// k_resident: the filter polynomial on a field that STAYS ON THE CHIP -- "one persistent field per GPU with the whole n_steps
+// polynomial fused into a single launch, 2-D blocking with LDS-staged halo tiles" (north star), for fields small enough to live in
+// the register files and LDS of the 256 CUs: the 300-row slab one rank owns when a 2400 x 3600 grid is cut 8 ways (1.3 M cells with
+// its ghost rows), BASELINE config 1 (512 x 512), and anything else up to ~1.5 M cells (f64).
+//
+// Why.  The strip-marching kernels (k_ring / k_ringc) re-read every plane from HBM / the memory-side cache once per 5-8 levels and
+// need >= 1024 independent wave strips to fill the chip.  On a 300-row slab a strip is 11 rows tall and marches 11 + 2 S rows: 2.45 x
+// redundant, 28 us per 8-level launch, 0.256 ms per application -- the 8-GPU strong-scaling bound was 4.0 x.  Here
+// every workgroup (one per CU) owns ONE 2-D tile for the whole launch (up to 64 levels): coefficients, the constant input and both
+// Clenshaw states of its cells sit in registers (a thread owns RC consecutive cells of a tile row), the newest state is mirrored in
+// LDS so that neighbours can read it (structure-of-arrays: every LDS access is unit-stride across lanes, conflict-free), one barrier
+// per level.  Tiles carry a halo of K = 4 cells that goes stale by one cell per level; every K levels the tiles exchange their edge
+// bands THROUGH L2 / the memory-side cache: owned band cells are stored to an exchange plane, fence, a per-tile epoch flag is released
+// (agent scope), the eight neighbours' flags are acquired, halo cells are re-loaded.  Neighbour-to-neighbour, never grid-wide.  Nothing
+// but those bands (22 % of a tile) and the final result touches memory between the first load and the last store.
+//
+// Arithmetic = k_ringc's backward (Clenshaw) level, operand for operand (gcmf_ringc_impl.hpp `level`): results are bit-identical to
+// the strip-marching path however the levels are cut into launches (tests/test_gpu_resident.py).  NaN semantics: a tile runs without
+// nan_to_num until a non-finite value shows up in one of its cells (checked on everything loaded and everything produced; the flag
+// rides on the level barrier), from then on its stencil operands go through nan_to_num (kernels.py:175, 300) -- what k_ringc's redo
+// pass computes.  REGULAR has no nan_to_num in the reference (NaN spreads, kernels.py:113-121) and none here.
+//
+// Deadlock freedom: the launch is cooperative (hipLaunchCooperativeKernel: all workgroups co-resident or the launch fails), at most
+// one workgroup per CU; every flag wait is bounded (s_memrealtime) and a wait that runs out poisons the result with NaN and raises
+// the plan's sticky failure word (mapped host memory; the next call on the plan returns GCMF_ERR_HIP) -- never a hung GPU.
+// Two PROCESSES sharing one GPU must not run resident launches at the same time (each would hold CUs the other waits for): the
+// callers (SlabFilter with ranks on one device: the test set-up of this repo) serialise them with a file lock.
+#include "gcmf_multi_common.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <mutex>
+#include <string>
+
+namespace gcmf {
+
+constexpr int K_MASKZ = 5;     // (as in gcmf_scalar_multi_impl.hpp: the land-mask stencil on states whose land cells are zero)
+constexpr int RES_MAXL = 64;   // levels per launch
+constexpr int RES_NT = 512;    // threads per workgroup: two waves per SIMD with up to 256 registers each
+
+struct ResP {
+  const double *u0, *v0;   // b_{k+1}, b_{k+2} (ignored by a first launch: b_n = p_n f, b_{n+1} = 0)
+  double *uo, *vo;         // the states after L levels (not written by a last launch)
+  const double *f;         // the constant input (prepare()d and land-masked as it is loaded)
+  double *out;             // last launch: the result
+  const double *cE, *cN, *ra;   // K_FLUX
+  const uint8_t *mbits;         // K_MASKZ
+  const uint8_t *lbits;         // land bits (bit 0: the cell exchanges with a neighbour) or NULL
+  const double *area;           // area-weighted types or NULL
+  double *ex[2][2];        // exchange planes [parity][state]
+  unsigned *flags;         // one epoch word per tile
+  unsigned *fail;          // sticky failure word (device address of mapped host memory)
+  unsigned epoch0;
+  int nx, rows;            // the plan's slab allocation
+  int r_lo, r_hi;          // rows this launch keeps alive (the dependency cone of out_lo .. out_hi)
+  int out_lo, out_hi;      // rows stored at the end
+  int nty, ntx, nruns, K, L;
+  int wrap;                // y-periodic and the region is the whole domain
+  int first, last;
+  int xcd_per;             // tiles per XCD when the tile count is a multiple of 8 (neighbouring tiles share an L2), else 0
+  double pk[RES_MAXL];
+  double p0, c;
+  long long spin_limit;
+};
+
+__device__ __forceinline__ bool res_finite(double x) { return __builtin_fabs(x) <= DBL_MAX; }   // false for NaN and +-inf
+
+// The exchange planes and the tile flags are written by one XCD and read by another INSIDE one kernel; the XCDs' L2s are not coherent
+// with each other for ordinary (coarse-grained) memory.  Agent-scope fences would make them so -- at a whole-L2 write-back / invalidate
+// per wave: the first version of this kernel spent 130 us per exchange in them (8 waves x 32 workgroups per XCD, serialised at the L2).
+// Per-access device-scope (sc1) atomics on ordinary memory turned out NOT to be enough (sporadic stale halos) and serialise (26 dependent
+// round trips per edge thread).  So the exchange planes and flags live in UNCACHED device memory (hipDeviceMallocUncached: MTYPE UC,
+// every access goes to the memory side, where the 256 MB memory-side cache is shared by all XCDs): plain loads and stores, issued in
+// batches, ordered by "all my stores acknowledged (vmcnt 0) -> workgroup barrier -> flag store" on the writer's side and "flag seen
+// -> workgroup barrier -> loads" on the reader's.
+__device__ __forceinline__ void dev_store(double *p, double v) { *p = v; }
+// loads go past the CU's vector L1 (device scope: sc1), which may still hold the line from two exchanges ago (same parity, same address):
+// measured -- plain loads returned stale halos from the third exchange on; a `buffer_inv sc0` does nothing outside threadgroup-split
+// mode and a `buffer_inv sc1` per wave costs 15 us per exchange
+__device__ __forceinline__ double dev_load(const double *p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+}
+
+template <int KIND, int RC>
+__global__ __launch_bounds__(RES_NT, 2) void k_resident(const ResP P) {
+  constexpr bool FLUX = (KIND == K_FLUX), MASK = (KIND == K_MASKZ);
+  constexpr bool WATCH = (KIND != K_REG);
+  // the deepest flux instantiation keeps the constant input in LDS (a third plane) instead of 2 * RC registers: 256 registers spilled
+  constexpr bool FLDS = FLUX && RC >= 13;
+  extern __shared__ double xs[];                 // [2][RC][RES_NT]: the newest state b_{k+1} of every cell of the padded tile (+ [RC][RES_NT]: f)
+  __shared__ unsigned s_bad[2];                  // a non-finite value was seen in this tile (double-buffered with the level parity)
+  __shared__ int s_fail;
+  int bx = blockIdx.x;
+  if (P.xcd_per > 0) bx = (bx & 7) * P.xcd_per + (bx >> 3);
+  const int ty = bx / P.ntx, tx = bx - ty * P.ntx;
+  const int tid = threadIdx.x;
+  const int nx = P.nx, rows = P.rows, K = P.K, nruns = P.nruns;
+  const int Rr = P.r_hi - P.r_lo;
+  const int r0 = P.r_lo + (int)((long long)ty * Rr / P.nty), r1 = P.r_lo + (int)((long long)(ty + 1) * Rr / P.nty);
+  const int c0 = (int)((long long)tx * nx / P.ntx), c1 = (int)((long long)(tx + 1) * nx / P.ntx);
+  const int PH = (r1 - r0) + 2 * K, w = c1 - c0, PW = nruns * RC;
+  const int prow = tid / nruns, run = tid - prow * nruns;
+  const bool active = prow < PH;
+  const int pc0 = run * RC;
+
+  // ---- where cells are ---------------------------------------------------------------------------------------------------------
+  // padded-tile row pr / column pc -> row / column of the plan's planes; -1: dead (outside the rows this launch keeps alive, or a
+  // padding column): zero coefficients, zero state, never exchanged
+  auto grow = [&](int pr) {
+    int g = r0 - K + pr;
+    if (P.wrap) return g < 0 ? g + rows : (g >= rows ? g - rows : g);
+    return (g >= P.r_lo && g < P.r_hi) ? g : -1;
+  };
+  auto gcolp = [&](int pc) {
+    if (pc >= w + 2 * K) return -1;
+    int g = c0 - K + pc;
+    g = g < 0 ? g + nx : g;
+    while (g >= nx) g -= nx;
+    return g;
+  };
+  const int gr = active ? grow(prow) : -1;
+  const bool own_row = active && prow >= K && prow < PH - K && gr >= 0;
+  unsigned owned = 0u, band = 0u, halo = 0u;   // bit c: cell c of this thread is ...
+#pragma unroll
+  for (int c = 0; c < RC; ++c) {
+    const int pc = pc0 + c;
+    const bool lv = gr >= 0 && pc < w + 2 * K;
+    const bool ow = lv && own_row && pc >= K && pc < K + w;
+    const bool bd = ow && (prow < 2 * K || prow >= PH - 2 * K || pc < 2 * K || pc >= w);
+    owned |= ow ? (1u << c) : 0u;
+    band |= bd ? (1u << c) : 0u;
+    halo |= (lv && !ow) ? (1u << c) : 0u;
+  }
+  const long long rbase = (long long)gr * nx;
+  auto gcol = [&](int c) { return gcolp(pc0 + c); };
+  // LDS neighbours (threads): the padded edge reads itself (garbage that never reaches a valid cell: the halo is K deep)
+  const int tN = (active && prow + 1 < PH && !(!P.wrap && gr == rows - 1)) ? tid + nruns : tid;
+  const int tS = (active && prow >= 1 && !(!P.wrap && gr == 0)) ? tid - nruns : tid;
+  const int tW = run > 0 ? tid - 1 : tid;
+  const int tE = (run < nruns - 1) ? tid + 1 : tid;
+
+  // ---- load: planes come in COALESCED (consecutive lanes = consecutive cells of a padded-tile row), are staged row-major in LDS and
+  // picked up by their owners (a thread's RC cells are consecutive there) -------------------------------------------------------------
+  // flat element e = k * RES_NT + tid of the padded tile -> offset in the plan's planes, -1 = dead
+  auto offs = [&](int k) {
+    const int e = k * RES_NT + tid;
+    int o = -1;
+    if (e < PH * PW) {
+      const int pr = e / PW, pc = e - pr * PW;
+      const int g = grow(pr), gc_ = gcolp(pc);
+      if (g >= 0 && gc_ >= 0) o = g * nx + gc_;
+    }
+    return o;
+  };
+  int goff[RC];        // (the load phase only: the store phase recomputes them instead of keeping RC registers through the levels)
+#pragma unroll
+  for (int k = 0; k < RC; ++k) goff[k] = offs(k);
+  double *stg = xs;                               // staging: PH * PW <= RC * RES_NT doubles
+  auto stage = [&](const double *plane) {        // (call between barriers)
+#pragma unroll
+    for (int k = 0; k < RC; ++k) {
+      const int e = k * RES_NT + tid;
+      if (e < PH * PW) stg[e] = goff[k] >= 0 ? plane[goff[k]] : 0.0;
+    }
+  };
+  const int mine = prow * PW + pc0;               // my first cell in the staged tile
+  double b1[RC], b2[RC], ff[FLDS ? 1 : RC];
+  double *fl = xs + 2 * RC * RES_NT;
+  double cEr[FLUX ? RC + 1 : 1], cNr[FLUX ? RC : 1], cSr[FLUX ? RC : 1], rar[FLUX ? RC : 1];
+  unsigned mb[MASK ? RC : 1];
+  bool bad = false;
+  if (tid == 0) { s_bad[0] = 0u; s_bad[1] = 0u; s_fail = 0; }
+  // the constant input: prepare()d (x area, kernels.py:100-101) and land-masked as it is staged
+#pragma unroll
+  for (int k = 0; k < RC; ++k) {
+    const int e = k * RES_NT + tid;
+    if (e < PH * PW) {
+      double fv = 0.0;
+      if (goff[k] >= 0) {
+        fv = P.f[goff[k]];
+        if (P.area) fv = fv * P.area[goff[k]];
+        if (P.lbits && !(P.lbits[goff[k]] & 1u)) fv = 0.0;
+      }
+      stg[e] = fv;
+    }
+  }
+  __syncthreads();
+  double fown[RC];
+#pragma unroll
+  for (int c = 0; c < RC; ++c) fown[c] = active ? stg[mine + c] : 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < RC; ++c) {
+    if constexpr (FLDS) fl[c * RES_NT + tid] = fown[c];
+    else ff[c] = fown[c];
+    if (WATCH) bad = bad || !res_finite(fown[c]);
+  }
+  if (P.first) {
+#pragma unroll
+    for (int c = 0; c < RC; ++c) {
+      b1[c] = P.p0 * fown[c];                      // b_n = p_n f (f is zero on land and on dead cells), b_{n+1} = 0
+      b2[c] = 0.0;
+    }
+  } else {
+    stage(P.u0);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < RC; ++c) b1[c] = active ? stg[mine + c] : 0.0;
+    __syncthreads();
+    stage(P.v0);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < RC; ++c) b2[c] = active ? stg[mine + c] : 0.0;
+    __syncthreads();
+    if (WATCH) {
+#pragma unroll
+      for (int c = 0; c < RC; ++c) bad = bad || !(res_finite(b1[c]) && res_finite(b2[c]));
+    }
+  }
+  if constexpr (FLUX) {
+    stage(P.cE);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < RC; ++c) cEr[c + 1] = active ? stg[mine + c] : 0.0;
+    cEr[0] = (active && pc0 > 0) ? stg[mine - 1] : 0.0;    // the east face of the cell west of my run (run 0: a padded edge, garbage anyway)
+    __syncthreads();
+    stage(P.cN);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < RC; ++c) {
+      cNr[c] = active ? stg[mine + c] : 0.0;
+      cSr[c] = (active && prow > 0) ? stg[mine - PW + c] : 0.0;   // the north face of the row below (dead rows: zero, no flux)
+    }
+    __syncthreads();
+    stage(P.ra);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < RC; ++c) rar[c] = active ? stg[mine + c] : 0.0;
+    __syncthreads();
+  }
+  if constexpr (MASK) {
+    unsigned *stu = reinterpret_cast<unsigned *>(stg);
+#pragma unroll
+    for (int k = 0; k < RC; ++k) {
+      const int e = k * RES_NT + tid;
+      if (e < PH * PW) stu[e] = goff[k] >= 0 ? (unsigned)P.mbits[goff[k]] : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < RC; ++c) mb[c] = active ? stu[mine + c] : 0u;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int c = 0; c < RC; ++c) xs[c * RES_NT + tid] = b1[c];
+  if (WATCH && bad) s_bad[0] = 1u;
+  __syncthreads();
+
+  bool sani = false;
+  unsigned epoch = P.epoch0;
+  const double cc = P.c;
+
+  auto level = [&](auto sani_c, int l) {
+    constexpr bool SANI = decltype(sani_c)::value;
+    const double *cur = xs + (l & 1) * (RC * RES_NT);
+    double *nxt = xs + ((l + 1) & 1) * (RC * RES_NT);
+    const double pk = P.pk[l];
+    const double two = (P.last && l == P.L - 1) ? 1.0 : 2.0;   // the last level of a filter is p_0 f + A(b_1) - b_2: A, not 2 A
+    auto sn = [&](double x) { return SANI ? msan(x) : x; };
+    const double xW = sn(cur[(RC - 1) * RES_NT + tW]);
+    const double xE = sn(cur[tE]);
+    double xc[RC];
+#pragma unroll
+    for (int c = 0; c < RC; ++c) xc[c] = sn(b1[c]);
+    double fprev = 0.0;
+    if constexpr (FLUX) fprev = (xc[0] - xW) * cEr[0];
+    bool bd = false;
+#pragma unroll
+    for (int c = 0; c < RC; ++c) {
+      const double xn = sn(cur[c * RES_NT + tN]);
+      const double xsv = sn(cur[c * RES_NT + tS]);
+      const double xe = (c == RC - 1) ? xE : xc[c < RC - 1 ? c + 1 : c];
+      double Lp;
+      if constexpr (FLUX) {
+        const double fe = (xe - xc[c]) * cEr[c + 1];
+        const double fw = fprev;
+        fprev = fe;
+        const double fn = (xn - xc[c]) * cNr[c];
+        const double fs = (xc[c] - xsv) * cSr[c];
+        Lp = (fe - fw + fn - fs) * rar[c];
+      } else {
+        const double xw = (c == 0) ? xW : xc[c > 0 ? c - 1 : 0];
+        if constexpr (MASK) {
+          const unsigned bb = mb[c];
+          const double wf = (double)(bb >> 5);
+          Lp = rfma(-wf, xc[c], xe);
+          Lp = Lp + xw;
+          Lp = Lp + xn;
+          Lp = Lp + xsv;
+          Lp = (bb & 1u) ? Lp : 0.0;
+        } else {
+          Lp = rfma(-4.0, xc[c], xe);
+          Lp = Lp + xw;
+          Lp = Lp + xn;
+          Lp = Lp + xsv;
+        }
+      }
+      const double av = cheb_a<true>(b1[c], cc, Lp);        // "-x" takes the raw value: a NaN stays in its cell (filter.py:166-175)
+      double tk = rfma(two, av, -b2[c]);
+      tk = rfma(pk, FLDS ? fl[c * RES_NT + tid] : ff[FLDS ? 0 : c], tk);
+      b2[c] = b1[c];
+      b1[c] = tk;
+      nxt[c * RES_NT + tid] = tk;
+      if (WATCH && !SANI) bd = bd || !res_finite(tk);
+    }
+    if (WATCH && !SANI && bd) s_bad[(l + 1) & 1] = 1u;
+  };
+
+  for (int l = 0; l < P.L; ++l) {
+    if (WATCH && !sani && s_bad[l & 1]) sani = true;       // (uniform: written before the barrier that ended the previous level)
+    if (active) {
+      if (sani) level(std::true_type{}, l);
+      else level(std::false_type{}, l);
+    }
+    __syncthreads();
+    if ((l + 1) % K == 0 && l + 1 < P.L) {
+      // ---- trade the edge bands with the eight neighbour tiles through L2 / the memory-side cache: band cells out (device-scope
+      // stores), all of them performed (vmcnt), barrier, ONE flag store; eight lanes poll the neighbours' flags, barrier, halo cells in
+      // (device-scope loads).  No L2-wide fence anywhere. -----------------------------------------------------------------------------
+      ++epoch;
+      double *e1 = P.ex[epoch & 1][0], *e2 = P.ex[epoch & 1][1];
+      if (band) {
+#pragma unroll
+        for (int c = 0; c < RC; ++c)
+          if ((band >> c) & 1u) {
+            dev_store(&e1[rbase + gcol(c)], b1[c]);
+            dev_store(&e2[rbase + gcol(c)], b2[c]);
+          }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_s_waitcnt(0);                             // every store of this wave has been acknowledged by the memory side
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(&P.flags[bx], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid >= 1 && tid <= 8) {
+        const int q = tid - 1 + (tid - 1 >= 4 ? 1 : 0);          // 0..8 without the centre
+        int ny_ = ty + q / 3 - 1, nx_ = tx + q % 3 - 1;
+        nx_ = nx_ < 0 ? nx_ + P.ntx : (nx_ >= P.ntx ? nx_ - P.ntx : nx_);
+        bool there = true;
+        if (ny_ < 0 || ny_ >= P.nty) {
+          if (P.wrap) ny_ = ny_ < 0 ? ny_ + P.nty : ny_ - P.nty;
+          else there = false;                                      // the region ends here: those halo rows are dead
+        }
+        if (there) {
+          const unsigned *fl_ = &P.flags[ny_ * P.ntx + nx_];
+          const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+          for (;;) {
+            const unsigned v = __hip_atomic_load(fl_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((int)(v - epoch) >= 0) break;
+            // (the failure word lives in mapped HOST memory: it is written on a time-out, never polled -- a read of it is a PCIe
+            // round trip, and 2048 lanes polling it cost 30 us per exchange in the first version)
+            if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > P.spin_limit) {
+              __hip_atomic_store(P.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              s_fail = 1;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+      }
+      __syncthreads();
+      if (halo) {
+        double *nxt = xs + ((l + 1) & 1) * (RC * RES_NT);
+        bool bd = false;
+#pragma unroll
+        for (int c = 0; c < RC; ++c)                              // (all loads first: they overlap)
+          if ((halo >> c) & 1u) {
+            b1[c] = dev_load(&e1[rbase + gcol(c)]);
+            b2[c] = dev_load(&e2[rbase + gcol(c)]);
+          }
+#pragma unroll
+        for (int c = 0; c < RC; ++c)
+          if ((halo >> c) & 1u) {
+            nxt[c * RES_NT + tid] = b1[c];
+            if (WATCH) bd = bd || !(res_finite(b1[c]) && res_finite(b2[c]));
+          }
+        if (WATCH && bd) s_bad[(l + 1) & 1] = 1u;
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- store: owners put their cells into the staged tile, consecutive lanes write consecutive cells --------------------------------
+  const bool failed = s_fail != 0;
+  const double poison = __longlong_as_double(-1LL);
+  auto unstage = [&](double *plane, bool finalize) {      // (call between barriers)
+#pragma unroll
+    for (int k = 0; k < RC; ++k) {
+      const int e = k * RES_NT + tid;
+      const int o = offs(k);
+      if (o >= 0) {
+        const int pr = e / PW, pc = e - pr * PW;
+        const int g = o / nx;
+        if (pr >= K && pr < PH - K && pc >= K && pc < K + w && g >= P.out_lo && g < P.out_hi) {
+          double r = stg[e];
+          if (finalize && P.area) r = r / P.area[o];         // finalize(): / area (kernels.py:103-104)
+          plane[o] = failed ? poison : r;
+        }
+      }
+    }
+  };
+  if (active) {
+#pragma unroll
+    for (int c = 0; c < RC; ++c) stg[mine + c] = b1[c];
+  }
+  __syncthreads();
+  unstage(P.last ? P.out : P.uo, P.last);
+  if (!P.last) {
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int c = 0; c < RC; ++c) stg[mine + c] = b2[c];
+    }
+    __syncthreads();
+    unstage(P.vo, false);
+  }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------------------
+
+struct ResGeom {
+  int rc = 0, nty = 0, ntx = 0, nruns = 0;
+  long long cost = 0;
+};
+
+// tiles for a region of Rr rows x nx columns on at most max_wg workgroups: a thread owns RC cells of a padded tile row, a workgroup
+// has RES_NT threads and 2 * RC * RES_NT * 8 bytes of LDS.  The cheapest geometry = the fewest padded cells per workgroup.
+static ResGeom res_geometry(int kind, int Rr, int nx, int K, int max_wg) {
+  ResGeom best;
+  const int rcs_flux[] = {4, 8, 13}, rcs_other[] = {4, 8, 13, 16};
+  const int *rcs = kind == K_FLUX ? rcs_flux : rcs_other;
+  const int nrc = kind == K_FLUX ? 3 : 4;
+  for (int q = 0; q < nrc; ++q) {
+    const int RC = rcs[q];
+    for (int ntx = 1; ntx <= max_wg && ntx <= nx; ++ntx) {
+      const int w = (nx + ntx - 1) / ntx;
+      if (nx / ntx < K) continue;                            // a halo must come from the direct neighbour
+      const int nruns = (w + 2 * K + RC - 1) / RC;
+      const int ph_max = RES_NT / nruns;
+      if (ph_max <= 2 * K) continue;
+      const int nty_min = (Rr + (ph_max - 2 * K) - 1) / (ph_max - 2 * K);
+      int nty = std::min(max_wg / ntx, Rr / K > 0 ? Rr / K : 1);   // (tiles at least K rows tall)
+      if (nty < nty_min || nty < 1) continue;
+      const int h = (Rr + nty - 1) / nty;
+      const long long cost = (long long)RC * nruns * (h + 2 * K);
+      if (!best.rc || cost < best.cost || (cost == best.cost && nty * ntx < best.nty * best.ntx)) {
+        best.rc = RC; best.nty = nty; best.ntx = ntx; best.nruns = nruns; best.cost = cost;
+      }
+    }
+  }
+  return best;
+}
+
+struct ResState {      // per plan (lazily built)
+  double *ex = nullptr;        // four exchange planes
+  size_t ex_bytes = 0;
+  unsigned *flags = nullptr;   // 1024 epoch words
+  unsigned *fail_host = nullptr, *fail_dev = nullptr;
+  unsigned epoch = 0;
+  int max_wg = 0;
+};
+
+}  // namespace gcmf
+
+using namespace gcmf;
+
+namespace gcmf {
+void resident_free(gcmf_plan *pl) {   // gcmf_plan_destroy
+  ResState *st = (ResState *)pl->resident;
+  if (!st) return;
+  if (st->ex) (void)hipFree(st->ex);
+  if (st->flags) (void)hipFree(st->flags);
+  if (st->fail_host) (void)hipHostFree(st->fail_host);
+  delete st;
+  pl->resident = nullptr;
+}
+}  // namespace gcmf
+
+template <int KIND, int RC> static int res_launch(const ResP &P, int nwg, hipStream_t s) {
+  const size_t lds = (size_t)((KIND == K_FLUX && RC >= 13) ? 3 : 2) * RC * RES_NT * sizeof(double);
+  static bool attr_done = false;
+  if (!attr_done) {
+    GCMF_HIP(hipFuncSetAttribute((const void *)k_resident<KIND, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  // A plain launch: the grid has at most one workgroup per CU, so every workgroup becomes resident as soon as whatever ran before on
+  // the chip has drained (ordinary kernels always finish).  GCMF_RESIDENT_COOP=1 asks the runtime to guarantee it instead
+  // (hipLaunchCooperativeKernel: its cooperative queue costs a cross-queue dependency per launch).
+  static const bool coop = getenv("GCMF_RESIDENT_COOP") && atoi(getenv("GCMF_RESIDENT_COOP")) != 0;
+  if (coop) {
+    ResP Pc = P;
+    void *args[] = {(void *)&Pc};
+    GCMF_HIP(hipLaunchCooperativeKernel((const void *)k_resident<KIND, RC>, dim3(nwg), dim3(RES_NT), args, (unsigned)lds, s));
+  } else {
+    hipLaunchKernelGGL((k_resident<KIND, RC>), dim3(nwg), dim3(RES_NT), lds, s, P);
+    GCMF_HIP(hipGetLastError());
+  }
+  return GCMF_OK;
+}
+
+template <int KIND> static int res_launch_kind(int rc, const ResP &P, int nwg, hipStream_t s) {
+  switch (rc) {
+    case 4: return res_launch<KIND, 4>(P, nwg, s);
+    case 8: return res_launch<KIND, 8>(P, nwg, s);
+    case 13: return res_launch<KIND, 13>(P, nwg, s);
+    case 16:
+      if constexpr (KIND != K_FLUX) return res_launch<KIND, 16>(P, nwg, s);
+  }
+  set_error("k_resident: no instantiation for %d cells per thread", rc);
+  return GCMF_ERR_INVALID_ARG;
+}
+
+static int res_kind(const gcmf_plan *pl) {
+  // K_MASK plans run the land-zeroed form (K_MASKZ) of the stencil, as k_ringc does (land is masked out of f as it is loaded)
+  return pl->kind == K_MASK ? K_MASKZ : pl->kind;
+}
+
+// Can L levels with output rows [row_lo, row_hi) of this plan run resident?  (f64 scalar plans without a tripole seam in the region.)
+static bool res_supported(const gcmf_plan *pl, int row_lo, int row_hi, int L, ResGeom *g_out, int *r_lo_out, int *r_hi_out, bool *wrap_out) {
+  if (!pl || pl->ncomp != 1 || pl->d.dtype != GCMF_F64 || L < 1 || L > RES_MAXL) return false;
+  if (!(pl->kind == K_FLUX || pl->kind == K_MASK || pl->kind == K_REG)) return false;
+  if (pl->kind == K_MASK && !pl->g.mbits) return false;
+  const int rows = pl->g.rows;
+  if (row_lo < 0 || row_hi > rows || row_hi <= row_lo) return false;
+  const bool whole = (row_lo == 0 && row_hi == rows);
+  const bool wrap = whole && pl->g.south_wrap && pl->g.north_wrap;
+  int r_lo = wrap ? 0 : std::max(0, row_lo - L), r_hi = wrap ? rows : std::min(rows, row_hi + L);
+  if (pl->g.fold && r_hi == rows) return false;          // the tripole seam is not handled here (k_fold_band's job)
+  if (whole && !wrap && !pl->g.fold) {
+    // closed / clamped ends of a single slab: handled (dead rows beyond, clamped neighbours), as k_ringc does
+  }
+  int dev = 0, ncu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+  if (const char *e = getenv("GCMF_RESIDENT_MAX_WG")) ncu = std::min(ncu, std::max(1, atoi(e)));
+  const int K = 4;
+  const ResGeom g = res_geometry(res_kind(pl), r_hi - r_lo, pl->g.nx, K, ncu);
+  if (!g.rc) return false;
+  if (g_out) *g_out = g;
+  if (r_lo_out) *r_lo_out = r_lo;
+  if (r_hi_out) *r_hi_out = r_hi;
+  if (wrap_out) *wrap_out = wrap;
+  return true;
+}
+
+namespace gcmf {
+
+bool resident_supported(const gcmf_plan *pl, int row_lo, int row_hi, int L) {
+  if (const char *e = getenv("GCMF_RESIDENT"))
+    if (atoi(e) == 0) return false;
+  return res_supported(pl, row_lo, row_hi, L, nullptr, nullptr, nullptr, nullptr);
+}
+
+// L levels (a.S is ignored: pk = the L coefficients) of the backward evaluation on rows [a.row_lo, a.row_hi), one launch.
+// The plan's mutex is held and its device is current.
+int launch_resident(gcmf_plan *pl, const MultiArgs &a, const double *pk, int L, hipStream_t s) {
+  ResGeom g;
+  int r_lo = 0, r_hi = 0;
+  bool wrap = false;
+  if (!res_supported(pl, a.row_lo, a.row_hi, L, &g, &r_lo, &r_hi, &wrap)) {
+    set_error("k_resident: rows [%d, %d) x %d levels of this plan do not fit on the chip", a.row_lo, a.row_hi, L);
+    return GCMF_ERR_UNSUPPORTED;
+  }
+  if (a.nbatch != 1) {
+    set_error("k_resident: one field per launch");
+    return GCMF_ERR_UNSUPPORTED;
+  }
+  if (!pl->resident) pl->resident = new ResState();
+  ResState *st = (ResState *)pl->resident;
+  const size_t plane = (size_t)pl->g.rows * pl->g.nx * sizeof(double);
+  if (!st->flags) {
+    GCMF_HIP(hipExtMallocWithFlags((void **)&st->flags, 1024 * sizeof(unsigned), hipDeviceMallocUncached));
+    GCMF_HIP(hipMemsetAsync(st->flags, 0, 1024 * sizeof(unsigned), s));
+    GCMF_HIP(hipHostMalloc((void **)&st->fail_host, 64, hipHostMallocMapped));
+    *st->fail_host = 0u;
+    GCMF_HIP(hipHostGetDevicePointer((void **)&st->fail_dev, st->fail_host, 0));
+  }
+  if (st->ex_bytes < 4 * plane) {
+    if (st->ex) {
+      GCMF_HIP(hipStreamSynchronize(s));
+      (void)hipFree(st->ex);
+      st->ex = nullptr;
+    }
+    GCMF_HIP(hipExtMallocWithFlags((void **)&st->ex, 4 * plane, hipDeviceMallocUncached));
+    st->ex_bytes = 4 * plane;
+  }
+  if (__atomic_load_n(st->fail_host, __ATOMIC_ACQUIRE)) {
+    set_error("k_resident: an earlier resident launch of this plan timed out waiting for a neighbour tile (was another process "
+              "running a resident kernel on this GPU?); its results are NaN");
+    return GCMF_ERR_HIP;
+  }
+  const Geom &gm = pl->g;
+  ResP P{};
+  P.u0 = (const double *)a.u0; P.v0 = (const double *)a.v0; P.uo = (double *)a.uo; P.vo = (double *)a.vo;
+  P.f = (const double *)a.fb_in; P.out = (double *)a.fb_out;
+  P.cE = (const double *)gm.coef[0]; P.cN = (const double *)gm.coef[1]; P.ra = (const double *)gm.coef[2];
+  P.mbits = gm.mbits;
+  P.lbits = (pl->n_land > 0) ? pl->lbits : nullptr;
+  P.area = (pl->kind != K_FLUX && gm.area_weighted) ? (const double *)gm.area : nullptr;
+  for (int par = 0; par < 2; ++par)
+    for (int q = 0; q < 2; ++q) P.ex[par][q] = (double *)((char *)st->ex + (size_t)(par * 2 + q) * plane);
+  P.flags = st->flags;
+  P.fail = st->fail_dev;
+  P.epoch0 = st->epoch;
+  P.nx = gm.nx; P.rows = gm.rows;
+  P.r_lo = r_lo; P.r_hi = r_hi; P.out_lo = a.row_lo; P.out_hi = a.row_hi;
+  P.nty = g.nty; P.ntx = g.ntx; P.nruns = g.nruns; P.K = 4; P.L = L;
+  P.wrap = wrap ? 1 : 0;
+  P.first = a.first; P.last = a.last;
+  const int nwg = g.nty * g.ntx;
+  P.xcd_per = (pl->xcd_remap && nwg % 8 == 0) ? nwg / 8 : 0;
+  for (int t = 0; t < RES_MAXL; ++t) P.pk[t] = t < L ? pk[t] : 0.0;
+  P.p0 = a.p0; P.c = a.c;
+  long long ms = 2000;
+  if (const char *e = getenv("GCMF_RESIDENT_TIMEOUT_MS")) ms = std::max(1LL, atoll(e));
+  P.spin_limit = ms * 100000LL;
+  st->epoch += (unsigned)((L - 1) / P.K);
+  int rc;
+  switch (res_kind(pl)) {
+    case K_FLUX: rc = res_launch_kind<K_FLUX>(g.rc, P, nwg, s); break;
+    case K_MASKZ: rc = res_launch_kind<K_MASKZ>(g.rc, P, nwg, s); break;
+    default: rc = res_launch_kind<K_REG>(g.rc, P, nwg, s); break;
+  }
+  if (rc) return rc;
+  char geom[160];
+  snprintf(geom, sizeof geom, "tiles=%dx%d RC=%d nruns=%d K=%d L=%d rowlo=%d rowhi=%d", g.nty, g.ntx, g.rc, g.nruns, P.K, L, r_lo, r_hi);
+  note_kernel(pl, std::string("gcmf::k_resident<") + std::to_string(res_kind(pl)) + ", " + std::to_string(g.rc) + ">", L, geom);
+  return GCMF_OK;
+}
+
+}  // namespace gcmf

@@ -75,6 +75,8 @@ typedef enum gcmf_dtype { GCMF_F32 = 0, GCMF_F64 = 1 } gcmf_dtype;
                               /* recurrence with its accumulation scheme (filter.py:192-206: f64 running sum   */
                               /* also for f32 state) even where the library would evaluate it backwards        */
                               /* (Clenshaw: f64 flux-form plans, C-grid plans)                                  */
+#define GCMF_NO_RESIDENT 0x8u /* gcmf_apply / gcmf_slab_apply_backward: never use the on-chip (resident) kernel,   */
+                              /* csrc/gcmf_resident.hip -- the strip-marching launches of 5..8 levels instead (same bits) */
 
 /* Chebyshev step modes for gcmf_cheb_step */
 #define GCMF_STEP_FIRST 0x1u /* T1 = A(T0);            fbar  = p0*T0 + p1*T1                  */
@@ -328,6 +330,20 @@ void gcmf_p2p_destroy(gcmf_p2p *p);
 int gcmf_slab_apply_backward(gcmf_plan *plan, gcmf_comm *comm, gcmf_p2p *p2p, int south, int north, const double *p, int n_steps, double c,
                              const int *cut, int ncut, void *X, void *const *pool, void *out, int64_t nbatch, int halo, int overlap,
                              uint32_t flags, void *stream);
+
+/* ---- the on-chip (resident) kernel, csrc/gcmf_resident.hip: the north star's "one persistent field per GPU with the whole n_steps
+ * polynomial fused into a single launch, 2-D blocking with LDS-staged halo tiles", for fields that fit the register files + LDS of the
+ * chip (the 300-row slab of an 8-way cut of 2400 x 3600 with its ghost rows; 512 x 512; up to ~1.5 M f64 cells).  One workgroup per CU owns
+ * a 2-D tile for up to 64 levels of the backward (Clenshaw) evaluation of filter.py:162-212's polynomial; tiles trade their 4-cell edge
+ * bands through L2 with per-tile epoch flags every 4 levels.  gcmf_apply and gcmf_slab_apply_backward use it by themselves when it fits
+ * and pays (GCMF_NO_RESIDENT / env GCMF_RESIDENT=0 turn it off); these two entries are the building block.
+ * gcmf_resident_supported: can L levels with output rows [row_lo, row_hi) run in one resident launch?  gcmf_resident_levels: run them --
+ * (u, v) = (b_{k+1}, b_{k+2}) (GCMF_STEP_FIRST: unused), f = the constant input, pk[l] = coefficient of level l + 1, p0 = p_n;
+ * GCMF_STEP_LAST: `out` gets the result, otherwise (uo, vo) the new states.  Bit-identical to the same levels through gcmf_cheb_multi
+ * with GCMF_STEP_CLENSHAW.  Two PROCESSES must not run resident launches on one GPU at the same time (see the file's header). */
+int gcmf_resident_supported(const gcmf_plan *plan, int64_t row_lo, int64_t row_hi, int L);
+int gcmf_resident_levels(gcmf_plan *plan, const void *u, const void *v, void *uo, void *vo, const void *f, void *out, const double *pk,
+                         int L, double p0, double c, uint32_t mode, int64_t row_lo, int64_t row_hi, void *stream);
 
 
 /* Tunables: rows marched per wave of the single-step kernel (0 keeps the default); XCD-aware tile order

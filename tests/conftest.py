@@ -21,7 +21,7 @@ def pytest_configure(config):
 # and the multi-process orchestration tests (torchrun children, IPC, time-outs: the flakiest kind) last, so that one of those can
 # never hide the parity suite again (round 3: one two-rank bench test, first in alphabetical order, kept 587 parity tests from running).
 _ORDER = ["test_c_abi_program", "test_gpu_parity", "test_gpu_clenshaw", "test_gpu_fullsize", "test_gpu_xarray", "test_gpu_grid_helpers",
-          "test_gpu_host_blocks", "test_gpu_short_slab", "test_gpu_exchange", "test_gpu_distributed", "test_gpu_bench_cli"]
+          "test_gpu_host_blocks", "test_gpu_resident", "test_gpu_exchange", "test_gpu_distributed", "test_gpu_bench_cli"]
 
 
 def pytest_collection_modifyitems(session, config, items):

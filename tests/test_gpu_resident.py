@@ -1,0 +1,138 @@
+"""The on-chip (resident) kernel, csrc/gcmf_resident.hip: up to 64 levels of the backward (Clenshaw) evaluation in ONE launch on a field
+that lives in the register files + LDS of the chip -- against the strip-marching launches of 5..8 levels (bit for bit: the arithmetic of
+a level is the same, operand for operand), against the oracle, and on row slabs (the 8-GPU geometry of BASELINE configs 3 / 4)."""
+import numpy as np
+import pytest
+
+from gcm_filters_amd import Filter, FilterShape, GridType, _lib, testing as T
+from gcm_filters_amd.kernels import ALL_KERNELS
+from oracle import gcmf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _levels_by_launches(plan, f, p, c, n, cut, torch):
+    """The n levels as launches of 5..8 (gcmf_cheb_multi, GCMF_STEP_CLENSHAW) over the whole domain."""
+    rows = f.shape[-2]
+    pool = [torch.zeros_like(f) for _ in range(4)]
+    out = torch.zeros_like(f)
+    u = v = None
+    lvl = 1
+    for q, S in enumerate(cut):
+        free = [b for b in pool if b is not u and b is not v]
+        mode = _lib.STEP_CLENSHAW | (_lib.STEP_FIRST if q == 0 else 0) | (_lib.STEP_LAST if q == len(cut) - 1 else 0)
+        pk = p[n - lvl - S + 1: n - lvl + 1][::-1]
+        plan.cheb_multi_vec(None if u is None else [u.data_ptr()], None if v is None else [v.data_ptr()], [free[0].data_ptr()],
+                            [free[1].data_ptr()], [f.data_ptr()], [out.data_ptr()], pk, p[n], c, mode, 1, 0, rows,
+                            stream=torch.cuda.current_stream().cuda_stream)
+        u, v = free[0], free[1]
+        lvl += S
+    return out, u, v
+
+
+@pytest.mark.parametrize("grid,shape,n", [
+    ("IRREGULAR_WITH_LAND", (96, 160), 16), ("IRREGULAR_WITH_LAND", (300, 364), 63), ("IRREGULAR_WITH_LAND", (37, 52), 11),
+    ("MOM5U", (64, 96), 21), ("MOM5T", (100, 72), 13), ("REGULAR", (128, 128), 16), ("REGULAR_AREA_WEIGHTED", (90, 150), 24),
+    ("REGULAR_WITH_LAND", (96, 160), 21), ("REGULAR_WITH_LAND_AREA_WEIGHTED", (150, 100), 56), ("REGULAR", (512, 512), 16),
+    ("IRREGULAR_WITH_LAND", (364, 3600), 32),       # the slab of one of eight ranks of BASELINE config 3 with its 2 x 32 ghost rows
+])
+@pytest.mark.parametrize("nan", ["", "land", "wet"])
+def test_resident_levels_equal_the_strip_marching_launches_bit_for_bit(grid, shape, n, nan):
+    import torch
+    if nan == "land" and grid in ("REGULAR", "REGULAR_AREA_WEIGHTED"):
+        pytest.skip("no land")
+    f, gv = T.scalar_case(grid, shape)
+    if nan == "land":
+        f = np.where(gv["wet_mask"] == 0, np.nan, f)
+    if nan == "wet":
+        wet = np.argwhere(gv["wet_mask"] != 0) if "wet_mask" in gv else np.argwhere(np.ones(shape, bool))
+        j, i = wet[len(wet) // 3]
+        f = f.copy()
+        f[j, i] = np.nan
+    dx = T.grid_dx_min(grid, gv) if O.DIMENSIONAL[grid] else 1.0
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        flt = Filter(filter_scale=6.0 * dx, dx_min=dx, n_steps=n, filter_shape=FilterShape.TAPER, grid_type=GridType[grid], grid_vars=gv)
+    plan = ALL_KERNELS[GridType[grid]](**gv)._plan(_lib.F64, shape)
+    spec = flt.filter_spec
+    p = np.asarray(spec.p, dtype=np.float64)
+    c = 2 / spec.s_max if ALL_KERNELS[GridType[grid]].is_dimensional else 2 / (spec.s_max * spec.dx_min_sq)
+    cut = plan.clenshaw_cut(n)
+    assert cut and sum(cut) == n
+    L = min(n, 64)
+    assert plan.resident_supported(0, shape[0], L)
+    d = torch.from_numpy(f).cuda()
+    want, wu, wv = _levels_by_launches(plan, d, p, c, n, cut, torch)
+    s = torch.cuda.current_stream().cuda_stream
+    # the whole polynomial in one launch
+    got = torch.zeros_like(d)
+    plan.resident_levels(None, None, None, None, d.data_ptr(), got.data_ptr(), p[:n][::-1], p[n], c, _lib.STEP_FIRST | _lib.STEP_LAST,
+                         0, shape[0], stream=s)
+    assert "k_resident<" in plan.last_kernel(), plan.last_kernel()
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(want, nan=-7.0)), float((got - want).abs().nan_to_num().max())
+    # ... and cut in two at an arbitrary level: states out, states in
+    if n >= 10:
+        a = n // 2 + 1
+        u1, v1, got2 = torch.zeros_like(d), torch.zeros_like(d), torch.zeros_like(d)
+        plan.resident_levels(None, None, u1.data_ptr(), v1.data_ptr(), d.data_ptr(), None, p[n - a: n][::-1], p[n], c, _lib.STEP_FIRST,
+                             0, shape[0], stream=s)
+        plan.resident_levels(u1.data_ptr(), v1.data_ptr(), None, None, d.data_ptr(), got2.data_ptr(), p[: n - a][::-1], p[n], c,
+                             _lib.STEP_LAST, 0, shape[0], stream=s)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.nan_to_num(got2, nan=-7.0), torch.nan_to_num(want, nan=-7.0))
+
+
+@pytest.mark.parametrize("grid,shape,scale", [("REGULAR", (512, 512), 4.0), ("IRREGULAR_WITH_LAND", (256, 384), 12.0),
+                                              ("REGULAR_WITH_LAND", (200, 300), 40.0), ("MOM5T", (128, 192), 70.0)])
+def test_small_grids_run_the_whole_polynomial_in_one_launch(grid, shape, scale, monkeypatch):
+    """north star: "the whole n_steps polynomial fused into a single launch" -- gcmf_apply does that for fields that fit on the chip
+    (64 levels per launch).  Against the oracle, against the strip-marching path (GCMF_RESIDENT=0: same bits), NaN on land."""
+    f, gv = T.scalar_case(grid, shape)
+    if "wet_mask" in gv:
+        f = np.where(gv["wet_mask"] == 0, np.nan, f)
+    dx = T.grid_dx_min(grid, gv) if O.DIMENSIONAL[grid] else 1.0
+    kw = dict(filter_scale=scale * dx, dx_min=dx, grid_type=GridType[grid], grid_vars=gv)
+    if grid == "REGULAR":
+        kw["n_steps"] = 16                                      # BASELINE config 1
+    flt = Filter(**kw)
+    plan = ALL_KERNELS[GridType[grid]](**gv)._plan(_lib.F64, shape)
+    got = flt.apply(f)
+    assert "k_resident<" in plan.last_kernel(), plan.last_kernel()
+    fs = flt.filter_spec
+    with np.errstate(all="ignore"):
+        want = O.filter_func(O.FilterSpec(fs.n_steps, fs.s_max, np.asarray(fs.p), fs.dx_min_sq), grid, f, gv)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.nanmax(np.abs(got - want)) <= 1e-12 * np.nanmax(np.abs(want))
+    monkeypatch.setenv("GCMF_RESIDENT", "0")
+    again = flt.apply(f)
+    assert "k_resident<" not in plan.last_kernel()
+    assert np.array_equal(got, again, equal_nan=True)
+
+
+@pytest.mark.parametrize("grid,shape,halo,exchange", [("IRREGULAR_WITH_LAND", (300, 360), 32, "native"), ("IRREGULAR_WITH_LAND", (130, 132), 8, "p2p"),
+                                                      ("REGULAR_WITH_LAND", (120, 128), 16, "p2p"), ("REGULAR", (96, 128), 12, "native"),
+                                                      ("MOM5U", (96, 64), 10, "p2p")])
+def test_slab_driver_runs_resident_between_exchanges(grid, shape, halo, exchange):
+    """A ring of one rank (ghost rows exchanged with itself: the 8-GPU choreography on one GPU): gcmf_slab_apply_backward runs every
+    stretch between two exchanges as ONE resident launch; same bits as its strip-marching launches and as the single-domain filter."""
+    from gcm_filters_amd.distributed import SlabFilter
+    f, gv = T.scalar_case(grid, shape)
+    if "wet_mask" in gv:
+        f = np.where(gv["wet_mask"] == 0, np.nan, f)
+    dx = T.grid_dx_min(grid, gv) if O.DIMENSIONAL[grid] else 1.0
+    fk = dict(filter_scale=14.0 * dx, dx_min=dx, filter_shape="TAPER")
+    sf = SlabFilter(grid, gv, fk, shape[0], shape[1], halo=halo, dtype=np.float64, device=0, rank=0, world=1, self_ring=True, exchange=exchange)
+    assert sf.backward_cut and sf.native_driver
+    got = sf.apply_local(sf.scatter_from_global([f[None]]))[0].cpu().numpy()
+    assert "k_resident<" in sf.engine.plan.last_kernel(), sf.engine.plan.last_kernel()
+    n_ex = sf.exchanges
+    sf.resident = False
+    again = sf.apply_local(sf.scatter_from_global([f[None]]))[0].cpu().numpy()
+    assert "k_resident<" not in sf.engine.plan.last_kernel()
+    assert np.array_equal(got, again, equal_nan=True)
+    assert n_ex <= sf.exchanges - n_ex                                   # one exchange per `halo` levels: never more than the launches of 5..8 need
+    one = Filter(filter_scale=fk["filter_scale"], dx_min=dx, filter_shape=FilterShape.TAPER, grid_type=GridType[grid], grid_vars=gv).apply(f)
+    assert np.array_equal(np.isnan(got[0]), np.isnan(one))
+    assert np.nanmax(np.abs(got[0] - one)) <= 1e-13 * np.nanmax(np.abs(one))
