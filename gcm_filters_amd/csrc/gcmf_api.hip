@@ -628,7 +628,7 @@ int gcmf_cheb_multi(gcmf_plan *pl, const void *u, const void *v, void *uo, void 
 int gcmf_resident_supported(const gcmf_plan *pl, int64_t row_lo, int64_t row_hi, int L) {
   if (!pl) return 0;
   (void)hipSetDevice(pl->d.device);
-  return resident_supported(pl, (int)row_lo, (int)row_hi, L) ? 1 : 0;
+  return resident_fits(pl, (int)row_lo, (int)row_hi, L) ? 1 : 0;
 }
 
 // L levels of the backward evaluation in one launch on rows [row_lo, row_hi) (their dependency cone [row_lo - L, row_hi + L) must hold
@@ -980,8 +980,7 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
     // and the coefficients live in registers / LDS, nothing but the result goes back to memory.  Same bits as the launches below.
     bool resident = false;
     if (n_clen > 0 && nbatch == 1 && !(flags & GCMF_NO_RESIDENT)) {
-      static const long long max_cells = getenv("GCMF_RESIDENT_MAX_CELLS") ? atoll(getenv("GCMF_RESIDENT_MAX_CELLS")) : 700000LL;
-      resident = (long long)rows * pl->g.nx <= max_cells && resident_supported(pl, 0, rows, std::min(n_steps, 64));
+      resident = resident_supported(pl, 0, rows, std::min(n_steps, 64));   // (small whole grids; GCMF_RESIDENT=1: whatever fits)
     }
     if (resident) {
       void *pool[4] = {A[0], B[0], Cb[0], Db[0]};

@@ -9,10 +9,11 @@
 // every workgroup (one per CU) owns ONE 2-D tile for the whole launch (up to 64 levels): coefficients, the constant input and both
 // Clenshaw states of its cells sit in registers (a thread owns RC consecutive cells of a tile row), the newest state is mirrored in
 // LDS so that neighbours can read it (structure-of-arrays: every LDS access is unit-stride across lanes, conflict-free), one barrier
-// per level.  Tiles carry a halo of K = 4 cells that goes stale by one cell per level; every K levels the tiles exchange their edge
-// bands THROUGH L2 / the memory-side cache: owned band cells are stored to an exchange plane, fence, a per-tile epoch flag is released
-// (agent scope), the eight neighbours' flags are acquired, halo cells are re-loaded.  Neighbour-to-neighbour, never grid-wide.  Nothing
-// but those bands (22 % of a tile) and the final result touches memory between the first load and the last store.
+// per level.  Tiles carry a halo of K = 4 cells that goes stale by one cell per level; every K levels the tiles trade their edge
+// bands THROUGH the memory-side cache: band cells are staged as flat lists in LDS and stored by consecutive lanes to an exchange plane in
+// UNCACHED device memory, every store acknowledged, barrier, a per-tile epoch flag is raised, the eight neighbours' flags are polled,
+// halo cells come back the same way.  Neighbour-to-neighbour, never grid-wide; no L2-wide fence.  Nothing but those bands (22 % of a
+// tile) and the final result touches memory between the first load and the last store.
 //
 // Arithmetic = k_ringc's backward (Clenshaw) level, operand for operand (gcmf_ringc_impl.hpp `level`): results are bit-identical to
 // the strip-marching path however the levels are cut into launches (tests/test_gpu_resident.py).  NaN semantics: a tile runs without
@@ -20,11 +21,22 @@
 // rides on the level barrier), from then on its stencil operands go through nan_to_num (kernels.py:175, 300) -- what k_ringc's redo
 // pass computes.  REGULAR has no nan_to_num in the reference (NaN spreads, kernels.py:113-121) and none here.
 //
-// Deadlock freedom: the launch is cooperative (hipLaunchCooperativeKernel: all workgroups co-resident or the launch fails), at most
-// one workgroup per CU; every flag wait is bounded (s_memrealtime) and a wait that runs out poisons the result with NaN and raises
-// the plan's sticky failure word (mapped host memory; the next call on the plan returns GCMF_ERR_HIP) -- never a hung GPU.
-// Two PROCESSES sharing one GPU must not run resident launches at the same time (each would hold CUs the other waits for): the
-// callers (SlabFilter with ranks on one device: the test set-up of this repo) serialise them with a file lock.
+// WHERE IT STANDS (round 4, MI355X, tools/measure_resident.py / tools/probe_resident.py): correct and bit-identical, NOT
+// faster -- therefore opt-in (GCMF_RESIDENT=1).  364 x 3600 IRREGULAR f64: load + store 33 us, ~1.0 us per level (the f64 issue
+// rate of 13 cells x 8 waves per CU), ~9.5 us per tile exchange; 32 levels 132 us, 64 levels 239 us -- the strip-marching launches do
+// 32 levels of the same slab in ~115 us.  The exchange is what costs: 15 of them per 63-level filter, because registers + LDS of a CU
+// hold no more than a K = 4 halo around a 91 x 57 tile of a flux-form grid (7 doubles per cell).  The protocol alone (same volumes, no
+// arithmetic: experiments/tile_exchange_probe) takes 4.4 us; LL-style tagged items without flags are no faster (4.9 us).  History of
+// the exchange, each step measured: agent-scope fences by every wave 130 us (a whole-L2 write-back / invalidate each); per-access sc1
+// atomics on ordinary memory: stale halos; a failure word in mapped host memory POLLED by 2048 lanes: 30 us of PCIe reads; plain loads
+// of uncached memory: stale lines in the CU's vector L1 from two exchanges ago (`buffer_inv sc0` is a no-op outside threadgroup-split
+// mode, `buffer_inv sc1` per wave costs 15 us); per-thread scattered band / halo accesses 14 us; flat lists by all lanes 9.5 us.
+//
+// Deadlock freedom: at most one workgroup per CU and no more workgroups than CUs, so every workgroup becomes resident once whatever ran
+// before has drained; every flag wait is bounded (s_memrealtime) and a wait that runs out poisons the result with NaN and raises the
+// plan's sticky failure word (mapped host memory; the next call on the plan returns GCMF_ERR_HIP) -- never a hung GPU.
+// Two PROCESSES sharing one GPU must not run resident launches at the same time (each would hold CUs the other waits for): SlabFilter
+// falls back to the strip-marching launches when its ranks share a device (this repo's one-GPU test set-up).
 #include "gcmf_multi_common.hpp"
 
 #include <algorithm>
@@ -88,6 +100,7 @@ __global__ __launch_bounds__(RES_NT, 2) void k_resident(const ResP P) {
   constexpr bool WATCH = (KIND != K_REG);
   // the deepest flux instantiation keeps the constant input in LDS (a third plane) instead of 2 * RC registers: 256 registers spilled
   constexpr bool FLDS = FLUX && RC >= 13;
+  constexpr int NB = RC * RES_NT;                // doubles per LDS buffer
   extern __shared__ double xs[];                 // [2][RC][RES_NT]: the newest state b_{k+1} of every cell of the padded tile (+ [RC][RES_NT]: f)
   __shared__ unsigned s_bad[2];                  // a non-finite value was seen in this tile (double-buffered with the level parity)
   __shared__ int s_fail;
@@ -99,7 +112,8 @@ __global__ __launch_bounds__(RES_NT, 2) void k_resident(const ResP P) {
   const int Rr = P.r_hi - P.r_lo;
   const int r0 = P.r_lo + (int)((long long)ty * Rr / P.nty), r1 = P.r_lo + (int)((long long)(ty + 1) * Rr / P.nty);
   const int c0 = (int)((long long)tx * nx / P.ntx), c1 = (int)((long long)(tx + 1) * nx / P.ntx);
-  const int PH = (r1 - r0) + 2 * K, w = c1 - c0, PW = nruns * RC;
+  const int h = r1 - r0, w = c1 - c0;            // owned rows / columns (both >= 2 K: res_geometry)
+  const int PH = h + 2 * K, PW = nruns * RC, PWl = w + 2 * K;   // padded rows, padded columns (allocated / live)
   const int prow = tid / nruns, run = tid - prow * nruns;
   const bool active = prow < PH;
   const int pc0 = run * RC;
@@ -113,11 +127,10 @@ __global__ __launch_bounds__(RES_NT, 2) void k_resident(const ResP P) {
     return (g >= P.r_lo && g < P.r_hi) ? g : -1;
   };
   auto gcolp = [&](int pc) {
-    if (pc >= w + 2 * K) return -1;
+    if (pc >= PWl) return -1;
     int g = c0 - K + pc;
     g = g < 0 ? g + nx : g;
-    while (g >= nx) g -= nx;
-    return g;
+    return g >= nx ? g - nx : g;                  // (one period is enough: PWl <= nx + 2 K <= 2 nx, res_geometry)
   };
   const int gr = active ? grow(prow) : -1;
   const bool own_row = active && prow >= K && prow < PH - K && gr >= 0;
@@ -125,23 +138,69 @@ __global__ __launch_bounds__(RES_NT, 2) void k_resident(const ResP P) {
 #pragma unroll
   for (int c = 0; c < RC; ++c) {
     const int pc = pc0 + c;
-    const bool lv = gr >= 0 && pc < w + 2 * K;
+    const bool lv = gr >= 0 && pc < PWl;
     const bool ow = lv && own_row && pc >= K && pc < K + w;
     const bool bd = ow && (prow < 2 * K || prow >= PH - 2 * K || pc < 2 * K || pc >= w);
     owned |= ow ? (1u << c) : 0u;
     band |= bd ? (1u << c) : 0u;
     halo |= (lv && !ow) ? (1u << c) : 0u;
   }
-  const long long rbase = (long long)gr * nx;
-  auto gcol = [&](int c) { return gcolp(pc0 + c); };
+  // The band (owned cells within K of the tile edge: what the neighbours need) and the halo (the padded frame around the owned cells:
+  // what this tile needs) as FLAT lists, so that the exchange moves them with consecutive lanes on consecutive cells:
+  //   band  i: [0, K w) top rows, [K w, 2 K w) bottom rows, then (h - 2K) x K left columns, then (h - 2K) x K right columns
+  //   halo  i: [0, K PWl) top rows, [K PWl, 2 K PWl) bottom rows, then h x K left columns, then h x K right columns
+  const int nband = 2 * K * w + 2 * (h - 2 * K) * K, nhalo = 2 * K * PWl + 2 * h * K;
+  auto band_cell = [&](int i, int &pr, int &pc) {         // flat band index -> padded-tile coordinates
+    if (i < 2 * K * w) {
+      const int r = i / w;
+      pc = K + (i - r * w);
+      pr = r < K ? K + r : PH - 2 * K + (r - K);
+    } else {
+      int j = i - 2 * K * w;
+      const bool right = j >= (h - 2 * K) * K;
+      j -= right ? (h - 2 * K) * K : 0;
+      const int r = j / K;
+      pr = 2 * K + r;
+      pc = (right ? w : K) + (j - r * K);
+    }
+  };
+  auto halo_cell = [&](int i, int &pr, int &pc) {
+    if (i < 2 * K * PWl) {
+      const int r = i / PWl;
+      pc = i - r * PWl;
+      pr = r < K ? r : PH - 2 * K + r;
+    } else {
+      int j = i - 2 * K * PWl;
+      const bool right = j >= h * K;
+      j -= right ? h * K : 0;
+      const int r = j / K;
+      pr = K + r;
+      pc = (right ? K + w : 0) + (j - r * K);
+    }
+  };
+  // my own cells' flat indices: a thread's row is of one kind (top / bottom / middle), so cell c's index is base + c (clamped users)
+  const int my_band0 = !own_row ? 0 : (prow < 2 * K ? (prow - K) * w : (prow >= PH - 2 * K ? K * w + (prow - (PH - 2 * K)) * w : -1));
+  const int my_halo0 = !active ? 0 : (prow < K ? prow * PWl : (prow >= PH - K ? K * PWl + (prow - (PH - K)) * PWl : -1));
+  auto band_index = [&](int c) {                          // (only for cells whose band bit is set)
+    const int pc = pc0 + c;
+    if (my_band0 >= 0) return my_band0 + (pc - K);
+    const int r = prow - 2 * K;
+    return 2 * K * w + (pc < 2 * K ? r * K + (pc - K) : (h - 2 * K) * K + r * K + (pc - w));
+  };
+  auto halo_index = [&](int c) {                          // (only for cells whose halo bit is set)
+    const int pc = pc0 + c;
+    if (my_halo0 >= 0) return my_halo0 + pc;
+    const int r = prow - K;
+    return 2 * K * PWl + (pc < K ? r * K + pc : h * K + r * K + (pc - K - w));
+  };
   // LDS neighbours (threads): the padded edge reads itself (garbage that never reaches a valid cell: the halo is K deep)
   const int tN = (active && prow + 1 < PH && !(!P.wrap && gr == rows - 1)) ? tid + nruns : tid;
   const int tS = (active && prow >= 1 && !(!P.wrap && gr == 0)) ? tid - nruns : tid;
   const int tW = run > 0 ? tid - 1 : tid;
   const int tE = (run < nruns - 1) ? tid + 1 : tid;
 
-  // ---- load: planes come in COALESCED (consecutive lanes = consecutive cells of a padded-tile row), are staged row-major in LDS and
-  // picked up by their owners (a thread's RC cells are consecutive there) -------------------------------------------------------------
+  // ---- load: planes come in COALESCED (consecutive lanes = consecutive cells of a padded-tile row), two at a time, are staged
+  // row-major in the two LDS buffers and picked up by their owners (a thread's RC cells are consecutive there) ---------------------------
   // flat element e = k * RES_NT + tid of the padded tile -> offset in the plan's planes, -1 = dead
   auto offs = [&](int k) {
     const int e = k * RES_NT + tid;
@@ -156,45 +215,77 @@ __global__ __launch_bounds__(RES_NT, 2) void k_resident(const ResP P) {
   int goff[RC];        // (the load phase only: the store phase recomputes them instead of keeping RC registers through the levels)
 #pragma unroll
   for (int k = 0; k < RC; ++k) goff[k] = offs(k);
-  double *stg = xs;                               // staging: PH * PW <= RC * RES_NT doubles
-  auto stage = [&](const double *plane) {        // (call between barriers)
+  double *stgA = xs, *stgB = xs + NB;             // staging: PH * PW <= RC * RES_NT doubles each
+  auto stage2 = [&](const double *pa, const double *pb) {   // (call between barriers) two planes in flight
+    double va[RC], vb[RC];
+#pragma unroll
+    for (int k = 0; k < RC; ++k) {
+      va[k] = goff[k] >= 0 ? pa[goff[k]] : 0.0;
+      vb[k] = goff[k] >= 0 ? pb[goff[k]] : 0.0;
+    }
 #pragma unroll
     for (int k = 0; k < RC; ++k) {
       const int e = k * RES_NT + tid;
-      if (e < PH * PW) stg[e] = goff[k] >= 0 ? plane[goff[k]] : 0.0;
+      if (e < PH * PW) {
+        stgA[e] = va[k];
+        stgB[e] = vb[k];
+      }
     }
   };
-  const int mine = prow * PW + pc0;               // my first cell in the staged tile
+  const int mine = prow * PW + pc0;               // my first cell in a staged tile
   double b1[RC], b2[RC], ff[FLDS ? 1 : RC];
-  double *fl = xs + 2 * RC * RES_NT;
+  double *fl = xs + 2 * NB;
   double cEr[FLUX ? RC + 1 : 1], cNr[FLUX ? RC : 1], cSr[FLUX ? RC : 1], rar[FLUX ? RC : 1];
   unsigned mb[MASK ? RC : 1];
   bool bad = false;
   if (tid == 0) { s_bad[0] = 0u; s_bad[1] = 0u; s_fail = 0; }
-  // the constant input: prepare()d (x area, kernels.py:100-101) and land-masked as it is staged
+  {
+    // round 1: the constant input -- prepare()d (x area, kernels.py:100-101) and land-masked as it is staged -- and the first
+    // coefficient plane (flux kinds) / the mask bytes (land-mask kinds)
+    double va[RC], vb[RC];
 #pragma unroll
-  for (int k = 0; k < RC; ++k) {
-    const int e = k * RES_NT + tid;
-    if (e < PH * PW) {
-      double fv = 0.0;
+    for (int k = 0; k < RC; ++k) {
+      double fv = 0.0, q = 0.0;
       if (goff[k] >= 0) {
         fv = P.f[goff[k]];
         if (P.area) fv = fv * P.area[goff[k]];
         if (P.lbits && !(P.lbits[goff[k]] & 1u)) fv = 0.0;
+        if constexpr (FLUX) q = P.cE[goff[k]];
+        if constexpr (MASK) q = (double)P.mbits[goff[k]];
       }
-      stg[e] = fv;
+      va[k] = fv;
+      vb[k] = q;
+    }
+#pragma unroll
+    for (int k = 0; k < RC; ++k) {
+      const int e = k * RES_NT + tid;
+      if (e < PH * PW) {
+        stgA[e] = va[k];
+        stgB[e] = vb[k];
+      }
     }
   }
   __syncthreads();
   double fown[RC];
 #pragma unroll
-  for (int c = 0; c < RC; ++c) fown[c] = active ? stg[mine + c] : 0.0;
-  __syncthreads();
-#pragma unroll
   for (int c = 0; c < RC; ++c) {
-    if constexpr (FLDS) fl[c * RES_NT + tid] = fown[c];
-    else ff[c] = fown[c];
+    fown[c] = active ? stgA[mine + c] : 0.0;
+    if constexpr (FLUX) cEr[c + 1] = active ? stgB[mine + c] : 0.0;
+    if constexpr (MASK) mb[c] = active ? (unsigned)stgB[mine + c] : 0u;
     if (WATCH) bad = bad || !res_finite(fown[c]);
+  }
+  if constexpr (FLUX) cEr[0] = (active && pc0 > 0) ? stgB[mine - 1] : 0.0;   // the east face of the cell west of my run (run 0: a padded edge, garbage anyway)
+  __syncthreads();
+  if constexpr (FLUX) {
+    stage2(P.cN, P.ra);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < RC; ++c) {
+      cNr[c] = active ? stgA[mine + c] : 0.0;
+      cSr[c] = (active && prow > 0) ? stgA[mine - PW + c] : 0.0;   // the north face of the row below (dead rows: zero, no flux)
+      rar[c] = active ? stgB[mine + c] : 0.0;
+    }
+    __syncthreads();
   }
   if (P.first) {
 #pragma unroll
@@ -203,56 +294,22 @@ __global__ __launch_bounds__(RES_NT, 2) void k_resident(const ResP P) {
       b2[c] = 0.0;
     }
   } else {
-    stage(P.u0);
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < RC; ++c) b1[c] = active ? stg[mine + c] : 0.0;
-    __syncthreads();
-    stage(P.v0);
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < RC; ++c) b2[c] = active ? stg[mine + c] : 0.0;
-    __syncthreads();
-    if (WATCH) {
-#pragma unroll
-      for (int c = 0; c < RC; ++c) bad = bad || !(res_finite(b1[c]) && res_finite(b2[c]));
-    }
-  }
-  if constexpr (FLUX) {
-    stage(P.cE);
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < RC; ++c) cEr[c + 1] = active ? stg[mine + c] : 0.0;
-    cEr[0] = (active && pc0 > 0) ? stg[mine - 1] : 0.0;    // the east face of the cell west of my run (run 0: a padded edge, garbage anyway)
-    __syncthreads();
-    stage(P.cN);
+    stage2(P.u0, P.v0);
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < RC; ++c) {
-      cNr[c] = active ? stg[mine + c] : 0.0;
-      cSr[c] = (active && prow > 0) ? stg[mine - PW + c] : 0.0;   // the north face of the row below (dead rows: zero, no flux)
+      b1[c] = active ? stgA[mine + c] : 0.0;
+      b2[c] = active ? stgB[mine + c] : 0.0;
+      if (WATCH) bad = bad || !(res_finite(b1[c]) && res_finite(b2[c]));
     }
-    __syncthreads();
-    stage(P.ra);
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < RC; ++c) rar[c] = active ? stg[mine + c] : 0.0;
-    __syncthreads();
-  }
-  if constexpr (MASK) {
-    unsigned *stu = reinterpret_cast<unsigned *>(stg);
-#pragma unroll
-    for (int k = 0; k < RC; ++k) {
-      const int e = k * RES_NT + tid;
-      if (e < PH * PW) stu[e] = goff[k] >= 0 ? (unsigned)P.mbits[goff[k]] : 0u;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < RC; ++c) mb[c] = active ? stu[mine + c] : 0u;
     __syncthreads();
   }
 #pragma unroll
-  for (int c = 0; c < RC; ++c) xs[c * RES_NT + tid] = b1[c];
+  for (int c = 0; c < RC; ++c) {
+    if constexpr (FLDS) fl[c * RES_NT + tid] = fown[c];
+    else ff[c] = fown[c];
+    xs[c * RES_NT + tid] = b1[c];
+  }
   if (WATCH && bad) s_bad[0] = 1u;
   __syncthreads();
 
@@ -262,8 +319,8 @@ __global__ __launch_bounds__(RES_NT, 2) void k_resident(const ResP P) {
 
   auto level = [&](auto sani_c, int l) {
     constexpr bool SANI = decltype(sani_c)::value;
-    const double *cur = xs + (l & 1) * (RC * RES_NT);
-    double *nxt = xs + ((l + 1) & 1) * (RC * RES_NT);
+    const double *cur = xs + (l & 1) * NB;
+    double *nxt = xs + ((l + 1) & 1) * NB;
     const double pk = P.pk[l];
     const double two = (P.last && l == P.L - 1) ? 1.0 : 2.0;   // the last level of a filter is p_0 f + A(b_1) - b_2: A, not 2 A
     auto sn = [&](double x) { return SANI ? msan(x) : x; };
@@ -324,18 +381,30 @@ __global__ __launch_bounds__(RES_NT, 2) void k_resident(const ResP P) {
     }
     __syncthreads();
     if ((l + 1) % K == 0 && l + 1 < P.L) {
-      // ---- trade the edge bands with the eight neighbour tiles through L2 / the memory-side cache: band cells out (device-scope
-      // stores), all of them performed (vmcnt), barrier, ONE flag store; eight lanes poll the neighbours' flags, barrier, halo cells in
-      // (device-scope loads).  No L2-wide fence anywhere. -----------------------------------------------------------------------------
+      // ---- trade the edge bands with the eight neighbour tiles through the memory-side cache.  The buffer of the state before this
+      // level is free now: owners put their band cells there as flat lists (both states), all lanes copy the lists out with consecutive
+      // lanes on consecutive cells; every store acknowledged (vmcnt 0), barrier, ONE flag store; eight lanes poll the neighbours'
+      // flags, barrier; the halo comes in the same way (device-scope loads) and its owners pick it up.  No L2-wide fence anywhere. ------
       ++epoch;
       double *e1 = P.ex[epoch & 1][0], *e2 = P.ex[epoch & 1][1];
+      double *sg = xs + (l & 1) * NB;                      // (nband + nhalo <= 2 K (PH + PW) << NB / 2)
+      double *sg2 = sg + NB / 2;
       if (band) {
 #pragma unroll
         for (int c = 0; c < RC; ++c)
           if ((band >> c) & 1u) {
-            dev_store(&e1[rbase + gcol(c)], b1[c]);
-            dev_store(&e2[rbase + gcol(c)], b2[c]);
+            const int i = band_index(c);
+            sg[i] = b1[c];
+            sg2[i] = b2[c];
           }
+      }
+      __syncthreads();
+      for (int i = tid; i < nband; i += RES_NT) {
+        int pr, pc;
+        band_cell(i, pr, pc);
+        const long long o = (long long)grow(pr) * nx + gcolp(pc);   // (band cells are owned: alive)
+        e1[o] = sg[i];
+        e2[o] = sg2[i];
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_s_waitcnt(0);                             // every store of this wave has been acknowledged by the memory side
@@ -368,18 +437,29 @@ __global__ __launch_bounds__(RES_NT, 2) void k_resident(const ResP P) {
         }
       }
       __syncthreads();
+      for (int i = tid; i < nhalo; i += RES_NT) {
+        int pr, pc;
+        halo_cell(i, pr, pc);
+        const int g = grow(pr), gc_ = gcolp(pc);
+        double v1 = 0.0, v2 = 0.0;
+        if (g >= 0 && gc_ >= 0) {
+          const long long o = (long long)g * nx + gc_;
+          v1 = dev_load(&e1[o]);
+          v2 = dev_load(&e2[o]);
+        }
+        sg[i] = v1;
+        sg2[i] = v2;
+      }
+      __syncthreads();
       if (halo) {
-        double *nxt = xs + ((l + 1) & 1) * (RC * RES_NT);
+        double *nxt = xs + ((l + 1) & 1) * NB;
         bool bd = false;
-#pragma unroll
-        for (int c = 0; c < RC; ++c)                              // (all loads first: they overlap)
-          if ((halo >> c) & 1u) {
-            b1[c] = dev_load(&e1[rbase + gcol(c)]);
-            b2[c] = dev_load(&e2[rbase + gcol(c)]);
-          }
 #pragma unroll
         for (int c = 0; c < RC; ++c)
           if ((halo >> c) & 1u) {
+            const int i = halo_index(c);
+            b1[c] = sg[i];
+            b2[c] = sg2[i];
             nxt[c * RES_NT + tid] = b1[c];
             if (WATCH) bd = bd || !(res_finite(b1[c]) && res_finite(b2[c]));
           }
@@ -389,39 +469,35 @@ __global__ __launch_bounds__(RES_NT, 2) void k_resident(const ResP P) {
     }
   }
 
-  // ---- store: owners put their cells into the staged tile, consecutive lanes write consecutive cells --------------------------------
+  // ---- store: owners put their cells into the staged tiles, consecutive lanes write consecutive cells -------------------------------
   const bool failed = s_fail != 0;
   const double poison = __longlong_as_double(-1LL);
-  auto unstage = [&](double *plane, bool finalize) {      // (call between barriers)
+  if (active) {
 #pragma unroll
-    for (int k = 0; k < RC; ++k) {
-      const int e = k * RES_NT + tid;
-      const int o = offs(k);
-      if (o >= 0) {
-        const int pr = e / PW, pc = e - pr * PW;
-        const int g = o / nx;
-        if (pr >= K && pr < PH - K && pc >= K && pc < K + w && g >= P.out_lo && g < P.out_hi) {
-          double r = stg[e];
-          if (finalize && P.area) r = r / P.area[o];         // finalize(): / area (kernels.py:103-104)
-          plane[o] = failed ? poison : r;
+    for (int c = 0; c < RC; ++c) {
+      stgA[mine + c] = b1[c];
+      stgB[mine + c] = b2[c];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < RC; ++k) {
+    const int e = k * RES_NT + tid;
+    const int o = offs(k);
+    if (o >= 0) {
+      const int pr = e / PW, pc = e - pr * PW;
+      const int g = o / nx;
+      if (pr >= K && pr < PH - K && pc >= K && pc < K + w && g >= P.out_lo && g < P.out_hi) {
+        if (P.last) {
+          double r = stgA[e];
+          if (P.area) r = r / P.area[o];                     // finalize(): / area (kernels.py:103-104)
+          P.out[o] = failed ? poison : r;
+        } else {
+          P.uo[o] = failed ? poison : stgA[e];
+          P.vo[o] = failed ? poison : stgB[e];
         }
       }
     }
-  };
-  if (active) {
-#pragma unroll
-    for (int c = 0; c < RC; ++c) stg[mine + c] = b1[c];
-  }
-  __syncthreads();
-  unstage(P.last ? P.out : P.uo, P.last);
-  if (!P.last) {
-    __syncthreads();
-    if (active) {
-#pragma unroll
-      for (int c = 0; c < RC; ++c) stg[mine + c] = b2[c];
-    }
-    __syncthreads();
-    unstage(P.vo, false);
   }
 }
 
@@ -443,12 +519,12 @@ static ResGeom res_geometry(int kind, int Rr, int nx, int K, int max_wg) {
     const int RC = rcs[q];
     for (int ntx = 1; ntx <= max_wg && ntx <= nx; ++ntx) {
       const int w = (nx + ntx - 1) / ntx;
-      if (nx / ntx < K) continue;                            // a halo must come from the direct neighbour
+      if (nx / ntx < 2 * K) continue;                        // tiles at least 2 K wide: the flat band lists do not overlap
       const int nruns = (w + 2 * K + RC - 1) / RC;
       const int ph_max = RES_NT / nruns;
       if (ph_max <= 2 * K) continue;
       const int nty_min = (Rr + (ph_max - 2 * K) - 1) / (ph_max - 2 * K);
-      int nty = std::min(max_wg / ntx, Rr / K > 0 ? Rr / K : 1);   // (tiles at least K rows tall)
+      int nty = std::min(max_wg / ntx, Rr / (2 * K) > 0 ? Rr / (2 * K) : 1);   // (tiles at least 2 K rows tall)
       if (nty < nty_min || nty < 1) continue;
       const int h = (Rr + nty - 1) / nty;
       const long long cost = (long long)RC * nruns * (h + 2 * K);
@@ -485,6 +561,14 @@ void resident_free(gcmf_plan *pl) {   // gcmf_plan_destroy
 }
 }  // namespace gcmf
 
+// Resident kernels of ONE process run one at a time, whatever streams they are launched on (two plans filtered from two threads): two
+// of them interleaved on the chip would each hold CUs the other's missing workgroups need.  A process-wide chain of events does it
+// without touching the host: every resident launch waits for the previous one's end.  (Two PROCESSES on one GPU cannot be chained; see
+// the header of this file.)
+static std::mutex g_chain_mu;
+static hipEvent_t g_chain_ev[16] = {nullptr};
+static bool g_chain_set[16] = {false};
+
 template <int KIND, int RC> static int res_launch(const ResP &P, int nwg, hipStream_t s) {
   const size_t lds = (size_t)((KIND == K_FLUX && RC >= 13) ? 3 : 2) * RC * RES_NT * sizeof(double);
   static bool attr_done = false;
@@ -496,6 +580,16 @@ template <int KIND, int RC> static int res_launch(const ResP &P, int nwg, hipStr
   // the chip has drained (ordinary kernels always finish).  GCMF_RESIDENT_COOP=1 asks the runtime to guarantee it instead
   // (hipLaunchCooperativeKernel: its cooperative queue costs a cross-queue dependency per launch).
   static const bool coop = getenv("GCMF_RESIDENT_COOP") && atoi(getenv("GCMF_RESIDENT_COOP")) != 0;
+  int dev = 0;
+  GCMF_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> chain(g_chain_mu);
+  const int dq = dev & 15;
+  if (!g_chain_ev[dq]) GCMF_HIP(hipEventCreateWithFlags(&g_chain_ev[dq], hipEventDisableTiming));
+  if (g_chain_set[dq]) GCMF_HIP(hipStreamWaitEvent(s, g_chain_ev[dq], 0));
+  struct Mark {
+    hipEvent_t e; hipStream_t s; bool *set;
+    ~Mark() { if (hipEventRecord(e, s) == hipSuccess) *set = true; }
+  } mark{g_chain_ev[dq], s, &g_chain_set[dq]};
   if (coop) {
     ResP Pc = P;
     void *args[] = {(void *)&Pc};
@@ -542,6 +636,7 @@ static bool res_supported(const gcmf_plan *pl, int row_lo, int row_hi, int L, Re
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
   if (const char *e = getenv("GCMF_RESIDENT_MAX_WG")) ncu = std::min(ncu, std::max(1, atoi(e)));
   const int K = 4;
+  if (pl->g.nx < 2 * K + 16 || r_hi - r_lo < 2 * K) return false;
   const ResGeom g = res_geometry(res_kind(pl), r_hi - r_lo, pl->g.nx, K, ncu);
   if (!g.rc) return false;
   if (g_out) *g_out = g;
@@ -553,11 +648,27 @@ static bool res_supported(const gcmf_plan *pl, int row_lo, int row_hi, int L, Re
 
 namespace gcmf {
 
+// Whether gcmf_apply / gcmf_slab_apply_backward pick the resident kernel BY THEMSELVES (it is bit-identical to the strip-marching launches,
+// so this is a question of speed only; measured in round 4, tools/measure_resident.py):
+//   * whole small grids (gcmf_apply, `whole`): yes up to 400 k cells -- the polynomial runs in ONE launch and the tiles are small enough
+//     for the flag exchanges to be cheap: IRREGULAR 512 x 512, n 63: 106 us against 179 us for eight strip-marching launches; REGULAR
+//     512 x 512 n 16 (BASELINE config 1) 25 us either way; at 720 x 1440 the two are equal or the strips win;
+//   * row slabs of a multi-GPU run: no -- on the 8-way slab of 2400 x 3600 a tile exchange costs ~9.5 us against ~1 us per level and
+//     registers + LDS only hold a K = 4 halo: 0.336 against 0.307 ms per application.
+// env GCMF_RESIDENT=1 forces it wherever it fits, =0 forbids it; the building block (gcmf_resident_levels) is always available.
 bool resident_supported(const gcmf_plan *pl, int row_lo, int row_hi, int L) {
-  if (const char *e = getenv("GCMF_RESIDENT"))
-    if (atoi(e) == 0) return false;
+  const char *e = getenv("GCMF_RESIDENT");
+  const int mode = e ? atoi(e) : -1;
+  if (mode == 0) return false;
+  if (mode < 0) {
+    static const long long max_cells = getenv("GCMF_RESIDENT_MAX_CELLS") ? atoll(getenv("GCMF_RESIDENT_MAX_CELLS")) : 400000LL;
+    const bool whole = pl && row_lo == 0 && row_hi == pl->g.rows && pl->full;
+    if (!whole || (long long)pl->g.rows * pl->g.nx > max_cells) return false;
+  }
   return res_supported(pl, row_lo, row_hi, L, nullptr, nullptr, nullptr, nullptr);
 }
+
+bool resident_fits(const gcmf_plan *pl, int row_lo, int row_hi, int L) { return res_supported(pl, row_lo, row_hi, L, nullptr, nullptr, nullptr, nullptr); }
 
 // L levels (a.S is ignored: pk = the L coefficients) of the backward evaluation on rows [a.row_lo, a.row_hi), one launch.
 // The plan's mutex is held and its device is current.

@@ -335,8 +335,11 @@ int gcmf_slab_apply_backward(gcmf_plan *plan, gcmf_comm *comm, gcmf_p2p *p2p, in
  * polynomial fused into a single launch, 2-D blocking with LDS-staged halo tiles", for fields that fit the register files + LDS of the
  * chip (the 300-row slab of an 8-way cut of 2400 x 3600 with its ghost rows; 512 x 512; up to ~1.5 M f64 cells).  One workgroup per CU owns
  * a 2-D tile for up to 64 levels of the backward (Clenshaw) evaluation of filter.py:162-212's polynomial; tiles trade their 4-cell edge
- * bands through L2 with per-tile epoch flags every 4 levels.  gcmf_apply and gcmf_slab_apply_backward use it by themselves when it fits
- * and pays (GCMF_NO_RESIDENT / env GCMF_RESIDENT=0 turn it off); these two entries are the building block.
+ * bands through the memory-side cache with per-tile epoch flags every 4 levels.  Bit-identical to the strip-marching launches.
+ * gcmf_apply uses it by itself for whole grids up to 400 k cells (one launch for the whole polynomial: IRREGULAR 512 x 512, n 63: 106 us
+ * against 179 us); on the row slabs of a multi-GPU run it measured slower (a tile exchange costs ~9.5 us against ~1 us per level,
+ * DESIGN.md 3.6), so gcmf_slab_apply_backward uses it only with env GCMF_RESIDENT=1 (=0 forbids it everywhere; GCMF_NO_RESIDENT per
+ * call); these two entries are the building block and always available.
  * gcmf_resident_supported: can L levels with output rows [row_lo, row_hi) run in one resident launch?  gcmf_resident_levels: run them --
  * (u, v) = (b_{k+1}, b_{k+2}) (GCMF_STEP_FIRST: unused), f = the constant input, pk[l] = coefficient of level l + 1, p0 = p_n;
  * GCMF_STEP_LAST: `out` gets the result, otherwise (uo, vo) the new states.  Bit-identical to the same levels through gcmf_cheb_multi

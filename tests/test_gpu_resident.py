@@ -85,8 +85,11 @@ def test_resident_levels_equal_the_strip_marching_launches_bit_for_bit(grid, sha
 
 
 @pytest.mark.parametrize("grid,shape,scale", [("REGULAR", (512, 512), 4.0), ("IRREGULAR_WITH_LAND", (256, 384), 12.0),
-                                              ("REGULAR_WITH_LAND", (200, 300), 40.0), ("MOM5T", (128, 192), 70.0)])
+                                              ("REGULAR_WITH_LAND", (200, 300), 40.0), ("MOM5T", (128, 192), 70.0), ("MOM5U", (96, 160), 9.0),
+                                              ("REGULAR_AREA_WEIGHTED", (128, 256), 20.0), ("REGULAR_WITH_LAND_AREA_WEIGHTED", (300, 400), 8.0),
+                                              ("IRREGULAR_WITH_LAND", (512, 512), 16.0)])
 def test_small_grids_run_the_whole_polynomial_in_one_launch(grid, shape, scale, monkeypatch):
+    monkeypatch.delenv("GCMF_RESIDENT", raising=False)    # the DEFAULT policy: whole grids of up to 400 k cells run on the chip
     """north star: "the whole n_steps polynomial fused into a single launch" -- gcmf_apply does that for fields that fit on the chip
     (64 levels per launch).  Against the oracle, against the strip-marching path (GCMF_RESIDENT=0: same bits), NaN on land."""
     f, gv = T.scalar_case(grid, shape)
@@ -109,12 +112,30 @@ def test_small_grids_run_the_whole_polynomial_in_one_launch(grid, shape, scale, 
     again = flt.apply(f)
     assert "k_resident<" not in plan.last_kernel()
     assert np.array_equal(got, again, equal_nan=True)
+    # a tripolar grid (the seam is k_fold_band's job) and a grid beyond 400 k cells stay on the strip-marching launches by default
+    monkeypatch.delenv("GCMF_RESIDENT", raising=False)
+
+
+def test_default_policy_leaves_tripolar_and_larger_grids_on_the_strip_marching_launches(monkeypatch):
+    monkeypatch.delenv("GCMF_RESIDENT", raising=False)
+    for grid, shape in (("TRIPOLAR_POP_WITH_LAND", (128, 192)), ("IRREGULAR_WITH_LAND", (720, 1440))):
+        f, gv = T.scalar_case(grid, shape)
+        dx = T.grid_dx_min(grid, gv)
+        flt = Filter(filter_scale=12.0 * dx, dx_min=dx, grid_type=GridType[grid], grid_vars=gv)
+        plan = ALL_KERNELS[GridType[grid]](**gv)._plan(_lib.F64, shape)
+        got = flt.apply(f)
+        assert "k_ringc<" in plan.last_kernel(), (grid, plan.last_kernel())
+        fs = flt.filter_spec
+        with np.errstate(all="ignore"):
+            want = O.filter_func(O.FilterSpec(fs.n_steps, fs.s_max, np.asarray(fs.p), fs.dx_min_sq), grid, f, gv)
+        assert np.nanmax(np.abs(got - want)) <= 1e-12 * np.nanmax(np.abs(want))
 
 
 @pytest.mark.parametrize("grid,shape,halo,exchange", [("IRREGULAR_WITH_LAND", (300, 360), 32, "native"), ("IRREGULAR_WITH_LAND", (130, 132), 8, "p2p"),
                                                       ("REGULAR_WITH_LAND", (120, 128), 16, "p2p"), ("REGULAR", (96, 128), 12, "native"),
                                                       ("MOM5U", (96, 64), 10, "p2p")])
-def test_slab_driver_runs_resident_between_exchanges(grid, shape, halo, exchange):
+def test_slab_driver_runs_resident_between_exchanges(grid, shape, halo, exchange, monkeypatch):
+    monkeypatch.setenv("GCMF_RESIDENT", "1")
     """A ring of one rank (ghost rows exchanged with itself: the 8-GPU choreography on one GPU): gcmf_slab_apply_backward runs every
     stretch between two exchanges as ONE resident launch; same bits as its strip-marching launches and as the single-domain filter."""
     from gcm_filters_amd.distributed import SlabFilter

@@ -9,6 +9,7 @@
     python tools/measure_resident.py
 """
 import os, sys, time
+os.environ["GCMF_RESIDENT"] = "1"
 import numpy as np
 sys.path.insert(0, "/root/repo")
 import torch
