@@ -32,7 +32,7 @@ EXPORTS = [
     "gcmf_has_land", "gcmf_zero_land", "gcmf_land_fix", "gcmf_last_kernel", "gcmf_last_kernel_timing", "gcmf_ring_fallbacks", "gcmf_clenshaw_cut",
     "gcmf_comm_unique_id", "gcmf_comm_create", "gcmf_comm_destroy", "gcmf_halo_start", "gcmf_halo_finish", "gcmf_comm_info",
     "gcmf_build_id", "gcmf_last_kernel_geometry",
-    "gcmf_slab_apply_backward", "gcmf_resident_supported", "gcmf_resident_levels", "gcmf_p2p_create", "gcmf_p2p_export", "gcmf_p2p_connect", "gcmf_p2p_start", "gcmf_p2p_finish", "gcmf_p2p_status", "gcmf_p2p_destroy", "gcmf_p2p_guard", "gcmf_p2p_seq", "gcmf_p2p_set_timeout_ms", "gcmf_p2p_debug_skip_post",
+    "gcmf_slab_apply_backward", "gcmf_slab_backward_vec_supported", "gcmf_slab_apply_backward_vec", "gcmf_resident_supported", "gcmf_resident_levels", "gcmf_p2p_create", "gcmf_p2p_export", "gcmf_p2p_connect", "gcmf_p2p_start", "gcmf_p2p_finish", "gcmf_p2p_status", "gcmf_p2p_destroy", "gcmf_p2p_guard", "gcmf_p2p_seq", "gcmf_p2p_set_timeout_ms", "gcmf_p2p_debug_skip_post",
 ]
 PLAN_SELF_RING, PLAN_SKIP_KAPPA_ONE = 0x1, 0x2
 
@@ -130,6 +130,11 @@ def load() -> C.CDLL:
         lib.gcmf_prepare.restype = C.c_int
         lib.gcmf_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         lib.gcmf_last_timing.restype = C.c_int
+        lib.gcmf_slab_backward_vec_supported.argtypes = [vp, C.c_int64, C.c_int]
+        lib.gcmf_slab_backward_vec_supported.restype = C.c_int
+        lib.gcmf_slab_apply_backward_vec.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_double, vpp, vpp, vpp, C.c_int64,
+                                                     C.c_int, C.c_uint32, vp]
+        lib.gcmf_slab_apply_backward_vec.restype = C.c_int
         lib.gcmf_resident_supported.argtypes = [vp, C.c_int64, C.c_int64, C.c_int]
         lib.gcmf_resident_supported.restype = C.c_int
         lib.gcmf_resident_levels.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_double), C.c_int, C.c_double, C.c_double, C.c_uint32,
@@ -321,6 +326,18 @@ class Plan:
             -1 if north is None else int(north), p.ctypes.data_as(C.POINTER(C.c_double)), len(p) - 1, float(c), cut, len(cut),
             C.c_void_p(X), _ptr_array(pool), C.c_void_p(out), int(nbatch), int(halo), int(bool(overlap)),
             (OUT_F32 if out_f32 else 0) | (0 if resident else NO_RESIDENT), C.c_void_p(stream or None)))
+
+    def slab_backward_vec_supported(self, nbatch: int, halo: int = 0) -> bool:
+        return bool(load().gcmf_slab_backward_vec_supported(self._h, int(nbatch), int(halo)))
+
+    def slab_apply_backward_vec(self, comm, p2p, south, north, p, c, X, pool, out, nbatch, halo, *, out_f32=False, stream=0):
+        """One whole backward application of a VECTOR plan on this slab incl. its halo exchanges (gcmf_slab_apply_backward_vec).
+        X / out: two device pointers (u, v); pool: eight (four state pairs, pool[2 q + component])."""
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        check(load().gcmf_slab_apply_backward_vec(
+            self._h, None if comm is None else comm._h, None if p2p is None else p2p._h, -1 if south is None else int(south),
+            -1 if north is None else int(north), p.ctypes.data_as(C.POINTER(C.c_double)), len(p) - 1, float(c), _ptr_array(X), _ptr_array(pool),
+            _ptr_array(out), int(nbatch), int(halo), OUT_F32 if out_f32 else 0, C.c_void_p(stream or None)))
 
     def resident_supported(self, row_lo: int, row_hi: int, L: int) -> bool:
         """Can L levels of the backward evaluation with output rows [row_lo, row_hi) run in one on-chip launch (gcmf_resident.hip)?"""

@@ -875,6 +875,96 @@ land_and_guard:
   return GCMF_OK;
 }
 
+// The vector kinds' counterpart (a C-grid / B-grid field sharded over y used to run the Python choreography of
+// distributed.py, forward, ~15 us of host time per launch): one whole backward (Clenshaw) application of a VECTOR plan on this rank's slab
+// in one call.  X / out: the two components; pool: four state plane PAIRS, pool[2 q + comp]; all (nbatch, rows_alloc, nx).  The levels are
+// cut exactly as gcmf_apply cuts them for this plan (at most four per launch), so a level filtered on a slab and in one piece see the same
+// arithmetic; a launch of S levels uses up S ghost rows, the ghost zone is refreshed (both states, both components: four planes in one
+// message per neighbour) when fewer are left than the next launch needs.  No edge / interior split.
+int gcmf_slab_backward_vec_supported(const gcmf_plan *pl, int64_t nbatch, int halo) {
+  if (!pl || pl->ncomp != 2 || nbatch < 1) return 0;
+  if (!((pl->kind == K_CGRID && pl->clenshaw >= 1) || (pl->kind == K_BGRID && pl->clenshaw >= 2))) return 0;
+  return (pl->multi_s >= 2 && vec_multi_supported(pl, nbatch, 2) && (halo == 0 || halo >= 4)) ? 1 : 0;
+}
+
+int gcmf_slab_apply_backward_vec(gcmf_plan *pl, gcmf_comm *comm, gcmf_p2p *p2p, int south, int north, const double *p, int n_steps, double c,
+                                 void *const *X, void *const *pool, void *const *out, int64_t nbatch, int halo, uint32_t flags, void *stream) {
+  if (!pl || !p || !X || !pool || !out || !X[0] || !X[1] || !out[0] || !out[1] || nbatch < 1 || n_steps < 2) {
+    set_error("gcmf_slab_apply_backward_vec: bad argument");
+    return GCMF_ERR_INVALID_ARG;
+  }
+  const bool multi = (south >= 0 || north >= 0);
+  if (!gcmf_slab_backward_vec_supported(pl, nbatch, multi ? halo : 0) || (multi && !(comm || p2p)) || (comm && p2p)) {
+    set_error("gcmf_slab_apply_backward_vec: no backward vector kernel for this plan / batch, a ghost zone shallower than a launch (4), or no exchange given");
+    return GCMF_ERR_UNSUPPORTED;
+  }
+  for (int q = 0; q < 8; ++q)
+    if (!pool[q]) return GCMF_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t fo = pl->first_owned, ro = pl->rows_owned, ra = pl->rows_alloc;
+  const bool gs = fo > 0, gn = ra - fo - ro > 0;
+  const int hs = multi ? halo : 0;
+  const int dtype = pl->d.dtype;
+  const int nx = (int)pl->d.nx;
+  const bool fb32 = (dtype == GCMF_F32) && (flags & GCMF_OUT_F32);
+  auto exchange = [&](void *const *st, int nst) -> int {
+    if (!multi) return GCMF_OK;
+    int rc = p2p ? gcmf_p2p_start(p2p, st, nst, nbatch, ra, nx, fo, ro, hs, dtype, stream)
+                 : gcmf_halo_start(comm, st, nst, nbatch, ra, nx, fo, ro, hs, dtype, south, north, stream);
+    if (rc) return rc;
+    return p2p ? gcmf_p2p_finish(p2p, stream) : gcmf_halo_finish(comm, stream);
+  };
+  int rc;
+  {  // f's ghost rows (both components)
+    void *st[2] = {X[0], X[1]};
+    if ((rc = exchange(st, 2))) return rc;
+  }
+  const void *u[2] = {X[0], X[1]}, *v[2] = {nullptr, nullptr};
+  const int smax = std::min(pl->multi_s, 4);
+  int valid = hs, lvl = 1;
+  while (lvl <= n_steps) {
+    const int left = n_steps - lvl + 1;
+    int S = 0;
+    for (int cand = smax; cand >= 2 && !S; --cand)
+      if (cand <= left && left - cand != 1 && vec_multi_supported(pl, nbatch, cand)) S = cand;
+    if (!S) S = left;
+    if (multi && valid < S) {   // (never before the first launch: valid = halo >= 4 there)
+      void *st[4] = {const_cast<void *>(u[0]), const_cast<void *>(u[1]), const_cast<void *>(v[0]), const_cast<void *>(v[1])};
+      if ((rc = exchange(st, 4))) return rc;
+      valid = hs;
+    }
+    void *fr[2][2];
+    int nf = 0;
+    for (int q = 0; q < 4 && nf < 2; ++q)
+      if (pool[2 * q] != u[0] && pool[2 * q] != v[0]) { fr[nf][0] = pool[2 * q]; fr[nf][1] = pool[2 * q + 1]; ++nf; }
+    const int v_out = multi ? valid - S : 0;
+    const bool is_last = (lvl + S - 1 == n_steps);
+    VecMultiArgs m{};
+    for (int q = 0; q < 2; ++q) {
+      m.u0[q] = u[q]; m.uprev[q] = v[q]; m.u1o[q] = fr[0][q]; m.u2o[q] = fr[1][q];
+      m.fb_in[q] = X[q]; m.fb_out[q] = out[q];
+    }
+    for (int t = 0; t < S; ++t) m.pk[t] = p[n_steps - (lvl + t)];
+    m.p0 = p[n_steps]; m.c = c; m.S = S; m.clen = 1;
+    m.first = (lvl == 1); m.last = is_last; m.fb_is_f32 = fb32; m.nbatch = nbatch;
+    m.row_lo = (int)(fo - (gs ? v_out : 0)); m.row_hi = (int)(fo + ro + (gn ? v_out : 0));
+    {
+      std::lock_guard<std::mutex> lk(pl->mu);
+      GCMF_HIP(hipSetDevice(pl->d.device));
+      if ((rc = launch_vec_multi(pl, m, s))) return rc;
+    }
+    for (int q = 0; q < 2; ++q) { u[q] = fr[1][q]; v[q] = fr[0][q]; }
+    valid = v_out;
+    lvl += S;
+  }
+  if (p2p && multi) {
+    const size_t obytes = (size_t)nbatch * ra * nx * ((dtype == GCMF_F32 && fb32) ? 4 : 8);
+    for (int q = 0; q < 2; ++q)
+      if ((rc = gcmf_p2p_guard(p2p, out[q], (int64_t)(obytes / 16 * 16), stream))) return rc;
+  }
+  return GCMF_OK;
+}
+
 int gcmf_prepare(gcmf_plan *pl, const void *const *in, void *const *out, int64_t nbatch, int64_t row_lo,
                  int64_t row_hi, void *stream) {
   if (!pl || !in || !out) return GCMF_ERR_INVALID_ARG;
@@ -931,7 +1021,7 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
   // than necessary but correct -- so back-to-back calls on one stream pay for no event at all: two queue packets less per
   // application, ~8 us of a 512x512 filter)
   if (pl->busy_valid && pl->busy_stream != s) {
-    if (hipEventRecord(pl->ev_busy, pl->busy_stream) == hipSuccess) {
+    if (pl->busy_recorded || hipEventRecord(pl->ev_busy, pl->busy_stream) == hipSuccess) {
       GCMF_HIP(hipStreamWaitEvent(s, pl->ev_busy, 0));
     } else {   // the caller destroyed that stream meanwhile: whatever ran on it is waited for the blunt way
       (void)hipGetLastError();
@@ -1222,6 +1312,16 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
     }
   }
   if (timing) GCMF_HIP(hipEventRecord(pl->ev1, s));
+  // "work buffers busy": recorded lazily by the NEXT call when it arrives on another stream (back-to-back calls on one stream pay for no
+  // event).  That needs this stream to be alive then: a stream handed in by the caller (not the plan's own, not the null stream) may be
+  // destroyed before the next call, so for such a stream the event is recorded now, while the handle is known to be good, whenever
+  // the stream differs from the previous call's (a caller cycling through streams) -- the common case, one long-lived stream, stays free.
+  if (s != pl->stream && s != nullptr && pl->busy_valid && pl->busy_stream != s) {
+    GCMF_HIP(hipEventRecord(pl->ev_busy, s));
+    pl->busy_recorded = true;
+  } else {
+    pl->busy_recorded = false;
+  }
   pl->busy_stream = s;
   pl->busy_valid = true;
   pl->last_launches = timed ? launches : pl->last_launches + launches;

@@ -130,6 +130,7 @@ struct gcmf_plan {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_busy = nullptr;  // end of the last gcmf_apply that used the plan's work buffers
   bool busy_valid = false;
+  bool busy_recorded = false;   // ev_busy already stands behind the last call's work (recorded eagerly: see run_whole_locked)
   hipStream_t busy_stream = nullptr;  // the stream that call ran on
   bool timing = false;
   // gcmf_set_timing(plan, 2): an event pair around every temporally blocked launch of gcmf_apply (the dominant kernel)

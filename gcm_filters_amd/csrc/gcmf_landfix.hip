@@ -5,8 +5,7 @@
 // its own input value.  gcmf_apply runs the blocked kernels with these cells zeroed and calls this kernel at the end: it
 // replays the recurrence with the same operations, in the same precision and order as the stencil kernels (the helpers of
 // gcmf_recurrence.hpp), prepare / finalize included, and writes the result over `out` on those cells only.
-#include "gcmf_internal.hpp"
-#include "gcmf_recurrence.hpp"
+#include "gcmf_multi_common.hpp"
 
 namespace gcmf {
 
@@ -35,7 +34,9 @@ __global__ __launch_bounds__(256) void k_land_fix(const T *in, FB *out, const ui
       fb[j] = cheb_acc_first<FUSED, T, FB>(sp[0], sp[1], x, a);
       xm2[j] = x;
       xm1[j] = a;
-      finite = finite && (__builtin_fabs((double)x) <= 1.7976931348623157e308);
+      // |x| <= max / 2 of the STATE type: the unfused forward kinds form 2 * a, which overflows beyond that and the general loop's bits
+      // would differ (advisor, round 3)
+      finite = finite && (mabs(x) <= MLim<T>::big() * T(0.5));
     }
     if (finite) {
       // With L = 0 and a finite x every step is exact up to the running sum: A(T) = -T, T_k = 2 A(T_{k-1}) - T_{k-2} = (-1)^k x, so only

@@ -224,6 +224,8 @@ class SlabFilter:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
             use = int(flag.item())
         self.backward_cut = list(cut) if use else []
+        self.evaluation = evaluation
+        self._vec_backward = {}     # nbatch -> does every rank have a backward vector kernel for this batch (decided collectively, once)
         self.tdtype = torch.float64 if self.np_dtype == np.float64 else torch.float32
         self._bufs = {}
         self.kernel_ms = 0.0
@@ -489,6 +491,52 @@ class SlabFilter:
         fo, ro = self.first_owned, self.rows_owned
         return [O[0][:, fo: fo + ro, :]]
 
+    def _vector_backward_ok(self, nbatch: int) -> bool:
+        """Vector kinds (C-grid, B-grid) with a library-issued exchange: the backward application in ONE call into libgcmf
+        (gcmf_slab_apply_backward_vec), like the scalar kinds -- if every rank's plan has the backward kernel for this batch size."""
+        if (self.ncomp != 2 or self.evaluation != "auto" or not self.native_driver or not isinstance(self.engine, HipSlabEngine)
+                or (self.multi and self.exchange_kind not in ("native", "p2p"))):
+            return False
+        ok = self._vec_backward.get(nbatch)
+        if ok is None:
+            ok = 1 if self.engine.plan.slab_backward_vec_supported(nbatch, self.halo if self.multi else 0) else 0
+            if self.world > 1 and self.dist.is_initialized():
+                flag = self.torch.tensor([ok], dtype=self.torch.int32,
+                                         device=self.device if self.dist.get_backend(self.group) == "nccl" else self.torch.device("cpu"))
+                self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)
+                ok = int(flag.item())
+            self._vec_backward[nbatch] = ok
+        return bool(ok)
+
+    def _apply_backward_vec_native(self, st, p, nbatch):
+        t = self.torch
+        X, O = st["X"], st["O"]
+        if self.exchange_kind == "p2p" and self.multi:
+            self._p2p_ready(4 * nbatch * self.halo * self.nx * X.element_size())     # (two states of two components)
+        if self.time_kernels:
+            e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+            e0.record()
+        pool = [st[k][comp].data_ptr() for k in "ABCD" for comp in range(2)]
+        self.engine.plan.slab_apply_backward_vec(
+            self.comm if (self.exchange_kind == "native" and self.multi) else None, self.p2p if (self.exchange_kind == "p2p" and self.multi) else None,
+            self.south, self.north, p, self.c, [X[0].data_ptr(), X[1].data_ptr()], pool, [O[0].data_ptr(), O[1].data_ptr()], nbatch, self.halo,
+            stream=t.cuda.current_stream().cuda_stream)
+        nlaunch, left, valid, nex = 0, self.n_steps, self.halo, 1
+        while left > 0:      # (the bookkeeping of the C++ driver, for the counters)
+            S = next((cnd for cnd in (4, 3, 2) if cnd <= left and left - cnd != 1), left)
+            if self.multi and valid < S:
+                nex, valid = nex + 1, self.halo
+            valid -= S
+            left -= S
+            nlaunch += 1
+        if self.multi:
+            self.exchanges += nex
+        if self.time_kernels:
+            e1.record()
+            self._pending_events.append((e0, e1, nlaunch))
+        fo, ro = self.first_owned, self.rows_owned
+        return [O[k][:, fo: fo + ro, :] for k in range(2)]
+
     def _exchange_points(self, cut):
         """Launches of a backward application that are followed (or preceded) by an exchange of the state: the bookkeeping of
         _apply_backward without the launches (for the `exchanges` counter)."""
@@ -597,6 +645,8 @@ class SlabFilter:
             if self.native_driver and self.ncomp == 1 and isinstance(self.engine, HipSlabEngine) and self.exchange_kind in ("native", "p2p"):
                 return self._apply_backward_native(self.backward_cut, st, p, nbatch)
             return self._apply_backward(self.backward_cut, st, p, nbatch)
+        if self._vector_backward_ok(nbatch):
+            return self._apply_backward_vec_native(st, p, nbatch)
         u, v = X, None          # T_{k-1}, T_{k-2}
         valid = 0               # ghost rows of u (and at least valid-1 of v) that are up to date
         events = []

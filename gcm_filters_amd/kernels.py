@@ -310,11 +310,6 @@ PLAN_CACHE = _PlanCache()
 def clear_plan_cache():
     """Drop every cached device plan (frees their HBM) and give the grid arrays they were built from back their writability."""
     PLAN_CACHE.clear()
-    global _CACHE_EPOCH
-    _CACHE_EPOCH += 1
-
-
-_CACHE_EPOCH = 0
 
 
 def kernels_cache_enabled() -> bool:

@@ -152,7 +152,9 @@ int gcmf_plan_rows(const gcmf_plan *plan, int64_t *rows_alloc, int64_t *first_ow
  * dtype and is not modified; `out` is f64 unless the plan is f32 and GCMF_OUT_F32 is given and must not alias `in`.
  * Only valid on single-slab plans (row_begin = 0, row_end = ny).
  * `stream`: hipStream_t to run on.  With GCMF_DEVICE_PTRS the work is enqueued asynchronously on exactly
- * that stream (NULL = the HIP default stream), ordered with the caller's other work on it.  With host
+ * that stream (NULL = the HIP default stream), ordered with the caller's other work on it.  A stream handed in here must stay
+ * alive until the NEXT gcmf_apply on this plan has returned (or the plan is destroyed): when that next call arrives on another
+ * stream it orders itself behind this one with an event recorded on this stream.  With host
  * pointers the call stages through HBM and is synchronous (NULL = a private stream of the plan); a batch of host
  * fields is cut into chunks whose upload, filtering and download overlap, and the input range is page-locked
  * (hipHostRegister, best effort) while the call runs -- see DESIGN.md section 6 and the GCMF_HOST_* variables.
@@ -330,6 +332,15 @@ void gcmf_p2p_destroy(gcmf_p2p *p);
 int gcmf_slab_apply_backward(gcmf_plan *plan, gcmf_comm *comm, gcmf_p2p *p2p, int south, int north, const double *p, int n_steps, double c,
                              const int *cut, int ncut, void *X, void *const *pool, void *out, int64_t nbatch, int halo, int overlap,
                              uint32_t flags, void *stream);
+
+/* The same for the VECTOR kinds (VECTOR_C_GRID, VECTOR_B_GRID; reference filter.py:217-291 filter_func_vec on a row slab): X / out = the two
+ * components, pool = four state plane pairs (pool[2 q + component]); the levels are cut as gcmf_apply cuts them for this plan (at most four
+ * per launch), the ghost zone (halo >= 4 rows) is refreshed -- both states of both components in one message per neighbour -- when the next
+ * launch needs more rows than are left.  gcmf_slab_backward_vec_supported: does this plan / batch have a backward vector kernel (every
+ * rank of a run must get the same answer; halo 0 = do not check the ghost depth)? */
+int gcmf_slab_backward_vec_supported(const gcmf_plan *plan, int64_t nbatch, int halo);
+int gcmf_slab_apply_backward_vec(gcmf_plan *plan, gcmf_comm *comm, gcmf_p2p *p2p, int south, int north, const double *p, int n_steps, double c,
+                                 void *const *X, void *const *pool, void *const *out, int64_t nbatch, int halo, uint32_t flags, void *stream);
 
 /* ---- the on-chip (resident) kernel, csrc/gcmf_resident.hip: the north star's "one persistent field per GPU with the whole n_steps
  * polynomial fused into a single launch, 2-D blocking with LDS-staged halo tiles", for fields that fit the register files + LDS of the

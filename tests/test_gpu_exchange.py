@@ -64,6 +64,10 @@ def test_self_ring_native_exchange_equals_single_domain(grid, shape, halo, nbatc
     assert sf.exchange_kind == exchange and sf.halo == halo and sf.rows_alloc == shape[0] + 2 * halo
     got = [t.cpu().numpy() for t in sf.apply_local(sf.scatter_from_global(fields))]
     assert sf.exchanges >= (sf.n_steps - 1) // halo and not sf.p2p_timed_out()
+    if vec and halo >= 4:
+        # vector kinds with a library-issued exchange: one call into libgcmf per application too (gcmf_slab_apply_backward_vec: the backward
+        # kernels, cut as gcmf_apply cuts them) -- not the forward Python choreography
+        assert sf._vec_backward.get(nbatch) == 1 and "stream2c<" in sf.engine.plan.last_kernel(), sf.engine.plan.last_kernel()
     if sf.backward_cut and not vec:
         # the scalar backward path ran inside libgcmf in one call (gcmf_slab_apply_backward); the Python choreography gives the same bits
         assert sf.native_driver

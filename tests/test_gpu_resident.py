@@ -86,7 +86,7 @@ def test_resident_levels_equal_the_strip_marching_launches_bit_for_bit(grid, sha
 
 @pytest.mark.parametrize("grid,shape,scale", [("REGULAR", (512, 512), 4.0), ("IRREGULAR_WITH_LAND", (256, 384), 12.0),
                                               ("REGULAR_WITH_LAND", (200, 300), 40.0), ("MOM5T", (128, 192), 70.0), ("MOM5U", (96, 160), 9.0),
-                                              ("REGULAR_AREA_WEIGHTED", (128, 256), 20.0), ("REGULAR_WITH_LAND_AREA_WEIGHTED", (300, 400), 8.0),
+                                              ("REGULAR_AREA_WEIGHTED", (128, 256), 20.0), ("REGULAR_WITH_LAND_AREA_WEIGHTED", (300, 400), 10.0),
                                               ("IRREGULAR_WITH_LAND", (512, 512), 16.0)])
 def test_small_grids_run_the_whole_polynomial_in_one_launch(grid, shape, scale, monkeypatch):
     monkeypatch.delenv("GCMF_RESIDENT", raising=False)    # the DEFAULT policy: whole grids of up to 400 k cells run on the chip
