@@ -378,11 +378,11 @@ __device__ __forceinline__ void cgrid_stream2_body(const CStream2P<T, FB> &P) {
 }
 
 template <typename T, typename FB, int VEC, int S, int D, bool PRIV>
-__global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) == 8 && (PRIV || S > 2) ? 1 : 2)) void k_cgrid_stream2(const CStream2P<T, FB> P) {
+__global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) * VEC == 16 && (PRIV || S > 2) ? 1 : 2)) void k_cgrid_stream2(const CStream2P<T, FB> P) {
   cgrid_stream2_body<T, FB, VEC, S, D, PRIV, false>(P);
 }
 template <typename T, int VEC, int S, int D, bool PRIV>
-__global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) == 8 && (PRIV || S > 2) ? 1 : 2)) void k_cgrid_stream2c(const CStream2P<T, T> P) {
+__global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) * VEC == 16 && (PRIV || S > 2) ? 1 : 2)) void k_cgrid_stream2c(const CStream2P<T, T> P) {
   cgrid_stream2_body<T, T, VEC, S, D, PRIV, true>(P);
 }
 
@@ -438,7 +438,7 @@ template <typename T, typename FB, int VEC, int S, int D, bool PRIV, bool CLEN =
     // 2048 resident waves (2 per SIMD): the fewest strips of <= 96 rows (64-96 measured best on config 5: 273 G
     // against 262 G at 160) fix the number of rounds, then the strip
     // count grows to fill the last round
-    long long cap = (sizeof(T) == 8 && S > 2) ? 1024 : 2048;  // f64 beyond two levels: one wave per SIMD
+    long long cap = (sizeof(T) * VEC == 16 && S > 2) ? 1024 : 2048;  // 16 bytes per lane beyond two levels: one wave per SIMD
     if (PRIV) {  // one-wave workgroups: registers (f64: one wave per SIMD) or the LDS ring bound the residency
       const long long by_lds = (160 * 1024) / ((long long)(S - 1) * 14 * 64 * sizeof(MPack<T, VEC>));
       const long long by_reg = sizeof(T) == 8 ? 4 : 8;
@@ -520,6 +520,8 @@ int launch_cgrid_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
     switch (a.S) {
       case 2: return priv ? launch_c2<float, float, 2, 2, 1, true, true>(pl, a, s) : launch_c2<float, float, 2, 2, 2, false, true>(pl, a, s);
       case 3: return priv ? launch_c2<float, float, 2, 3, 1, true, true>(pl, a, s) : launch_c2<float, float, 2, 3, 2, false, true>(pl, a, s);
+      // (round 4: FOUR cells per lane -- 16-byte accesses, 256-cell windows, 416 registers = one wave per SIMD like the f64 kernel -- measured
+      // 331 G against 358 G on config 5, same bits; experiments/README.md)
       case 4: return priv ? launch_c2<float, float, 2, 4, 1, true, true>(pl, a, s) : launch_c2<float, float, 2, 4, 2, false, true>(pl, a, s);
       case 5: return launch_c2<float, float, 2, 5, 1, false, true>(pl, a, s);
     }
