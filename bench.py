@@ -389,6 +389,9 @@ def roofline_of(cfg, r, steps, default_tuning):
         except Exception:
             pass
         out["traffic_over_alg_bytes"] = rec["bytes_per_launch"] / minb   # > 1: halo re-reads of the strip-marching scheme
+        if rec.get("fetch_scale"):   # FETCH_SIZE calibrated on this kernel's own access pattern instead of the x2 rule for 16-byte-per-lane loads
+            out["traffic_calibration"] = {"read_bytes_per_FETCH_SIZE_byte": rec["fetch_scale"], "note": rec.get("fetch_scale_note"),
+                                          "traffic_by_the_x2_rule": rec.get("bytes_per_launch_x2_rule")}
         # SQ-counter view of the same kernel (profiles/): how the wave cycles split; `bound` stays the contract's enum
         for k in ("bound", "valu_active_frac", "salu_active_frac", "wait_memory_frac", "wait_issue_frac", "valu_arith_share",
                   "counters_source"):

@@ -783,7 +783,7 @@ int gcmf_slab_apply_backward(gcmf_plan *pl, gcmf_comm *comm, gcmf_p2p *p2p, int 
       const int vo_ = multi ? hs - L : 0;
       std::lock_guard<std::mutex> lk(pl->mu);
       GCMF_HIP(hipSetDevice(pl->d.device));
-      fits = resident_supported(pl, (int)(fo - (gs ? vo_ : 0)), (int)(fo + ro + (gn ? vo_ : 0)), L);
+      fits = resident_supported(pl, (int)(fo - (gs ? vo_ : 0)), (int)(fo + ro + (gn ? vo_ : 0)), L, n_steps);
       done += L;
     }
     if (fits) {
@@ -1070,7 +1070,7 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
     // and the coefficients live in registers / LDS, nothing but the result goes back to memory.  Same bits as the launches below.
     bool resident = false;
     if (n_clen > 0 && nbatch == 1 && !(flags & GCMF_NO_RESIDENT)) {
-      resident = resident_supported(pl, 0, rows, std::min(n_steps, 64));   // (small whole grids; GCMF_RESIDENT=1: whatever fits)
+      resident = resident_supported(pl, 0, rows, std::min(n_steps, 64), n_steps);   // (small whole grids; GCMF_RESIDENT=1: whatever fits)
     }
     if (resident) {
       void *pool[4] = {A[0], B[0], Cb[0], Db[0]};

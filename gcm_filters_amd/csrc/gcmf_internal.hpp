@@ -208,7 +208,7 @@ int launch_ringc_flux_slab(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);   
 int launch_flux_multi2(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 // the on-chip kernel (gcmf_resident.hip): L <= 64 levels of the backward evaluation in ONE launch on a field that fits the register
 // files + LDS of the chip (short slabs, small grids); pk = the L coefficients (a.S / a.pk are ignored)
-bool resident_supported(const gcmf_plan *pl, int row_lo, int row_hi, int L);   // fits AND switched on (GCMF_RESIDENT=1)
+bool resident_supported(const gcmf_plan *pl, int row_lo, int row_hi, int L, int n_total);   // fits AND the policy says so (n_total: levels of the whole filter)
 bool resident_fits(const gcmf_plan *pl, int row_lo, int row_hi, int L);
 int launch_resident(gcmf_plan *pl, const MultiArgs &a, const double *pk, int L, hipStream_t s);
 void resident_free(gcmf_plan *pl);

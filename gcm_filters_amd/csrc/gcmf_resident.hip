@@ -651,12 +651,13 @@ namespace gcmf {
 // Whether gcmf_apply / gcmf_slab_apply_backward pick the resident kernel BY THEMSELVES (it is bit-identical to the strip-marching launches,
 // so this is a question of speed only; measured in round 4, tools/measure_resident.py):
 //   * whole small grids (gcmf_apply, `whole`): yes up to 400 k cells -- the polynomial runs in ONE launch and the tiles are small enough
-//     for the flag exchanges to be cheap: IRREGULAR 512 x 512, n 63: 106 us against 179 us for eight strip-marching launches; REGULAR
-//     512 x 512 n 16 (BASELINE config 1) 25 us either way; at 720 x 1440 the two are equal or the strips win;
+//     for the flag exchanges to be cheap: IRREGULAR 512 x 512, n 63: 106 us against 179 us for eight strip-marching launches; at
+//     720 x 1440 the two are equal or the strips win.  The REGULAR / land-mask kinds (cheaper levels, two strip launches for 16 levels)
+//     only from 24 levels on: 512 x 512 n 36 51.7 against 54.5 us, but n 16 (BASELINE config 1) 25.4-28.9 against 23.6-27.1 us;
 //   * row slabs of a multi-GPU run: no -- on the 8-way slab of 2400 x 3600 a tile exchange costs ~9.5 us against ~1 us per level and
 //     registers + LDS only hold a K = 4 halo: 0.336 against 0.307 ms per application.
 // env GCMF_RESIDENT=1 forces it wherever it fits, =0 forbids it; the building block (gcmf_resident_levels) is always available.
-bool resident_supported(const gcmf_plan *pl, int row_lo, int row_hi, int L) {
+bool resident_supported(const gcmf_plan *pl, int row_lo, int row_hi, int L, int n_total) {
   const char *e = getenv("GCMF_RESIDENT");
   const int mode = e ? atoi(e) : -1;
   if (mode == 0) return false;
@@ -664,6 +665,7 @@ bool resident_supported(const gcmf_plan *pl, int row_lo, int row_hi, int L) {
     static const long long max_cells = getenv("GCMF_RESIDENT_MAX_CELLS") ? atoll(getenv("GCMF_RESIDENT_MAX_CELLS")) : 400000LL;
     const bool whole = pl && row_lo == 0 && row_hi == pl->g.rows && pl->full;
     if (!whole || (long long)pl->g.rows * pl->g.nx > max_cells) return false;
+    if (pl->kind != K_FLUX && n_total < 24) return false;
   }
   return res_supported(pl, row_lo, row_hi, L, nullptr, nullptr, nullptr, nullptr);
 }

@@ -15,6 +15,8 @@ pytestmark = pytest.mark.gpu
 def test_raw_exchange_fills_ghost_rows_direct_and_packed():
     import torch
     comm = _lib.Comm(_lib.Comm.unique_id(), 1, 0, 0)
+    info = comm.describe()      # what RCCL itself says about the communicator (bench.py prints it with the N > 1 line)
+    assert info["nranks"] == 1 and info["rank"] == 0 and info["rccl_version_code"] > 20000, info
     s = torch.cuda.current_stream().cuda_stream
     for nblocks, dt, code in [(1, torch.float64, _lib.F64), (3, torch.float32, _lib.F32), (12, torch.float64, _lib.F64)]:
         halo, owned, nx = 3, 20, 64

@@ -84,9 +84,9 @@ def test_resident_levels_equal_the_strip_marching_launches_bit_for_bit(grid, sha
         assert torch.equal(torch.nan_to_num(got2, nan=-7.0), torch.nan_to_num(want, nan=-7.0))
 
 
-@pytest.mark.parametrize("grid,shape,scale", [("REGULAR", (512, 512), 4.0), ("IRREGULAR_WITH_LAND", (256, 384), 12.0),
+@pytest.mark.parametrize("grid,shape,scale", [("REGULAR", (512, 512), 24.0), ("IRREGULAR_WITH_LAND", (256, 384), 12.0),
                                               ("REGULAR_WITH_LAND", (200, 300), 40.0), ("MOM5T", (128, 192), 70.0), ("MOM5U", (96, 160), 9.0),
-                                              ("REGULAR_AREA_WEIGHTED", (128, 256), 20.0), ("REGULAR_WITH_LAND_AREA_WEIGHTED", (300, 400), 10.0),
+                                              ("REGULAR_AREA_WEIGHTED", (128, 256), 24.0), ("REGULAR_WITH_LAND_AREA_WEIGHTED", (300, 400), 30.0),
                                               ("IRREGULAR_WITH_LAND", (512, 512), 16.0)])
 def test_small_grids_run_the_whole_polynomial_in_one_launch(grid, shape, scale, monkeypatch):
     monkeypatch.delenv("GCMF_RESIDENT", raising=False)    # the DEFAULT policy: whole grids of up to 400 k cells run on the chip
@@ -97,8 +97,6 @@ def test_small_grids_run_the_whole_polynomial_in_one_launch(grid, shape, scale, 
         f = np.where(gv["wet_mask"] == 0, np.nan, f)
     dx = T.grid_dx_min(grid, gv) if O.DIMENSIONAL[grid] else 1.0
     kw = dict(filter_scale=scale * dx, dx_min=dx, grid_type=GridType[grid], grid_vars=gv)
-    if grid == "REGULAR":
-        kw["n_steps"] = 16                                      # BASELINE config 1
     flt = Filter(**kw)
     plan = ALL_KERNELS[GridType[grid]](**gv)._plan(_lib.F64, shape)
     got = flt.apply(f)
@@ -118,10 +116,12 @@ def test_small_grids_run_the_whole_polynomial_in_one_launch(grid, shape, scale, 
 
 def test_default_policy_leaves_tripolar_and_larger_grids_on_the_strip_marching_launches(monkeypatch):
     monkeypatch.delenv("GCMF_RESIDENT", raising=False)
-    for grid, shape in (("TRIPOLAR_POP_WITH_LAND", (128, 192)), ("IRREGULAR_WITH_LAND", (720, 1440))):
+    # (... and BASELINE config 1 -- REGULAR 512 x 512, 16 levels: two strip launches take 24-27 us, the on-chip launch 25-29 us; the cheap
+    # REGULAR / land-mask levels go on the chip from 24 levels on)
+    for grid, shape in (("TRIPOLAR_POP_WITH_LAND", (128, 192)), ("IRREGULAR_WITH_LAND", (720, 1440)), ("REGULAR", (512, 512))):
         f, gv = T.scalar_case(grid, shape)
-        dx = T.grid_dx_min(grid, gv)
-        flt = Filter(filter_scale=12.0 * dx, dx_min=dx, grid_type=GridType[grid], grid_vars=gv)
+        dx = T.grid_dx_min(grid, gv) if O.DIMENSIONAL[grid] else 1.0
+        flt = Filter(filter_scale=12.0 * dx, dx_min=dx, grid_type=GridType[grid], grid_vars=gv, **({"n_steps": 16} if grid == "REGULAR" else {}))
         plan = ALL_KERNELS[GridType[grid]](**gv)._plan(_lib.F64, shape)
         got = flt.apply(f)
         assert "k_ringc<" in plan.last_kernel(), (grid, plan.last_kernel())
