@@ -242,24 +242,20 @@ class SlabFilter:
         # backward scalar applications with a library-issued exchange ("native" RCCL or "p2p"): the whole choreography in ONE call into
         # libgcmf (gcmf_slab_apply_backward) instead of a Python loop of C calls
         self.native_driver = True
-        # ... which runs every stretch between two exchanges as ONE on-chip launch when the slab fits the chip (csrc/gcmf_resident.hip:
-        # the 300-row slab of an 8-way cut of 2400 x 3600 does).  A resident kernel holds its CUs until its neighbour tiles have arrived, so
-        # two PROCESSES must not run one on the same GPU at the same time: ranks that share a device (this repo's one-GPU test set-up,
-        # never a real run) take a file lock around the call and wait for the stream inside it.
+        # ... which can run every stretch between two exchanges as ONE on-chip launch when the slab fits the chip (csrc/gcmf_resident.hip;
+        # measured slower than the strip-marching launches on the 8-way slab of 2400 x 3600, so libgcmf only does it with GCMF_RESIDENT=1,
+        # DESIGN.md 3.6).  A resident kernel holds its CUs until its neighbour tiles have arrived, so two PROCESSES must never run one on the
+        # same GPU at the same time: ranks that share a device (this repo's one-GPU test set-up, never a real run) are told apart here
+        # and always take the strip-marching launches.
         self.resident = True
-        self._shared_gpu_lock = None
+        self._shared_gpu = False
         if on_gpu and self.world > 1 and dist.is_initialized():
             import socket
             props = torch.cuda.get_device_properties(self.device)
-            ident = (socket.gethostname(), getattr(props, "uuid", None) and str(props.uuid), getattr(props, "pci_bus_id", None), self.device.index
-                     if getattr(props, "pci_bus_id", None) is None else None)
+            ident = (socket.gethostname(), str(getattr(props, "uuid", "")), str(getattr(props, "pci_bus_id", "")), self.device.index)
             every = [None] * self.world
             dist.all_gather_object(every, ident, group=group)
-            if len(set(every)) < len(every):
-                import hashlib
-                import tempfile
-                tag = hashlib.sha1(repr(ident).encode()).hexdigest()[:12]
-                self._shared_gpu_lock = os.path.join(tempfile.gettempdir(), f"gcmf_resident_{tag}.lock")
+            self._shared_gpu = len(set(every)) < len(every)
 
     # -- data movement helpers -----------------------------------------------------------------
     def scatter_from_global(self, fields: Sequence[np.ndarray]):
@@ -476,13 +472,8 @@ class SlabFilter:
             self.comm if self.exchange_kind == "native" else None, self.p2p if self.exchange_kind == "p2p" else None,
             self.south, self.north, p, self.c, cut, X[0].data_ptr(), [st[k][0].data_ptr() for k in "ABCD"], O[0].data_ptr(), nbatch,
             self.halo, self.overlap, stream=t.cuda.current_stream().cuda_stream, resident=resident)
-        if self.resident and self._shared_gpu_lock is not None:
-            # Ranks sharing ONE GPU (tests): a resident launch of this process must not meet one of another process on the chip, and a
-            # rank must not sit in a resident launch while a neighbour it exchanges with waits for the lock -- so the slab runs the
-            # strip-marching launches here.  (The resident path of the slab driver is exercised on a ring of one rank.)
-            call(False)
-        else:
-            call(self.resident)
+        # (ranks sharing ONE GPU: never the on-chip kernel, see __init__; its slab path is exercised on a ring of one rank)
+        call(self.resident and not self._shared_gpu)
         if self.multi:
             self.exchanges += 1 + sum(1 for _ in self._exchange_points(cut))
         if self.time_kernels:
