@@ -651,6 +651,19 @@ def main_multi(args, world, rank, local_rank):
 
     from gcm_filters_amd import testing as T
 
+    # Under a launcher (torch.distributed.run) there is no parent of ours to watch the run: every rank carries its own dead-man timer.  A
+    # rank that sits in an unmatched collective for GCMF_BENCH_TIMEOUT_S says so and leaves with exit code 124 (os._exit works from a
+    # timer thread while the main thread is stuck in a HIP / RCCL call; the launcher then tears the other ranks down) -- a hang never
+    # lasts until the driver's own limit.
+    import threading
+    limit = float(os.environ.get("GCMF_BENCH_TIMEOUT_S", "1500"))
+
+    def _dead_man():
+        print(f"bench.py: rank {rank} did not finish within {limit:.0f} s (GCMF_BENCH_TIMEOUT_S): leaving with exit code 124", file=sys.stderr, flush=True)
+        os._exit(124)
+    dead_man = threading.Timer(limit, _dead_man)
+    dead_man.daemon = True
+    dead_man.start()
     share_gpu = os.environ.get("GCMF_BENCH_SHARE_GPU") == "1"  # test hook: all ranks on cuda:0 over gloo
     if share_gpu:
         local_rank = 0
@@ -868,6 +881,7 @@ def main_multi(args, world, rank, local_rank):
             print("bench.py: PARITY FAILURE -- " + "; ".join(failed), file=sys.stderr)
     dist.barrier()
     dist.destroy_process_group()
+    dead_man.cancel()
     return 1 if failed else 0
 
 

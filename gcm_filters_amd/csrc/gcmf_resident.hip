@@ -536,13 +536,17 @@ static ResGeom res_geometry(int kind, int Rr, int nx, int K, int max_wg) {
   return best;
 }
 
-struct ResState {      // per plan (lazily built)
-  double *ex = nullptr;        // four exchange planes
+// Exchange planes, tile flags and the failure word: ONE set per device and process, shared by every plan (resident kernels of a process
+// run one at a time, see below), grow-only and NEVER handed back to the allocator.  Round 4's fuzzing showed why: with per-plan
+// uncached allocations that were freed with their plan, one later filter in a few thousand -- of any kind, never one that ran on the
+// chip itself -- came out wrong (tools/fuzz_gpu.py under GCMF_RESIDENT=1): memory that has been mapped uncached and written past the L2
+// must not come back as an ordinary cached allocation while the L2 may still hold lines of its earlier life.
+struct ResArena {
+  char *ex = nullptr;
   size_t ex_bytes = 0;
   unsigned *flags = nullptr;   // 1024 epoch words
   unsigned *fail_host = nullptr, *fail_dev = nullptr;
   unsigned epoch = 0;
-  int max_wg = 0;
 };
 
 }  // namespace gcmf
@@ -550,24 +554,17 @@ struct ResState {      // per plan (lazily built)
 using namespace gcmf;
 
 namespace gcmf {
-void resident_free(gcmf_plan *pl) {   // gcmf_plan_destroy
-  ResState *st = (ResState *)pl->resident;
-  if (!st) return;
-  if (st->ex) (void)hipFree(st->ex);
-  if (st->flags) (void)hipFree(st->flags);
-  if (st->fail_host) (void)hipHostFree(st->fail_host);
-  delete st;
-  pl->resident = nullptr;
-}
+void resident_free(gcmf_plan *pl) { pl->resident = nullptr; }   // (nothing per plan any more)
 }  // namespace gcmf
 
 // Resident kernels of ONE process run one at a time, whatever streams they are launched on (two plans filtered from two threads): two
 // of them interleaved on the chip would each hold CUs the other's missing workgroups need.  A process-wide chain of events does it
 // without touching the host: every resident launch waits for the previous one's end.  (Two PROCESSES on one GPU cannot be chained; see
-// the header of this file.)
+// the header of this file.)  The same lock guards the arena.
 static std::mutex g_chain_mu;
 static hipEvent_t g_chain_ev[16] = {nullptr};
 static bool g_chain_set[16] = {false};
+static ResArena g_arena[16];
 
 template <int KIND, int RC> static int res_launch(const ResP &P, int nwg, hipStream_t s) {
   const size_t lds = (size_t)((KIND == K_FLUX && RC >= 13) ? 3 : 2) * RC * RES_NT * sizeof(double);
@@ -580,16 +577,6 @@ template <int KIND, int RC> static int res_launch(const ResP &P, int nwg, hipStr
   // the chip has drained (ordinary kernels always finish).  GCMF_RESIDENT_COOP=1 asks the runtime to guarantee it instead
   // (hipLaunchCooperativeKernel: its cooperative queue costs a cross-queue dependency per launch).
   static const bool coop = getenv("GCMF_RESIDENT_COOP") && atoi(getenv("GCMF_RESIDENT_COOP")) != 0;
-  int dev = 0;
-  GCMF_HIP(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> chain(g_chain_mu);
-  const int dq = dev & 15;
-  if (!g_chain_ev[dq]) GCMF_HIP(hipEventCreateWithFlags(&g_chain_ev[dq], hipEventDisableTiming));
-  if (g_chain_set[dq]) GCMF_HIP(hipStreamWaitEvent(s, g_chain_ev[dq], 0));
-  struct Mark {
-    hipEvent_t e; hipStream_t s; bool *set;
-    ~Mark() { if (hipEventRecord(e, s) == hipSuccess) *set = true; }
-  } mark{g_chain_ev[dq], s, &g_chain_set[dq]};
   if (coop) {
     ResP Pc = P;
     void *args[] = {(void *)&Pc};
@@ -686,30 +673,39 @@ int launch_resident(gcmf_plan *pl, const MultiArgs &a, const double *pk, int L, 
     set_error("k_resident: one field per launch");
     return GCMF_ERR_UNSUPPORTED;
   }
-  if (!pl->resident) pl->resident = new ResState();
-  ResState *st = (ResState *)pl->resident;
+  int dev = 0;
+  GCMF_HIP(hipGetDevice(&dev));
+  const int dq = dev & 15;
+  std::lock_guard<std::mutex> chain(g_chain_mu);
+  ResArena *st = &g_arena[dq];
   const size_t plane = (size_t)pl->g.rows * pl->g.nx * sizeof(double);
+  if (!g_chain_ev[dq]) GCMF_HIP(hipEventCreateWithFlags(&g_chain_ev[dq], hipEventDisableTiming));
   if (!st->flags) {
     GCMF_HIP(hipExtMallocWithFlags((void **)&st->flags, 1024 * sizeof(unsigned), hipDeviceMallocUncached));
-    GCMF_HIP(hipMemsetAsync(st->flags, 0, 1024 * sizeof(unsigned), s));
+    GCMF_HIP(hipMemset(st->flags, 0, 1024 * sizeof(unsigned)));
     GCMF_HIP(hipHostMalloc((void **)&st->fail_host, 64, hipHostMallocMapped));
     *st->fail_host = 0u;
     GCMF_HIP(hipHostGetDevicePointer((void **)&st->fail_dev, st->fail_host, 0));
   }
   if (st->ex_bytes < 4 * plane) {
-    if (st->ex) {
-      GCMF_HIP(hipStreamSynchronize(s));
-      (void)hipFree(st->ex);
-      st->ex = nullptr;
-    }
-    GCMF_HIP(hipExtMallocWithFlags((void **)&st->ex, 4 * plane, hipDeviceMallocUncached));
-    st->ex_bytes = 4 * plane;
+    // grow: a new, larger block; the old one stays where it is (an earlier launch may still be using it, and uncached memory is never
+    // handed back -- see ResArena)
+    const size_t want = std::max(4 * plane, 2 * st->ex_bytes);
+    char *blk = nullptr;
+    GCMF_HIP(hipExtMallocWithFlags((void **)&blk, want, hipDeviceMallocUncached));
+    st->ex = blk;
+    st->ex_bytes = want;
   }
   if (__atomic_load_n(st->fail_host, __ATOMIC_ACQUIRE)) {
-    set_error("k_resident: an earlier resident launch of this plan timed out waiting for a neighbour tile (was another process "
-              "running a resident kernel on this GPU?); its results are NaN");
+    set_error("k_resident: an earlier resident launch of this process timed out waiting for a neighbour tile (was another process "
+              "running a resident kernel on this GPU?  set GCMF_RESIDENT=0 there); its results are NaN");
     return GCMF_ERR_HIP;
   }
+  if (g_chain_set[dq]) GCMF_HIP(hipStreamWaitEvent(s, g_chain_ev[dq], 0));
+  struct Mark {
+    hipEvent_t e; hipStream_t s; bool *set;
+    ~Mark() { if (hipEventRecord(e, s) == hipSuccess) *set = true; }
+  } mark{g_chain_ev[dq], s, &g_chain_set[dq]};
   const Geom &gm = pl->g;
   ResP P{};
   P.u0 = (const double *)a.u0; P.v0 = (const double *)a.v0; P.uo = (double *)a.uo; P.vo = (double *)a.vo;
@@ -719,7 +715,7 @@ int launch_resident(gcmf_plan *pl, const MultiArgs &a, const double *pk, int L, 
   P.lbits = (pl->n_land > 0) ? pl->lbits : nullptr;
   P.area = (pl->kind != K_FLUX && gm.area_weighted) ? (const double *)gm.area : nullptr;
   for (int par = 0; par < 2; ++par)
-    for (int q = 0; q < 2; ++q) P.ex[par][q] = (double *)((char *)st->ex + (size_t)(par * 2 + q) * plane);
+    for (int q = 0; q < 2; ++q) P.ex[par][q] = (double *)(st->ex + (size_t)(par * 2 + q) * plane);
   P.flags = st->flags;
   P.fail = st->fail_dev;
   P.epoch0 = st->epoch;
