@@ -527,6 +527,9 @@ static ResGeom res_geometry(int kind, int Rr, int nx, int K, int max_wg) {
       int nty = std::min(max_wg / ntx, Rr / (2 * K) > 0 ? Rr / (2 * K) : 1);   // (tiles at least 2 K rows tall)
       if (nty < nty_min || nty < 1) continue;
       const int h = (Rr + nty - 1) / nty;
+      // the exchange stages the band and the halo of both states as flat lists in ONE free LDS buffer (RC * RES_NT doubles, half per
+      // state): the halo list, 2 K (w + h + 2 K) cells, must fit a half (tall narrow tiles of narrow grids would not)
+      if ((long long)2 * K * (w + h + 2 * K) > (long long)RC * RES_NT / 2) continue;
       const long long cost = (long long)RC * nruns * (h + 2 * K);
       if (!best.rc || cost < best.cost || (cost == best.cost && nty * ntx < best.nty * best.ntx)) {
         best.rc = RC; best.nty = nty; best.ntx = ntx; best.nruns = nruns; best.cost = cost;

@@ -34,6 +34,7 @@ def _levels_by_launches(plan, f, p, c, n, cut, torch):
     ("IRREGULAR_WITH_LAND", (96, 160), 16), ("IRREGULAR_WITH_LAND", (300, 364), 63), ("IRREGULAR_WITH_LAND", (37, 52), 11),
     ("MOM5U", (64, 96), 21), ("MOM5T", (100, 72), 13), ("REGULAR", (128, 128), 16), ("REGULAR_AREA_WEIGHTED", (90, 150), 24),
     ("REGULAR_WITH_LAND", (96, 160), 21), ("REGULAR_WITH_LAND_AREA_WEIGHTED", (150, 100), 56), ("REGULAR", (512, 512), 16),
+    ("IRREGULAR_WITH_LAND", (600, 24), 13), ("REGULAR", (24, 600), 16), ("REGULAR_WITH_LAND", (1000, 32), 24),   # tall / flat narrow grids
     ("IRREGULAR_WITH_LAND", (364, 3600), 32),       # the slab of one of eight ranks of BASELINE config 3 with its 2 x 32 ghost rows
 ])
 @pytest.mark.parametrize("nan", ["", "land", "wet"])
