@@ -460,33 +460,52 @@ def self_launch(args):
     if have < args.gpus and not share:
         raise SystemExit(f"bench.py: --gpus {args.gpus} requested but only {have} HIP device(s) are visible "
                          f"(set GCMF_BENCH_SHARE_GPU=1 to run all ranks on one GPU over gloo for testing)")
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    from gcm_filters_amd.testing import free_port
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
     # Watchdog: this parent never touches a GPU, so it is the one place that may kill a hung multi-rank run (an unmatched RCCL recv
     # waits for ever).  The children run in their own process group; on time-out the whole group is killed and the exit code says so.
     limit = float(os.environ.get("GCMF_BENCH_TIMEOUT_S", "1500"))
-    child = subprocess.Popen(cmd, env=env, start_new_session=True)
-    try:
-        raise SystemExit(child.wait(timeout=limit))
-    except subprocess.TimeoutExpired:
-        print(f"bench.py: the {args.gpus}-rank run did not finish within {limit:.0f} s (GCMF_BENCH_TIMEOUT_S): killing its process group",
-              file=sys.stderr)
+    t_start = time.time()
+    for attempt in range(3):
+        # the rendezvous port: below the ephemeral range (free_port), and if the launcher still finds it taken (EADDRINUSE: somebody else
+        # bound it between our check and its listen) the run is started again on another port -- seen once in ~50 runs with OS-chosen ports
+        port = free_port()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        child = subprocess.Popen(cmd, env=env, start_new_session=True, stderr=subprocess.PIPE, text=True)
+        seen = {"inuse": False}
+
+        def pump(pipe=child.stderr, seen=seen):
+            for line in pipe:
+                if "EADDRINUSE" in line or "address already in use" in line.lower():
+                    seen["inuse"] = True
+                sys.stderr.write(line)
+            pipe.close()
+        import threading
+        th = threading.Thread(target=pump, daemon=True)
+        th.start()
         try:
-            os.killpg(child.pid, signal.SIGKILL)
-        except ProcessLookupError:
-            pass
-        child.wait()
-        raise SystemExit(124)
-    except KeyboardInterrupt:
-        try:
-            os.killpg(child.pid, signal.SIGKILL)
-        except ProcessLookupError:
-            pass
-        raise
+            rc = child.wait(timeout=max(limit - (time.time() - t_start), 0.001))
+        except subprocess.TimeoutExpired:
+            print(f"bench.py: the {args.gpus}-rank run did not finish within {limit:.0f} s (GCMF_BENCH_TIMEOUT_S): killing its process group",
+                  file=sys.stderr)
+            try:
+                os.killpg(child.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            child.wait()
+            raise SystemExit(124)
+        except KeyboardInterrupt:
+            try:
+                os.killpg(child.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            raise
+        th.join(5)
+        if rc != 0 and seen["inuse"] and attempt < 2:
+            print(f"bench.py: rendezvous port {port} was taken (EADDRINUSE): starting the {args.gpus}-rank run again on another port", file=sys.stderr)
+            continue
+        raise SystemExit(rc)
 
 
 def parse():

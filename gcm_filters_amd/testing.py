@@ -269,3 +269,31 @@ def probe_points(shape, n=300, seed=2024):
     """Seeded (j, i) sample positions of the full-size golden probes (tests/golden/reference_fullsize.npz)."""
     rng = Generator(PCG64(seed))
     return rng.integers(0, shape[-2], n), rng.integers(0, shape[-1], n)
+
+
+def free_port(tries: int = 64) -> int:
+    """A TCP port for a local rendezvous (torch.distributed on 127.0.0.1) that is free NOW and that the kernel will not hand out as the
+    source port of somebody's outgoing connection a moment later: ports asked from the OS (bind to 0) come from the ephemeral range, where
+    exactly that happens -- `EADDRINUSE` when the rendezvous server finally listens (seen once in ~50 multi-process test runs on the GPU
+    boxes).  So: a random port BELOW the ephemeral range, checked by binding it."""
+    import random
+    import socket
+    lo_eph = 32768
+    try:
+        with open("/proc/sys/net/ipv4/ip_local_port_range") as f:
+            lo_eph = int(f.read().split()[0])
+    except (OSError, ValueError):
+        pass
+    hi = max(min(lo_eph, 32768), 12000)
+    rnd = random.Random()
+    for _ in range(tries):
+        port = rnd.randrange(10000, hi)
+        with socket.socket() as sk:
+            try:
+                sk.bind(("127.0.0.1", port))
+            except OSError:
+                continue
+            return port
+    with socket.socket() as sk:       # give up on the preference
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

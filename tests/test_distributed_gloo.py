@@ -16,9 +16,8 @@ from oracle import gcmf_oracle as O
 
 
 def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    from gcm_filters_amd.testing import free_port
+    return free_port()     # (below the ephemeral range: see its docstring)
 
 
 CASES = [

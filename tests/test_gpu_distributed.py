@@ -48,9 +48,8 @@ CASES_8 = [
 
 
 def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    from gcm_filters_amd.testing import free_port
+    return free_port()     # (below the ephemeral range: see its docstring)
 
 
 def _worker(rank, world, port, q, exchange="auto"):

@@ -7,9 +7,8 @@ sys.path.insert(0, "/root/repo")
 
 
 def free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    from gcm_filters_amd.testing import free_port as fp
+    return fp()
 
 
 def make_cases(seed, n, world):
