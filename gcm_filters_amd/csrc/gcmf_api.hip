@@ -539,7 +539,8 @@ static int clenshaw_cut(const gcmf_plan *pl, int n_steps, int *depths, int max_d
   // (tripolar plans: the seam rows run k_fold_band's backward form beside every launch)
   // f32 state: the flux kinds only (four cells per lane; the whole polynomial is then carried in f32 -- Filter(evaluation="reference") /
   // GCMF_FORWARD_RECURRENCE keep the reference's f64 running sum)
-  if (!pl->ring || !pl->zero_row || (pl->d.dtype != GCMF_F64 && pl->kind != K_FLUX) || pl->multi_s < 8 || !multi_supported(pl, 8)) return 0;
+  // (f32 state: the flux kinds since round 3, the REGULAR / land-mask kinds since round 4)
+  if (!pl->ring || !pl->zero_row || pl->multi_s < 8 || !multi_supported(pl, 8)) return 0;
   if (pl->n_land > 0 && !land_ok(pl, n_steps)) return 0;
   if (!(n_steps >= 10 || (n_steps >= 5 && n_steps <= 8))) return 0;
   int n = 0, left = n_steps;

@@ -301,9 +301,7 @@ int launch_fold_band(gcmf_plan *pl, const MultiArgs &a, bool backward, hipStream
   const bool f64 = pl->d.dtype == GCMF_F64, flux = pl->kind == K_FLUX;
   if (backward) {
     if (f64) return flux ? launch_fb<double, double, K_FLUX, true>(pl, a, s) : launch_fb<double, double, K_MASK, true>(pl, a, s);
-    if (flux) return launch_fb<float, float, K_FLUX, true>(pl, a, s);
-    set_error("k_fold_band: the backward evaluation runs f64 plans and f32 plans of the flux kinds");
-    return GCMF_ERR_UNSUPPORTED;
+    return flux ? launch_fb<float, float, K_FLUX, true>(pl, a, s) : launch_fb<float, float, K_MASK, true>(pl, a, s);
   }
   if (f64) return flux ? launch_fb<double, double, K_FLUX, false>(pl, a, s) : launch_fb<double, double, K_MASK, false>(pl, a, s);
   if (a.fb_is_f32) return flux ? launch_fb<float, float, K_FLUX, false>(pl, a, s) : launch_fb<float, float, K_MASK, false>(pl, a, s);

@@ -107,8 +107,8 @@ def test_default_is_backward_for_flux_kinds_and_forward_for_the_rest():
     got = flt.apply(f)
     assert "k_ringc<" not in plan.last_kernel()
     assert np.nanmax(np.abs(got - want)) <= 1e-12 * np.nanmax(np.abs(want))
-    # f32 state: backward for the flux kinds (four cells per lane), forward for the kinds that are bit-exact with numpy
-    for grid, backward in (("IRREGULAR_WITH_LAND", True), ("REGULAR_WITH_LAND", False)):
+    # f32 state: backward too (four cells per lane; the flux kinds since round 3, the REGULAR / land-mask kinds since round 4)
+    for grid, backward in (("IRREGULAR_WITH_LAND", True), ("REGULAR_WITH_LAND", True), ("REGULAR", True)):
         f32, gv = T.scalar_case(grid, (120, 256))
         gv = {k: v.astype("f4") for k, v in gv.items()}
         dx = T.grid_dx_min(grid, gv) if O.DIMENSIONAL[grid] else 1.0
@@ -248,7 +248,8 @@ def test_evaluation_option_reaches_the_plan_for_scalar_grids_too():
     assert np.abs(outs["auto"] - outs["reference"]).max() <= 1e-13 * np.abs(outs["reference"]).max()
 
 
-@pytest.mark.parametrize("grid", ["IRREGULAR_WITH_LAND", "MOM5U", "MOM5T", "TRIPOLAR_POP_WITH_LAND"])
+@pytest.mark.parametrize("grid", ["IRREGULAR_WITH_LAND", "MOM5U", "MOM5T", "TRIPOLAR_POP_WITH_LAND", "REGULAR_WITH_LAND", "REGULAR",
+                                  "REGULAR_WITH_LAND_AREA_WEIGHTED", "REGULAR_AREA_WEIGHTED", "TRIPOLAR_REGULAR_WITH_LAND_AREA_WEIGHTED"])
 @pytest.mark.parametrize("n_steps,kwargs", [(16, {}), (24, dict(nanland=True)), (63, {}), (21, dict(nanwet=True)), (15, dict(nb=3, nanland=True))])
 def test_f32_flux_kinds_backward_evaluation(grid, n_steps, kwargs):
     """f32 state on the flux-form grids runs k_ringc<float> (four cells per lane, no f64 running-sum ring).  Against the
@@ -260,7 +261,12 @@ def test_f32_flux_kinds_backward_evaluation(grid, n_steps, kwargs):
     nb = kwargs.get("nb", 1)
     if nb > 1:
         f = np.stack([f + 0.1 * i for i in range(nb)])
-    land = gv["wet_mask"] == 0
+    if "wet_mask" not in gv:       # (round 4: the REGULAR kinds run k_ringc<float> too; no land there, and NaN spreads -- kernels.py:113-121)
+        if kwargs.get("nanland") or kwargs.get("nanwet"):
+            pytest.skip("no land / no nan_to_num on REGULAR")
+        land = np.zeros(shape, bool)
+    else:
+        land = gv["wet_mask"] == 0
     if kwargs.get("nanland"):
         f = np.where(land, np.nan, f)
     if kwargs.get("nanwet"):
@@ -269,7 +275,7 @@ def test_f32_flux_kinds_backward_evaluation(grid, n_steps, kwargs):
         f[..., j, i] = np.nan
     f4 = f.astype("f4")
     gv4 = {k: v.astype("f4") for k, v in gv.items()}
-    dx = T.grid_dx_min(grid, gv4)
+    dx = T.grid_dx_min(grid, gv4) if O.DIMENSIONAL[grid] else 1.0
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         flt = Filter(filter_scale=4.0 * dx, dx_min=dx, n_steps=n_steps, filter_shape=FilterShape.TAPER, grid_type=GridType[grid], grid_vars=gv4)
