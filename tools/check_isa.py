@@ -160,22 +160,32 @@ def main():
         names = demangle([k["name"] for k in kernels])
         for k, d in zip(kernels, names):
             k["dname"] = d.replace("void ", "").split("(")[0]
-        watched = [k for k in kernels if re.search(r"gcmf::k_(ring|ringc|ringcs|fold_band|cgrid_stream2c?|bgrid_stream2)<", k["dname"])]
+        watched = [k for k in kernels if re.search(r"gcmf::k_(ring|ringc|ringcs|fold_band|resident|cgrid_stream2c?|bgrid_stream2)<", k["dname"])]
         for k in sorted(watched, key=lambda k: k["dname"]):
             total = k["vgpr"]   # gfx90a and later: .vgpr_count is the unified total (architected + accumulation registers)
             alloc = (total + 7) // 8 * 8
             if args.v:
                 print(f"{k['dname']:70s} registers {k['vgpr']:3d} (of them accumulation {k['agpr']:3d}) allocated {alloc:3d} scratch {k['scratch']:4d} lds {k['lds']}")
-            if k["scratch"] and not re.search(r"k_[cb]grid_stream2", k["dname"]):
+            if k["scratch"] and not re.search(r"k_[cb]grid_stream2|k_resident<", k["dname"]):
                 failures.append(f"{k['dname']}: {k['scratch']} bytes of scratch per lane")
+            # k_resident's deepest instantiations park a dozen loop-invariant index words (the flat band / halo list bases) in scratch: written
+            # once before the level loop, read back in the tile exchange, nothing of it inside a level (checked in the ISA, round 4)
+            if "k_resident<" in k["dname"] and k["scratch"] > 64:
+                failures.append(f"{k['dname']}: {k['scratch']} bytes of scratch per lane (> 64: the level loop is probably spilling)")
             if "k_fold_band<" in k["dname"] and alloc > BAND_BUDGET:
                 failures.append(f"{k['dname']}: {alloc} registers > {BAND_BUDGET}: its waves no longer fit beside a k_ringc wave")
             if re.search(r"k_ringc<(double|float), 2,", k["dname"]) and alloc > RING_FLUX_BUDGET:
                 failures.append(f"{k['dname']}: {alloc} registers > {RING_FLUX_BUDGET}: no room for k_fold_band's waves on its SIMD (tripolar plans)")
             if re.search(r"k_ringc?s?<", k["dname"]) and alloc > 512:
                 failures.append(f"{k['dname']}: {alloc} registers > 512")
+            # the on-chip kernel: 512 threads = two waves per SIMD, so 256 registers and not a byte of scratch (its cells LIVE in registers)
+            if "k_resident<" in k["dname"] and alloc > 256:
+                failures.append(f"{k['dname']}: {alloc} registers > 256: a 512-thread workgroup no longer fits a CU")
         n_ring = sum(1 for k in watched if re.search(r"k_ringc?s?<", k["dname"]))
         n_band = sum(1 for k in watched if "k_fold_band<" in k["dname"])
+        n_res = sum(1 for k in watched if "k_resident<" in k["dname"])
+        if n_res < 11:
+            failures.append(f"{n_res} k_resident instantiations found, 11 expected (three kinds x cells per thread)")
         print(f"{len(kernels)} gfx950 kernels, {n_ring} k_ring / k_ringc and {n_band} k_fold_band instantiations checked for scratch and register budgets")
         if n_ring < 20 or n_band < 6:
             failures.append("fewer ring / band kernels found than the library instantiates: the metadata parser is out of date")
