@@ -212,27 +212,23 @@ __global__ __launch_bounds__(RES_NT, 2) void k_resident(const ResP P) {
     }
     return o;
   };
+  int goff[RC];        // (the load phase only: the store phase recomputes them instead of keeping RC registers through the levels)
+#pragma unroll
+  for (int k = 0; k < RC; ++k) goff[k] = offs(k);
   double *stgA = xs, *stgB = xs + NB;             // staging: PH * PW <= RC * RES_NT doubles each
-  // two planes in flight, half the cells of a thread at a time (the offsets are recomputed rather than kept: with all RC loads of two
-  // planes and RC offsets live at once the deepest instantiations spilled to scratch)
-  auto stage2 = [&](const double *pa, const double *pb) {   // (call between barriers)
-    constexpr int HALF = (RC + 1) / 2;
+  auto stage2 = [&](const double *pa, const double *pb) {   // (call between barriers) two planes in flight
+    double va[RC], vb[RC];
 #pragma unroll
-    for (int k0 = 0; k0 < RC; k0 += HALF) {
-      double va[HALF], vb[HALF];
+    for (int k = 0; k < RC; ++k) {
+      va[k] = goff[k] >= 0 ? pa[goff[k]] : 0.0;
+      vb[k] = goff[k] >= 0 ? pb[goff[k]] : 0.0;
+    }
 #pragma unroll
-      for (int k = 0; k < HALF; ++k) {
-        const int o = (k0 + k < RC) ? offs(k0 + k) : -1;
-        va[k] = o >= 0 ? pa[o] : 0.0;
-        vb[k] = o >= 0 ? pb[o] : 0.0;
-      }
-#pragma unroll
-      for (int k = 0; k < HALF; ++k) {
-        const int e = (k0 + k) * RES_NT + tid;
-        if (k0 + k < RC && e < PH * PW) {
-          stgA[e] = va[k];
-          stgB[e] = vb[k];
-        }
+    for (int k = 0; k < RC; ++k) {
+      const int e = k * RES_NT + tid;
+      if (e < PH * PW) {
+        stgA[e] = va[k];
+        stgB[e] = vb[k];
       }
     }
   };
@@ -246,31 +242,26 @@ __global__ __launch_bounds__(RES_NT, 2) void k_resident(const ResP P) {
   {
     // round 1: the constant input -- prepare()d (x area, kernels.py:100-101) and land-masked as it is staged -- and the first
     // coefficient plane (flux kinds) / the mask bytes (land-mask kinds)
-    constexpr int HALF = (RC + 1) / 2;
+    double va[RC], vb[RC];
 #pragma unroll
-    for (int k0 = 0; k0 < RC; k0 += HALF) {
-      double va[HALF], vb[HALF];
-#pragma unroll
-      for (int k = 0; k < HALF; ++k) {
-        const int o = (k0 + k < RC) ? offs(k0 + k) : -1;
-        double fv = 0.0, q = 0.0;
-        if (o >= 0) {
-          fv = P.f[o];
-          if (P.area) fv = fv * P.area[o];
-          if (P.lbits && !(P.lbits[o] & 1u)) fv = 0.0;
-          if constexpr (FLUX) q = P.cE[o];
-          if constexpr (MASK) q = (double)P.mbits[o];
-        }
-        va[k] = fv;
-        vb[k] = q;
+    for (int k = 0; k < RC; ++k) {
+      double fv = 0.0, q = 0.0;
+      if (goff[k] >= 0) {
+        fv = P.f[goff[k]];
+        if (P.area) fv = fv * P.area[goff[k]];
+        if (P.lbits && !(P.lbits[goff[k]] & 1u)) fv = 0.0;
+        if constexpr (FLUX) q = P.cE[goff[k]];
+        if constexpr (MASK) q = (double)P.mbits[goff[k]];
       }
+      va[k] = fv;
+      vb[k] = q;
+    }
 #pragma unroll
-      for (int k = 0; k < HALF; ++k) {
-        const int e = (k0 + k) * RES_NT + tid;
-        if (k0 + k < RC && e < PH * PW) {
-          stgA[e] = va[k];
-          stgB[e] = vb[k];
-        }
+    for (int k = 0; k < RC; ++k) {
+      const int e = k * RES_NT + tid;
+      if (e < PH * PW) {
+        stgA[e] = va[k];
+        stgB[e] = vb[k];
       }
     }
   }
