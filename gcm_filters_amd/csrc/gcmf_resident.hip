@@ -504,7 +504,7 @@ __global__ __launch_bounds__(RES_NT, 2) void k_resident(const ResP P) {
 // ---- host side -----------------------------------------------------------------------------------------------------------------
 
 struct ResGeom {
-  int rc = 0, nty = 0, ntx = 0, nruns = 0;
+  int rc = 0, nty = 0, ntx = 0, nruns = 0, K = 4;
   long long cost = 0;
 };
 
@@ -625,9 +625,23 @@ static bool res_supported(const gcmf_plan *pl, int row_lo, int row_hi, int L, Re
   int dev = 0, ncu = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
   if (const char *e = getenv("GCMF_RESIDENT_MAX_WG")) ncu = std::min(ncu, std::max(1, atoi(e)));
-  const int K = 4;
-  if (pl->g.nx < 2 * K + 16 || r_hi - r_lo < 2 * K) return false;
-  const ResGeom g = res_geometry(res_kind(pl), r_hi - r_lo, pl->g.nx, K, ncu);
+  // The halo depth K = levels between two tile exchanges: deeper halos cost padded cells (every level works on them), shallower ones
+  // cost exchanges.  Measured (tools/measure_resident_k.py, us per application at K = 4 / 8 / 12): IRREGULAR 256 x 256 n 63: 92 / 72 / 138;
+  // 512 x 512: 110 / 110 / 154; 600 x 640: 143 / 116 / 158; REGULAR 512 x 512 n 36: 55 / 54 / 71; REGULAR_WITH_LAND 720 x 1440 n 56:
+  // 200 / 183 / 167.  So: K = 8 where a geometry exists for it, else K = 4 (the 8-way slab of 2400 x 3600 only fits K = 4);
+  // GCMF_RESIDENT_K forces one (4, 8, 12).
+  ResGeom g;
+  static const int k_force = getenv("GCMF_RESIDENT_K") ? atoi(getenv("GCMF_RESIDENT_K")) : 0;
+  for (int K : {8, 4, 12}) {
+    if (k_force ? K != k_force : K == 12) continue;
+    if (pl->g.nx < 2 * K + 16 || r_hi - r_lo < 2 * K) continue;
+    const ResGeom c = res_geometry(res_kind(pl), r_hi - r_lo, pl->g.nx, K, ncu);
+    if (!c.rc) continue;
+    g = c;
+    g.K = K;
+    break;
+  }
+  (void)L;
   if (!g.rc) return false;
   if (g_out) *g_out = g;
   if (r_lo_out) *r_lo_out = r_lo;
@@ -724,7 +738,7 @@ int launch_resident(gcmf_plan *pl, const MultiArgs &a, const double *pk, int L, 
   P.epoch0 = st->epoch;
   P.nx = gm.nx; P.rows = gm.rows;
   P.r_lo = r_lo; P.r_hi = r_hi; P.out_lo = a.row_lo; P.out_hi = a.row_hi;
-  P.nty = g.nty; P.ntx = g.ntx; P.nruns = g.nruns; P.K = 4; P.L = L;
+  P.nty = g.nty; P.ntx = g.ntx; P.nruns = g.nruns; P.K = g.K; P.L = L;
   P.wrap = wrap ? 1 : 0;
   P.first = a.first; P.last = a.last;
   const int nwg = g.nty * g.ntx;
