@@ -438,6 +438,62 @@ def run_config1(dev):
     return rec
 
 
+def run_small_onchip(dev, no_cpu):
+    """Not a BASELINE config: a small flux-form grid (IRREGULAR_WITH_LAND 512x512, the headline's filter: Taper, filter_scale 16 dx_min,
+    n_steps 63) -- the north star's "whole n_steps polynomial fused into a single launch": gcmf_apply runs whole grids of up to 400 k
+    cells on the chip (csrc/gcmf_resident.hip).  Reports the on-chip launch, the strip-marching launches of the same
+    filter (GCMF_RESIDENT=0: eight launches, same bits) and, unless --no-cpu, the oracle parity of the result."""
+    import torch
+
+    from gcm_filters_amd import Filter, FilterShape, GridType, _lib, testing as T
+    from gcm_filters_amd.kernels import ALL_KERNELS
+
+    shape = (512, 512)
+    f, gv = T.scalar_case("IRREGULAR_WITH_LAND", shape)
+    dx = T.grid_dx_min("IRREGULAR_WITH_LAND", gv)
+    flt = Filter(filter_scale=16 * dx, dx_min=dx, filter_shape=FilterShape.TAPER, grid_type=GridType.IRREGULAR_WITH_LAND, grid_vars=gv)
+    plan = ALL_KERNELS[GridType.IRREGULAR_WITH_LAND](**gv)._plan(_lib.F64, shape, dev.index)
+    d = torch.from_numpy(f).to(dev)
+
+    def timed():
+        for _ in range(5):
+            out = flt.apply(d)
+        torch.cuda.synchronize()
+        plan.last_kernel()
+        blocks = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for _ in range(100):
+                out = flt.apply(d)
+            torch.cuda.synchronize()
+            blocks.append((time.perf_counter() - t0) / 100)
+        return sorted(blocks)[2], out, plan.last_kernel(), plan.last_kernel_geometry()
+    before = os.environ.get("GCMF_RESIDENT")
+    try:
+        t_chip, out, k_chip, geom = timed()
+        os.environ["GCMF_RESIDENT"] = "0"
+        t_strip, out2, k_strip, _ = timed()
+    finally:
+        if before is None:
+            os.environ.pop("GCMF_RESIDENT", None)
+        else:
+            os.environ["GCMF_RESIDENT"] = before
+    n = int(flt.n_steps)
+    rec = {"config": f"extra: IRREGULAR_WITH_LAND 512x512 f64, Taper filter_scale=16 dx_min, n_steps={n} (small grid: whole polynomial on the chip)",
+           "n_steps": n, "value": shape[0] * shape[1] * n / t_chip, "unit": "cell-steps/s", "us_per_application": 1e6 * t_chip,
+           "kernel": k_chip, "geometry": geom, "launches_per_application": 1 if "k_resident" in k_chip else None,
+           "strip_marching": {"us_per_application": 1e6 * t_strip, "kernel": k_strip, "same_bits": bool(torch.equal(out.nan_to_num(), out2.nan_to_num()))},
+           "dtype": "f64"}
+    if not no_cpu:
+        from oracle import gcmf_oracle as O
+        fs = flt.filter_spec
+        want = O.filter_func(O.FilterSpec(fs.n_steps, fs.s_max, np.asarray(fs.p), fs.dx_min_sq), "IRREGULAR_WITH_LAND", f, gv)
+        got = out.cpu().numpy()
+        rec["parity"] = {"rel_err": float(np.abs(got - want).max() / np.abs(want).max()), "tolerance": 1e-6,
+                         "checked_against": "oracle, same grid / field / whole polynomial"}
+    return rec
+
+
 def free_gpu():
     import gc
 
@@ -615,6 +671,9 @@ def main_single(args):
         extras = [run_config1(dev)]
         if not extras[0].get("parity", {"rel_err": 0})["rel_err"] <= 1e-6:
             failed.append(f"config 1 reference probe: rel_err {extras[0]['parity']['rel_err']:.3e}")
+        small = run_small_onchip(dev, args.no_cpu)
+        if not small.get("parity", {"rel_err": 0})["rel_err"] <= 1e-6 or not small["strip_marching"]["same_bits"]:
+            failed.append(f"small on-chip grid: parity {small.get('parity')} same bits as the strip-marching launches: {small['strip_marching']['same_bits']}")
         for cfg in (2, 4, 5):
             if cfg == args.config:
                 continue
@@ -654,6 +713,7 @@ def main_single(args):
                         failed.append(f"config {cfg} forward (reference) evaluation: rel_err {opt['parity']['rel_err']:.3e}")
                 rec["forward_reference_opt_in"] = opt
             extras.append(rec)
+        extras.append(small)
         out["extra_configs"] = extras
     if args.config == 5 and not args.no_cpu:
         out["cpu_baseline_pool"] = cpu_baseline_pool(5, args.ny, args.nx, nbatch_main, 4)
