@@ -365,3 +365,32 @@ def test_plan_cache_factory_error_leaves_no_gate_behind():
     with pytest.raises(ValueError):
         cache.get(("k",), boom)
     assert cache.get(("k",), _FakePlan).closed == 0 and not cache._building
+
+
+def test_rendezvous_ports_come_from_below_the_ephemeral_range():
+    """tests / bench.py pick their local torch.distributed rendezvous port with testing.free_port(): free now, and outside the range the kernel
+    hands out as source ports of outgoing connections (an OS-chosen port was found taken -- EADDRINUSE -- once in ~50 multi-process runs)."""
+    import socket
+    from gcm_filters_amd.testing import free_port
+    lo = 32768
+    try:
+        lo = int(open("/proc/sys/net/ipv4/ip_local_port_range").read().split()[0])
+    except (OSError, ValueError):
+        pass
+    ports = {free_port() for _ in range(20)}
+    assert len(ports) >= 10 and all(10000 <= p < max(min(lo, 32768), 12000) for p in ports)
+    p = free_port()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", p))      # really free
+
+
+def test_build_is_serialised_and_a_fresh_binary_is_not_rebuilt(tmp_path):
+    """_build.build_library: an inter-process lock around the build (the ranks of a torchrun job all find a stale binary at once), an early
+    return when the binary already carries the sources' build id, the link through a temporary name (advisor finding, round 3)."""
+    import inspect
+    from gcm_filters_amd import _build
+    src = inspect.getsource(_build.build_library) + inspect.getsource(_build._build_library_locked)
+    assert "fcntl.flock" in src and "os.replace(tmp, LIB)" in src
+    if _build.binary_build_id() == _build.source_build_id():
+        before = os.path.getmtime(_build.LIB)
+        assert _build.build_library() == _build.LIB and os.path.getmtime(_build.LIB) == before
