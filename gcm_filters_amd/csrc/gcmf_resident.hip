@@ -745,7 +745,7 @@ int launch_resident(gcmf_plan *pl, const MultiArgs &a, const double *pk, int L, 
   P.xcd_per = (pl->xcd_remap && nwg % 8 == 0) ? nwg / 8 : 0;
   for (int t = 0; t < RES_MAXL; ++t) P.pk[t] = t < L ? pk[t] : 0.0;
   P.p0 = a.p0; P.c = a.c;
-  long long ms = 2000;
+  long long ms = 10000;   // a tile waits this long for a neighbour (another kernel may be holding CUs for a while); a real clash ends here, loudly
   if (const char *e = getenv("GCMF_RESIDENT_TIMEOUT_MS")) ms = std::max(1LL, atoll(e));
   P.spin_limit = ms * 100000LL;
   st->epoch += (unsigned)((L - 1) / P.K);
