@@ -94,8 +94,11 @@ __device__ __forceinline__ double dev_load(const double *p) {
                                                            __HIP_MEMORY_SCOPE_AGENT));
 }
 
-template <int KIND, int RC>
-__global__ __launch_bounds__(RES_NT, 2) void k_resident(const ResP P) {
+// NT = threads per workgroup: 512 (two waves per SIMD, up to 256 registers: the deep instantiations) or 1024 (four waves per SIMD, 128
+// registers: RC = 4 only -- small tiles, where a level is bound by latency and more waves hide more of it)
+template <int KIND, int RC, int NT>
+__global__ __launch_bounds__(NT, NT / 256) void k_resident(const ResP P) {
+  constexpr int RES_NT = NT;
   constexpr bool FLUX = (KIND == K_FLUX), MASK = (KIND == K_MASKZ);
   constexpr bool WATCH = (KIND != K_REG);
   // the deepest flux instantiation keeps the constant input in LDS (a third plane) instead of 2 * RC registers: 256 registers spilled
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(RES_NT, 2) void k_resident(const ResP P) {
 // ---- host side -----------------------------------------------------------------------------------------------------------------
 
 struct ResGeom {
-  int rc = 0, nty = 0, ntx = 0, nruns = 0, K = 4;
+  int rc = 0, nt = 512, nty = 0, ntx = 0, nruns = 0, K = 4;
   long long cost = 0;
 };
 
@@ -512,27 +515,32 @@ struct ResGeom {
 // has RES_NT threads and 2 * RC * RES_NT * 8 bytes of LDS.  The cheapest geometry = the fewest padded cells per workgroup.
 static ResGeom res_geometry(int kind, int Rr, int nx, int K, int max_wg) {
   ResGeom best;
-  const int rcs_flux[] = {4, 8, 13}, rcs_other[] = {4, 8, 13, 16};
-  const int *rcs = kind == K_FLUX ? rcs_flux : rcs_other;
-  const int nrc = kind == K_FLUX ? 3 : 4;
+  // (RC, NT) pairs on offer: 1024 threads only with four cells per thread (128 registers per lane)
+  const int rcs_flux[][2] = {{4, 1024}, {4, 512}, {8, 512}, {13, 512}}, rcs_other[][2] = {{4, 1024}, {4, 512}, {8, 512}, {13, 512}, {16, 512}};
+  const int(*rcs)[2] = kind == K_FLUX ? rcs_flux : rcs_other;
+  const int nrc = kind == K_FLUX ? 4 : 5;
+  static const int nt_force = getenv("GCMF_RESIDENT_NT") ? atoi(getenv("GCMF_RESIDENT_NT")) : 0;
   for (int q = 0; q < nrc; ++q) {
-    const int RC = rcs[q];
+    const int RC = rcs[q][0], NT = rcs[q][1];
+    if (nt_force && NT != nt_force) continue;
     for (int ntx = 1; ntx <= max_wg && ntx <= nx; ++ntx) {
       const int w = (nx + ntx - 1) / ntx;
       if (nx / ntx < 2 * K) continue;                        // tiles at least 2 K wide: the flat band lists do not overlap
       const int nruns = (w + 2 * K + RC - 1) / RC;
-      const int ph_max = RES_NT / nruns;
+      const int ph_max = NT / nruns;
       if (ph_max <= 2 * K) continue;
       const int nty_min = (Rr + (ph_max - 2 * K) - 1) / (ph_max - 2 * K);
       int nty = std::min(max_wg / ntx, Rr / (2 * K) > 0 ? Rr / (2 * K) : 1);   // (tiles at least 2 K rows tall)
       if (nty < nty_min || nty < 1) continue;
       const int h = (Rr + nty - 1) / nty;
-      // the exchange stages the band and the halo of both states as flat lists in ONE free LDS buffer (RC * RES_NT doubles, half per
+      // the exchange stages the band and the halo of both states as flat lists in ONE free LDS buffer (RC * NT doubles, half per
       // state): the halo list, 2 K (w + h + 2 K) cells, must fit a half (tall narrow tiles of narrow grids would not)
-      if ((long long)2 * K * (w + h + 2 * K) > (long long)RC * RES_NT / 2) continue;
+      if ((long long)2 * K * (w + h + 2 * K) > (long long)RC * NT / 2) continue;
+      // cost = padded cells per workgroup (what every level works through); within 3 % the geometry with FEWER cells per thread wins
+      // (more waves to hide the LDS / issue latency of a level: the pairs are tried in that order), then the one with fewer tiles
       const long long cost = (long long)RC * nruns * (h + 2 * K);
-      if (!best.rc || cost < best.cost || (cost == best.cost && nty * ntx < best.nty * best.ntx)) {
-        best.rc = RC; best.nty = nty; best.ntx = ntx; best.nruns = nruns; best.cost = cost;
+      if (!best.rc || cost * 103 < best.cost * 100 || (cost == best.cost && RC == best.rc && nty * ntx < best.nty * best.ntx)) {
+        best.rc = RC; best.nt = NT; best.nty = nty; best.ntx = ntx; best.nruns = nruns; best.cost = cost;
       }
     }
   }
@@ -569,11 +577,11 @@ static hipEvent_t g_chain_ev[16] = {nullptr};
 static bool g_chain_set[16] = {false};
 static ResArena g_arena[16];
 
-template <int KIND, int RC> static int res_launch(const ResP &P, int nwg, hipStream_t s) {
-  const size_t lds = (size_t)((KIND == K_FLUX && RC >= 13) ? 3 : 2) * RC * RES_NT * sizeof(double);
+template <int KIND, int RC, int NT = 512> static int res_launch(const ResP &P, int nwg, hipStream_t s) {
+  const size_t lds = (size_t)((KIND == K_FLUX && RC >= 13) ? 3 : 2) * RC * NT * sizeof(double);
   static bool attr_done = false;
   if (!attr_done) {
-    GCMF_HIP(hipFuncSetAttribute((const void *)k_resident<KIND, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GCMF_HIP(hipFuncSetAttribute((const void *)k_resident<KIND, RC, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
   // A plain launch: the grid has at most one workgroup per CU, so every workgroup becomes resident as soon as whatever ran before on
@@ -583,15 +591,16 @@ template <int KIND, int RC> static int res_launch(const ResP &P, int nwg, hipStr
   if (coop) {
     ResP Pc = P;
     void *args[] = {(void *)&Pc};
-    GCMF_HIP(hipLaunchCooperativeKernel((const void *)k_resident<KIND, RC>, dim3(nwg), dim3(RES_NT), args, (unsigned)lds, s));
+    GCMF_HIP(hipLaunchCooperativeKernel((const void *)k_resident<KIND, RC, NT>, dim3(nwg), dim3(NT), args, (unsigned)lds, s));
   } else {
-    hipLaunchKernelGGL((k_resident<KIND, RC>), dim3(nwg), dim3(RES_NT), lds, s, P);
+    hipLaunchKernelGGL((k_resident<KIND, RC, NT>), dim3(nwg), dim3(NT), lds, s, P);
     GCMF_HIP(hipGetLastError());
   }
   return GCMF_OK;
 }
 
-template <int KIND> static int res_launch_kind(int rc, const ResP &P, int nwg, hipStream_t s) {
+template <int KIND> static int res_launch_kind(int rc, int nt, const ResP &P, int nwg, hipStream_t s) {
+  if (nt == 1024 && rc == 4) return res_launch<KIND, 4, 1024>(P, nwg, s);
   switch (rc) {
     case 4: return res_launch<KIND, 4>(P, nwg, s);
     case 8: return res_launch<KIND, 8>(P, nwg, s);
@@ -655,7 +664,7 @@ namespace gcmf {
 // Whether gcmf_apply / gcmf_slab_apply_backward pick the resident kernel BY THEMSELVES (it is bit-identical to the strip-marching launches,
 // so this is a question of speed only; measured in round 4, tools/measure_resident.py):
 //   * whole small grids (gcmf_apply, `whole`): yes up to 400 k cells -- the polynomial runs in ONE launch and the tiles are small enough
-//     for the flag exchanges to be cheap: IRREGULAR 512 x 512, n 63: 106 us against 179 us for eight strip-marching launches; at
+//     for the flag exchanges to be cheap: IRREGULAR 512 x 512, n 63: 88 us against 179 us for eight strip-marching launches; at
 //     720 x 1440 the two are equal or the strips win.  The REGULAR / land-mask kinds (cheaper levels, two strip launches for 16 levels)
 //     only from 24 levels on: 512 x 512 n 36 51.7 against 54.5 us, but n 16 (BASELINE config 1) 25.4-28.9 against 23.6-27.1 us;
 //   * row slabs of a multi-GPU run: no -- on the 8-way slab of 2400 x 3600 a tile exchange costs ~9.5 us against ~1 us per level and
@@ -751,14 +760,14 @@ int launch_resident(gcmf_plan *pl, const MultiArgs &a, const double *pk, int L, 
   st->epoch += (unsigned)((L - 1) / P.K);
   int rc;
   switch (res_kind(pl)) {
-    case K_FLUX: rc = res_launch_kind<K_FLUX>(g.rc, P, nwg, s); break;
-    case K_MASKZ: rc = res_launch_kind<K_MASKZ>(g.rc, P, nwg, s); break;
-    default: rc = res_launch_kind<K_REG>(g.rc, P, nwg, s); break;
+    case K_FLUX: rc = res_launch_kind<K_FLUX>(g.rc, g.nt, P, nwg, s); break;
+    case K_MASKZ: rc = res_launch_kind<K_MASKZ>(g.rc, g.nt, P, nwg, s); break;
+    default: rc = res_launch_kind<K_REG>(g.rc, g.nt, P, nwg, s); break;
   }
   if (rc) return rc;
   char geom[160];
-  snprintf(geom, sizeof geom, "tiles=%dx%d RC=%d nruns=%d K=%d L=%d rowlo=%d rowhi=%d", g.nty, g.ntx, g.rc, g.nruns, P.K, L, r_lo, r_hi);
-  note_kernel(pl, std::string("gcmf::k_resident<") + std::to_string(res_kind(pl)) + ", " + std::to_string(g.rc) + ">", L, geom);
+  snprintf(geom, sizeof geom, "tiles=%dx%d RC=%d NT=%d nruns=%d K=%d L=%d rowlo=%d rowhi=%d", g.nty, g.ntx, g.rc, g.nt, g.nruns, P.K, L, r_lo, r_hi);
+  note_kernel(pl, std::string("gcmf::k_resident<") + std::to_string(res_kind(pl)) + ", " + std::to_string(g.rc) + ", " + std::to_string(g.nt) + ">", L, geom);
   return GCMF_OK;
 }
 
