@@ -279,8 +279,12 @@ def run_single(cfg, args, dev, steps, warmup, scale=0.0, levels=None, tuned=Fals
             clear_plan_cache()
             keep_away = torch.empty(48 << 20, dtype=torch.uint8, device=dev)   # nudge the allocator: the new planes land elsewhere
             plan = make_plan()
-            outs = run()          # untimed: first application on the new plan (lazy state buffers, clocks)
+            t_w = time.perf_counter()
+            outs = run()          # untimed: first application on the new plan (lazy state buffers) ...
             torch.cuda.synchronize()
+            while time.perf_counter() - t_w < 0.05:   # ... and 50 ms of them: the GPU idled while the host folded the plan and takes tens of
+                outs = run()                          # milliseconds to clock up again (one block in five came out 2-3 x slow without this)
+                torch.cuda.synchronize()
             del keep_away
             replans += 1
         t0 = time.perf_counter()
