@@ -663,7 +663,7 @@ namespace gcmf {
 
 // Whether gcmf_apply / gcmf_slab_apply_backward pick the resident kernel BY THEMSELVES (it is bit-identical to the strip-marching launches,
 // so this is a question of speed only; measured in round 4, tools/measure_resident.py):
-//   * whole small grids (gcmf_apply, `whole`): yes up to 400 k cells -- the polynomial runs in ONE launch and the tiles are small enough
+//   * whole small grids (gcmf_apply, `whole`): yes while the tiles fit the 1024-thread geometry (~420 k cells) -- the polynomial runs in ONE launch and the tiles are small enough
 //     for the flag exchanges to be cheap: IRREGULAR 512 x 512, n 63: 88 us against 179 us for eight strip-marching launches; at
 //     720 x 1440 the two are equal or the strips win.  The REGULAR / land-mask kinds (cheaper levels, two strip launches for 16 levels)
 //     only from 24 levels on: 512 x 512 n 36 51.7 against 54.5 us, but n 16 (BASELINE config 1) 25.4-28.9 against 23.6-27.1 us;
@@ -674,13 +674,19 @@ bool resident_supported(const gcmf_plan *pl, int row_lo, int row_hi, int L, int 
   const char *e = getenv("GCMF_RESIDENT");
   const int mode = e ? atoi(e) : -1;
   if (mode == 0) return false;
+  ResGeom g;
+  if (!res_supported(pl, row_lo, row_hi, L, &g, nullptr, nullptr, nullptr)) return false;
   if (mode < 0) {
-    static const long long max_cells = getenv("GCMF_RESIDENT_MAX_CELLS") ? atoll(getenv("GCMF_RESIDENT_MAX_CELLS")) : 400000LL;
+    // auto: whole grids whose tiles are small enough for the 1024-thread / four-cells-per-thread geometry (up to ~420 k cells on 256
+    // CUs) -- tools/measure_resident_sizes.py: on chip / strips = 0.46-0.56 (IRREGULAR n 63), 0.55-0.69 (REGULAR_WITH_LAND n 56),
+    // 0.67-0.86 (REGULAR n 56) at 147-410 k cells, and 1.0-1.4 from 640 k cells on, where the tiles need 13-16 cells per thread
+    static const long long max_cells = getenv("GCMF_RESIDENT_MAX_CELLS") ? atoll(getenv("GCMF_RESIDENT_MAX_CELLS")) : 0;
     const bool whole = pl && row_lo == 0 && row_hi == pl->g.rows && pl->full;
-    if (!whole || (long long)pl->g.rows * pl->g.nx > max_cells) return false;
+    if (!whole) return false;
+    if (max_cells > 0 ? (long long)pl->g.rows * pl->g.nx > max_cells : !(g.rc == 4 && g.nt == 1024)) return false;
     if (pl->kind != K_FLUX && n_total < 24) return false;
   }
-  return res_supported(pl, row_lo, row_hi, L, nullptr, nullptr, nullptr, nullptr);
+  return true;
 }
 
 bool resident_fits(const gcmf_plan *pl, int row_lo, int row_hi, int L) { return res_supported(pl, row_lo, row_hi, L, nullptr, nullptr, nullptr, nullptr); }

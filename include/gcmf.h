@@ -347,7 +347,7 @@ int gcmf_slab_apply_backward_vec(gcmf_plan *plan, gcmf_comm *comm, gcmf_p2p *p2p
  * chip (the 300-row slab of an 8-way cut of 2400 x 3600 with its ghost rows; 512 x 512; up to ~1.5 M f64 cells).  One workgroup per CU owns
  * a 2-D tile for up to 64 levels of the backward (Clenshaw) evaluation of filter.py:162-212's polynomial; tiles trade their 4-cell edge
  * bands through the memory-side cache with per-tile epoch flags every 4 levels.  Bit-identical to the strip-marching launches.
- * gcmf_apply uses it by itself for whole grids up to 400 k cells (one launch for the whole polynomial: IRREGULAR 512 x 512, n 63: 88 us
+ * gcmf_apply uses it by itself for whole grids up to ~420 k cells (one launch for the whole polynomial: IRREGULAR 512 x 512, n 63: 88 us
  * against 179 us); on the row slabs of a multi-GPU run it measured slower (a tile exchange costs ~9.5 us against ~1 us per level,
  * DESIGN.md 3.6), so gcmf_slab_apply_backward uses it only with env GCMF_RESIDENT=1 (=0 forbids it everywhere; GCMF_NO_RESIDENT per
  * call); these two entries are the building block and always available.

@@ -33,7 +33,7 @@ def pytest_collection_modifyitems(session, config, items):
 
 @pytest.fixture(autouse=True)
 def _strip_marching_unless_asked(request, monkeypatch):
-    """gcmf_apply runs whole grids of up to 400 k cells on the on-chip kernel (csrc/gcmf_resident.hip) by itself.  Most GPU tests use small
+    """gcmf_apply runs whole grids of up to ~420 k cells on the on-chip kernel (csrc/gcmf_resident.hip) by itself.  Most GPU tests use small
     grids AND assert which strip-marching kernel ran / tune it, so they pin GCMF_RESIDENT=0; tests/test_gpu_resident.py -- which checks
     the on-chip kernel against the strip-marching launches bit for bit, against the oracle, and the default policy -- manages the
     variable itself."""

@@ -90,7 +90,7 @@ def test_resident_levels_equal_the_strip_marching_launches_bit_for_bit(grid, sha
                                               ("REGULAR_AREA_WEIGHTED", (128, 256), 24.0), ("REGULAR_WITH_LAND_AREA_WEIGHTED", (300, 400), 30.0),
                                               ("IRREGULAR_WITH_LAND", (512, 512), 16.0)])
 def test_small_grids_run_the_whole_polynomial_in_one_launch(grid, shape, scale, monkeypatch):
-    monkeypatch.delenv("GCMF_RESIDENT", raising=False)    # the DEFAULT policy: whole grids of up to 400 k cells run on the chip
+    monkeypatch.delenv("GCMF_RESIDENT", raising=False)    # the DEFAULT policy: whole grids of up to ~420 k cells run on the chip
     """north star: "the whole n_steps polynomial fused into a single launch" -- gcmf_apply does that for fields that fit on the chip
     (64 levels per launch).  Against the oracle, against the strip-marching path (GCMF_RESIDENT=0: same bits), NaN on land."""
     f, gv = T.scalar_case(grid, shape)
@@ -111,7 +111,7 @@ def test_small_grids_run_the_whole_polynomial_in_one_launch(grid, shape, scale, 
     again = flt.apply(f)
     assert "k_resident<" not in plan.last_kernel()
     assert np.array_equal(got, again, equal_nan=True)
-    # a tripolar grid (the seam is k_fold_band's job) and a grid beyond 400 k cells stay on the strip-marching launches by default
+    # a tripolar grid (the seam is k_fold_band's job) and a grid beyond ~420 k cells stay on the strip-marching launches by default
     monkeypatch.delenv("GCMF_RESIDENT", raising=False)
 
 
