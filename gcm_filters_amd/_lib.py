@@ -423,8 +423,13 @@ class Plan:
         return out
 
     def set_tuning(self, rows_per_wave: int = 0, xcd_remap: int = -1, multi_s: int = 0, strip_rows: int = 0,
-                   prefetch_rows: int = 0, clenshaw: int = -1):
-        """`clenshaw` (needs multi_s > 0): backward evaluation 0 = off, 1 = flux kinds, 2 = all scalar kinds; -1 keeps it."""
+                   prefetch_rows: int = 0, clenshaw: int = -1, zigzag: int = -1):
+        """`clenshaw` (needs multi_s > 0): backward evaluation 0 = off, 1 = flux kinds, 2 = all scalar kinds; -1 keeps it.
+        `zigzag` (needs xcd_remap >= 0): neighbouring strips of the backward flux kernels march in opposite directions, 1 / 0; -1 keeps it."""
+        if zigzag >= 0:
+            if xcd_remap < 0:
+                raise ValueError("set_tuning: zigzag travels with xcd_remap; pass both")
+            xcd_remap = (int(xcd_remap) & 1) | ((int(zigzag) + 1) << 1)
         check(load().gcmf_set_tuning(self._h, int(rows_per_wave), int(xcd_remap),
                                      (int(multi_s) & 0xFF) | ((int(strip_rows) & 0xFFFF) << 8)
                                      | ((int(prefetch_rows) & 0xF) << 24) | (((int(clenshaw) + 1) & 3) << 28 if clenshaw >= 0 else 0)))

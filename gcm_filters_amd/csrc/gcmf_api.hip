@@ -365,6 +365,7 @@ int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int 
   if (const char *e = getenv("GCMF_HOST_REGISTER")) pl->host_register = atoi(e);
   if (const char *e = getenv("GCMF_ZERO_LAND")) pl->zero_land = atoi(e);
   if (const char *e = getenv("GCMF_RING")) pl->ring = atoi(e);
+  if (const char *e = getenv("GCMF_ZIGZAG")) pl->zigzag = atoi(e);
   if (const char *e = getenv("GCMF_CLENSHAW")) pl->clenshaw = atoi(e);
   PLAN_HIP(hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking));
   PLAN_HIP(hipEventCreate(&pl->ev0));
@@ -482,7 +483,10 @@ int gcmf_ring_fallbacks(gcmf_plan *pl, int64_t *count) {
 int gcmf_set_tuning(gcmf_plan *pl, int rows_per_wave, int xcd_remap, int multi_s) {
   if (!pl) return GCMF_ERR_INVALID_ARG;
   if (rows_per_wave > 0) pl->rows_per_wave = rows_per_wave;
-  if (xcd_remap >= 0) pl->xcd_remap = xcd_remap;
+  if (xcd_remap >= 0) {
+    pl->xcd_remap = xcd_remap & 1;
+    if ((xcd_remap >> 1) & 3) pl->zigzag = ((xcd_remap >> 1) & 3) - 1;
+  }
   if (multi_s > 0) {
     pl->multi_s = multi_s & 0xFF;               // low byte: steps per pass
     pl->strip_rows = (multi_s >> 8) & 0xFFFF;   // bits 8..23: rows per strip (0 = auto)

@@ -36,6 +36,7 @@ template <typename T, typename FB, int S> static int launch_f2(gcmf_plan *pl, co
   P.lbits = nullptr;
   P.nfb = nullptr;
   P.xcd_per = 0;
+  P.zigzag = 0;
   P.mbits = nullptr;
   P.area = nullptr;
   P.nx = g.nx;

@@ -140,7 +140,7 @@ __device__ __forceinline__ void flux_multi2_march(const MultiP<T, FB> &P, const 
       const T fw = (k == 0) ? few : fev[k > 0 ? k - 1 : 0];
       const T fn = (gN[k] - xC) * cNq[e][k];
       const T fs = (xC - gS[k]) * cNq[e + 1][k];
-      const T L = (fe - fw + fn - fs) * raq[e][k];
+      const T L = ((fe - fw) + (fn - fs)) * raq[e][k];
       const T x = FLAGGED ? unsan(xC, (fmid >> (2 * k)) & 3u) : xC;
       const T av = cheb_a<true>(x, c, L);
       T tk;

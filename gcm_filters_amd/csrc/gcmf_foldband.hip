@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_fold_band(const FoldBandP<T, FB> P) {
         const T fw = (gC - gW) * scE[line + qw];
         const T fn = (gN - gC) * scN[cell];
         const T fs = (gC - gS) * scN[cell - 2 * FB_WW];
-        L = (fe - fw + fn - fs) * sra[cell];
+        L = ((fe - fw) + (fn - fs)) * sra[cell];
       } else {
         const unsigned b = smb[cell];
         if constexpr (BACK) {   // k_ringc's land-mask form (land is zero in the state)

@@ -109,6 +109,7 @@ template <typename T, typename FB> struct MultiP {
   int H, nwx, nstrips, nwaves;
   int wrap, first, last, area_weighted;
   int xcd_per;       // k_ring: workgroups per XCD for the XCD-contiguous order (0 = launch order)
+  int zigzag;        // k_ringc, flux kinds: odd strips march upwards (gcmf_ringc_impl.hpp)
   long long bstride;
   double pk[MAX_S];  // coefficient of level t (1-based) at pk[t-1]
   double p0;         // first only

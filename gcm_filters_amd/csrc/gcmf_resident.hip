@@ -347,7 +347,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_resident(const ResP P) {
         fprev = fe;
         const double fn = (xn - xc[c]) * cNr[c];
         const double fs = (xc[c] - xsv) * cSr[c];
-        Lp = (fe - fw + fn - fs) * rar[c];
+        Lp = ((fe - fw) + (fn - fs)) * rar[c];
       } else {
         const double xw = (c == 0) ? xW : xc[c > 0 ? c - 1 : 0];
         if constexpr (MASK) {

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
         const T fe = fev[k];
         const T fw = (k == 0) ? few : fev[k > 0 ? k - 1 : 0];
         const T fn = (gN[k] - xC) * cN[sl][k];
-        L = (fe - fw + fn - FN[t][k]) * ra[sl][k];
+        L = ((fe - fw) + (fn - FN[t][k])) * ra[sl][k];
         FN[t][k] = fn;
       } else {
         const T xW = (k == 0) ? wv : gC[k > 0 ? k - 1 : 0];
@@ -455,6 +455,7 @@ static int launch_ring_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   P.c = a.c;
   dim3 block(256), grid((P.nwaves + 3) / 4, (unsigned)a.nbatch);
   P.xcd_per = pl->xcd_remap ? (int)(grid.x / 8) : 0;
+  P.zigzag = 0;
   hipLaunchKernelGGL((k_ring<T, FB, KIND, S, FIRST>), grid, block, 0, s, P);
   GCMF_HIP(hipGetLastError());
   note_kernel(pl, std::string("gcmf::k_ring<") + tyname<T>() + ", " + tyname<FB>() + ", " + std::to_string(KIND) + ", " +

@@ -101,24 +101,40 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
 
   const bool wrap = P.wrap;
   const int r_begin = a - S, r_last = b + S - 1;
+  // Odd strips of the flux kinds march UPWARDS (P.zigzag): the march below runs in "march order" m = r_begin - 1, r_begin, ... and
+  // visits the grid row  mir - m  instead of m  (mir = a + b - 1 maps the strip and its ghost rows onto themselves).  Two strips that
+  // share a boundary then reach it at the same time -- both at the start or both at the end of their marches -- so that the 2 S rows
+  // each of them re-reads from the other's territory are found in the L2 / the memory-side cache instead of in HBM (same-direction
+  // marches read them a whole march apart).  The arithmetic is the same instruction stream: "north" in march order is the grid's
+  // south, the row of cN that travels with a centre row j is that of row j - 1, the carried flux is minus the grid's north flux, and
+  // (fe - fw) + (fn - fs) is bit-for-bit symmetric under that exchange.
+  const bool up = FLUX && P.zigzag && (st & 1);
+  const int mir = a + b - 1;
   int cj, cj_prev;
   bool cout_, cout_prev;
+  int cr = up ? mir - (r_begin - 1) : r_begin - 1;   // the cursor's grid row
   {
-    const int r = r_begin - 1;
+    const int r = cr;
     const bool lo = r < 0, hi = r >= rows;
     cj = wrap ? (r + (lo ? rows : 0) - (hi ? rows : 0)) : (lo ? 0 : (hi ? rows - 1 : r));
     cout_ = !wrap && (lo || hi);
     cj_prev = cj;
     cout_prev = cout_;
   }
-  int cr = r_begin - 1;
   auto advance = [&]() {
     cj_prev = cj;
     cout_prev = cout_;
-    ++cr;
-    const int jn = cj + ((wrap || cr > 0) ? 1 : 0);
-    const bool hit = (jn >= rows);
-    cj = hit ? (wrap ? 0 : rows - 1) : jn;
+    if (!up) {
+      ++cr;
+      const int jn = cj + ((wrap || cr > 0) ? 1 : 0);
+      const bool hit = (jn >= rows);
+      cj = hit ? (wrap ? 0 : rows - 1) : jn;
+    } else {
+      --cr;
+      const int jn = cj - ((wrap || cr < rows - 1) ? 1 : 0);
+      const bool hit = (jn < 0);
+      cj = hit ? (wrap ? rows - 1 : 0) : jn;
+    }
     cout_ = !wrap && (cr < 0 || cr >= rows);
   };
   const T *fplane = P.fb_in + boff;  // the constant input f (Clenshaw has no fbar: the pointer slot is reused)
@@ -145,7 +161,8 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
     const long long rc = (long long)(cj_prev * nx);
     if constexpr (FLUX) {
       const T *pE = out_c ? P.zrow : P.cE + rc;
-      const T *pN = out_c ? P.zrow : P.cN + rc;
+      // (an upward march: the face between the centre row and the row the cursor is on -- grid row j - 1's north face)
+      const T *pN = !up ? (out_c ? P.zrow : P.cN + rc) : ((out_c || cout_) ? P.zrow : P.cN + (long long)(cj * nx));
       const T *pA = out_c ? P.zrow : P.ra + rc;
       mload<T, VEC>(cE[sl], lane_ptr(pE, colT));
       mload<T, VEC>(cN[sl], lane_ptr(pN, colT));
@@ -202,7 +219,7 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
         const T fe = fev[k];
         const T fw = (k == 0) ? few : fev[k > 0 ? k - 1 : 0];
         const T fn = (gN[k] - xC) * cN[sl][k];
-        L = (fe - fw + fn - FN[t][k]) * ra[sl][k];
+        L = ((fe - fw) + (fn - FN[t][k])) * ra[sl][k];
         FN[t][k] = fn;
       } else {
         const T xW = (k == 0) ? wv : gC[k > 0 ? k - 1 : 0];
@@ -271,7 +288,7 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
     if constexpr (S >= 6) level(ic<6>{}, ph_c);
     if constexpr (S >= 7) level(ic<7>{}, ph_c);
     if constexpr (S >= 8) level(ic<8>{}, ph_c);
-    const int ju = r - S;
+    const int ju = up ? mir - (r - S) : r - S;
     if (ju >= a && ju < b) {  // wave-uniform
       const long long off = boff + (long long)ju * nx;
       if (keep) {
@@ -295,7 +312,7 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
         }
       }
     }
-    const int jv = r - S + 1;
+    const int jv = up ? mir - (r - S + 1) : r - S + 1;
     if (!last && jv >= a && jv < b) {
       T *rowp = P.vo + boff + (long long)jv * nx;
       if (keep) mstore<T, VEC>(lane_ptr(rowp, colT), out_v);
@@ -426,6 +443,7 @@ static int launch_ringc_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   P.c = a.c;
   dim3 block(256), grid((P.nwaves + 3) / 4, (unsigned)a.nbatch);
   P.xcd_per = pl->xcd_remap ? (int)(grid.x / 8) : 0;
+  P.zigzag = pl->zigzag;
   if constexpr (XE) {
     hipLaunchKernelGGL((k_ringcs<T, S, FIRST>), grid, block, 0, s, P);
     GCMF_HIP(hipGetLastError());

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_scalar_step(const ScalarP<T, FB> P) {
         const T fw = (gC - gW) * cw;
         const T fn = (gN - gC) * cNv[k];
         const T fs = (gC - gS) * cNs[k];
-        L = (fe - fw + fn - fs) * rav[k];
+        L = ((fe - fw) + (fn - fs)) * rav[k];
       }
       const T x = cur[k];  // raw centre: NaNs survive in "-x" exactly as in the reference (filter.py:171-173)
       if (lapl) {

@@ -264,7 +264,7 @@ __device__ __forceinline__ void scalar_multi_march(const MultiP<T, FB> &P, const
         const T fw = (k == 0) ? few : fev[k > 0 ? k - 1 : 0];
         const T fn = (gN[k] - xC) * cNq[t][k];
         const T fs = (xC - gS[k]) * cNq[t + 1][k];
-        L = (fe - fw + fn - fs) * raq[t][k];
+        L = ((fe - fw) + (fn - fs)) * raq[t][k];
       }
       // raw centre of level t-1 (NaN/inf survive in "-x", filter.py:171-173)
       const T x = FLAGGED ? unsan(xC, (Rf[t - 1] >> (2 * VEC + 2 * k)) & 3u) : xC;
@@ -462,6 +462,7 @@ static int launch_multi_s(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   P.lbits = nullptr;
   P.nfb = nullptr;
   P.xcd_per = 0;
+  P.zigzag = 0;
   P.mbits = g.mbits;
   P.area = (const T *)g.area;
   P.nx = g.nx;

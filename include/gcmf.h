@@ -361,7 +361,8 @@ int gcmf_resident_levels(gcmf_plan *plan, const void *u, const void *v, void *uo
 
 
 /* Tunables: rows marched per wave of the single-step kernel (0 keeps the default); XCD-aware tile order
- * (1 on, 0 off, <0 keep); temporal blocking: low byte = recurrence steps fused per HBM pass (1 = off,
+ * (bit 0: 1 on, 0 off; bits 1-2: neighbouring strips of the backward flux kernels march in opposite directions -- 1 off, 2 on, 0 keep;
+ * <0 keeps both); temporal blocking: low byte = recurrence steps fused per HBM pass (1 = off,
  * 2..8), bits 8-23 = rows per wave strip (0 = auto), bits 24-27 = operand rows in flight of the general kernels, bits 28-29 =
  * backward evaluation (1 off, 2 flux kinds, 3 all scalar kinds; 0 keep); 0 keeps the default. */
 int gcmf_set_tuning(gcmf_plan *plan, int rows_per_wave, int xcd_remap, int multi);

@@ -7,7 +7,7 @@ OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"; export TMPDIR=/tmp; REPO=$PWD; cd /tmp
 i=0
 for G in "$@"; do
-  rocprofv3 --kernel-trace --output-format csv --pmc $G -d "$OUT/g$i" -o pmc -- python3 $REPO/bench.py $ARGS > "$OUT/g$i.log" 2>&1
+  timeout 420 rocprofv3 --kernel-trace --output-format csv --pmc $G -d "$OUT/g$i" -o pmc -- python3 $REPO/bench.py $ARGS > "$OUT/g$i.log" 2>&1
   i=$((i+1))
 done
 cd $REPO

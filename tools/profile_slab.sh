@@ -4,7 +4,7 @@ set -u
 CFG=${1:-3}; N=${2:-8}
 OUT=$PWD/gpurun_out/prof_slab_cfg${CFG}_n${N}
 mkdir -p "$OUT"; export TMPDIR=/tmp; REPO=$PWD; cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- python3 $REPO/tools/measure_slab_compute.py $CFG $N > "$OUT/run.log" 2>&1
+timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- python3 $REPO/tools/measure_slab_compute.py $CFG $N > "$OUT/run.log" 2>&1
 cd $REPO
 python3 - <<PY
 import csv, glob
