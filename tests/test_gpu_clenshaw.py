@@ -93,9 +93,15 @@ def test_opposite_marches_give_the_same_bits(grid, dt, kwargs):
     sum (fe - fw) + (fn - fs) that is symmetric under the exchange -- every cell gets the same bits whichever way its strip marched,
     on closed, periodic and tripolar grids, through the nan_to_num redo of a strip, in batches, in f64 and f32."""
     flt, plan, f, want = _case(grid, (260, 520), 29, **kwargs)
-    if dt == "f4":
+    if dt == "f4":    # (an f32 plan is keyed by f32 grid variables)
+        import warnings
         f = f.astype(np.float32)
-        plan = ALL_KERNELS[GridType[grid]](**{k: v for k, v in flt.grid_vars.items()})._plan(_lib.F32, (260, 520))
+        gv4 = {k: np.asarray(v).astype("f4") for k, v in flt.grid_vars.items()}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            flt = Filter(filter_scale=flt.filter_scale, dx_min=flt.dx_min, n_steps=29, filter_shape=FilterShape.TAPER, grid_type=GridType[grid],
+                         grid_vars=gv4)
+        plan = ALL_KERNELS[GridType[grid]](**gv4)._plan(_lib.F32, (260, 520))
     outs = []
     try:
         for strip, zz in ((0, 0), (0, 1), (24, 1), (24, 0), (37, 1)):
@@ -108,7 +114,7 @@ def test_opposite_marches_give_the_same_bits(grid, dt, kwargs):
         assert np.array_equal(outs[0], o, equal_nan=True)
     ok = ~np.isnan(want)
     assert np.array_equal(np.isnan(outs[0]), np.isnan(want))
-    assert np.abs(outs[0][ok] - want[ok]).max() <= (1e-12 if dt == "f8" else 3e-5) * np.abs(want[ok]).max()
+    assert np.abs(outs[0][ok] - want[ok]).max() <= (1e-12 if dt == "f8" else 1e-4) * np.abs(want[ok]).max()
 
 
 def test_default_is_backward_for_flux_kinds_and_forward_for_the_rest():
