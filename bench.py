@@ -358,11 +358,13 @@ def roofline_of(cfg, r, steps, default_tuning):
     avg_ms = r["dom_ms"] / r["dom_n"]                       # HIP events around each launch of the dominant kernel
     # recurrence steps one launch of that kernel advances: its last (vector kernels: fourth) template argument
     targs = r["kernel"][r["kernel"].index("<") + 1: r["kernel"].rindex(">")].split(", ")
-    steps_per_launch = float(targs[2] if ("k_ringc<" in r["kernel"] or "k_cgrid_stream2c<" in r["kernel"]) else
+    backward = any(k in r["kernel"] for k in ("k_ringc<", "k_ringcs<", "k_cgrid_stream2c<"))
+    steps_per_launch = float(targs[1] if "k_ringcs<" in r["kernel"] else      # (the early-exit form of short strips: <T, S, FIRST>)
+                             targs[2] if backward else
                              targs[3] if any(k in r["kernel"] for k in ("stream2", "k_scalar_multi", "k_ring")) else
                              (targs[-1] if "k_flux_multi2" in r["kernel"] else 1))
     one_pass_per_step = balg * r["cells"] * steps_per_launch / (avg_ms * 1e-3) / 1e9
-    minb = min_bytes_per_cell_launch(grid, w, 8, nb, backward=("k_ringc<" in r["kernel"] or "k_cgrid_stream2c<" in r["kernel"])) * r["cells"]
+    minb = min_bytes_per_cell_launch(grid, w, 8, nb, backward=backward) * r["cells"]
     rec, src = load_traffic(cfg, r["kernel"], r.get("geometry")) if default_tuning else (None, "non-default tuning: traffic withheld")
     # `achieved` / `frac` are PHYSICAL: the algorithmic bytes of ONE launch = every operand plane of SURVEY 8d's byte count read
     # once and every result plane written once (a launch is one pass over HBM however many Chebyshev steps it advances),

@@ -157,8 +157,18 @@ static int launch_ringc(gcmf_plan *pl, const MultiArgs &m, hipStream_t s) {
     case K_REG: return launch_ringc_reg(pl, m, s);
     case K_MASK: return launch_ringc_maskz(pl, m, s);
     case K_FLUX:
-      // a slab that owns no tripole seam: short strips, nothing has to fit beside the waves -> the early-exit form
-      if (!pl->full && !pl->g.fold && pl->d.dtype == GCMF_F64) return launch_ringc_flux_slab(pl, m, s);
+      // Nothing has to fit beside the waves where there is no tripole seam -> the early-exit form wherever strips are short: row slabs,
+      // and whole grids of up to a few million cells (1024 lone waves on 1080 x 1440 cells own 14-row strips; marching whole 12-row
+      // periods would make them 20 rows and leave half the SIMDs without a wave: 330 -> 4xx G cell-steps/s, tools/measure_midsize.py).
+      if (!pl->g.fold && pl->d.dtype == GCMF_F64) {
+        bool xe = !pl->full;
+        if (pl->full) {
+          const long long nwx = (pl->g.nx + 111) / 112, want = std::max(1LL, 1024 / (nwx * std::max<long long>(1, m.nbatch)));
+          const long long H0 = pl->strip_rows > 0 ? pl->strip_rows : ((long long)(m.row_hi - m.row_lo) + want - 1) / want;
+          xe = H0 < pl->ringc_xe_rows;
+        }
+        if (xe) return launch_ringc_flux_slab(pl, m, s);
+      }
       return launch_ringc_flux(pl, m, s);
     default: break;
   }
@@ -366,6 +376,7 @@ int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int 
   if (const char *e = getenv("GCMF_ZERO_LAND")) pl->zero_land = atoi(e);
   if (const char *e = getenv("GCMF_RING")) pl->ring = atoi(e);
   if (const char *e = getenv("GCMF_ZIGZAG")) pl->zigzag = atoi(e);
+  if (const char *e = getenv("GCMF_RINGC_XE_ROWS")) pl->ringc_xe_rows = atoi(e);
   if (const char *e = getenv("GCMF_CLENSHAW")) pl->clenshaw = atoi(e);
   PLAN_HIP(hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking));
   PLAN_HIP(hipEventCreate(&pl->ev0));
