@@ -258,8 +258,11 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
     }
   };
 
-  auto phase = [&](auto ph_c, int r) {
+  auto phase = [&](auto ph_c, int r, auto pro_c) {
     constexpr int ph = decltype(ph_c)::value;
+    // the strip's first period: level t starts with phase 2 t - 1 (below).  Flux kinds only: the land-mask / REGULAR kernels lose 3-4 % at
+    // full size with the peeled period (config 2: 82 -> 85 us per launch on one box) and gain 3 % on 1/4-degree grids.
+    constexpr bool PRO = decltype(pro_c)::value && FLUX;
     advance();
     load_centre(ic<(ph + D) % R>{}, ic<(ph + D) % RV>{});
     load_u(ic<(ph + D) % RU>{});
@@ -280,14 +283,18 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
         Ff[s1][k] = (!has_land || ((Zc[s1] >> (8 * k)) & 1u)) ? Ff[s1][k] : T(0);
       }
     }
-    level(ic<1>{}, ph_c);
-    if constexpr (S >= 2) level(ic<2>{}, ph_c);
-    if constexpr (S >= 3) level(ic<3>{}, ph_c);
-    if constexpr (S >= 4) level(ic<4>{}, ph_c);
-    if constexpr (S >= 5) level(ic<5>{}, ph_c);
-    if constexpr (S >= 6) level(ic<6>{}, ph_c);
-    if constexpr (S >= 7) level(ic<7>{}, ph_c);
-    if constexpr (S >= 8) level(ic<8>{}, ph_c);
+    // The ramp: phase q of a strip (q = 0 at row r_begin = a - S) produces row a - S + q - t of level t, and the strip needs level t from
+    // row a - (S - t) on -- phase 2 t.  One phase earlier the level has to run for the flux it carries to its next row (its value there
+    // is never used); before that it would compute rows nobody reads.  S^2 of the (H + 2 S) S level-rows of a strip: 8 % at 80 rows, a
+    // quarter of the instruction stream of a 12-row strip (8-way slabs, 1/4-degree grids).
+    if constexpr (!PRO || ph >= 1) level(ic<1>{}, ph_c);
+    if constexpr (S >= 2 && (!PRO || ph >= 3)) level(ic<2>{}, ph_c);
+    if constexpr (S >= 3 && (!PRO || ph >= 5)) level(ic<3>{}, ph_c);
+    if constexpr (S >= 4 && (!PRO || ph >= 7)) level(ic<4>{}, ph_c);
+    if constexpr (S >= 5 && (!PRO || ph >= 9)) level(ic<5>{}, ph_c);
+    if constexpr (S >= 6 && (!PRO || ph >= 11)) level(ic<6>{}, ph_c);
+    if constexpr (S >= 7 && !PRO) level(ic<7>{}, ph_c);
+    if constexpr (S >= 8 && !PRO) level(ic<8>{}, ph_c);
     const int ju = up ? mir - (r - S) : r - S;
     if (ju >= a && ju < b) {  // wave-uniform
       const long long off = boff + (long long)ju * nx;
@@ -332,23 +339,41 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
   // The flux kinds march whole periods: every early exit costs this kernel dozens of registers (146 -> 204 AGPRs with an exit
   // every four rows), and on tripolar plans k_fold_band's waves have to fit on the SIMDs NEXT to these (gcmf_foldband.hip).
   constexpr bool EARLY = (KIND != K_FLUX) || XE;
-  for (int r0 = r_begin;; r0 += R) {
+  if constexpr (FLUX) {  // the first period, peeled: the ramp of the levels
+    constexpr std::integral_constant<bool, true> pro{};
+    phase(ic<0>{}, r_begin, pro);
+    phase(ic<1>{}, r_begin + 1, pro);
+    phase(ic<2>{}, r_begin + 2, pro);
+    phase(ic<3>{}, r_begin + 3, pro);
+    phase(ic<4>{}, r_begin + 4, pro);
+    phase(ic<5>{}, r_begin + 5, pro);
+    phase(ic<6>{}, r_begin + 6, pro);
+    phase(ic<7>{}, r_begin + 7, pro);
+    phase(ic<8>{}, r_begin + 8, pro);
+    phase(ic<9>{}, r_begin + 9, pro);
+    phase(ic<10>{}, r_begin + 10, pro);
+    phase(ic<11>{}, r_begin + 11, pro);
+    if (WATCH && __any(bad)) return true;
+    if (r_begin + 11 >= r_last) return false;   // (a last strip of one or two rows at S = 5)
+  }
+  constexpr std::integral_constant<bool, false> run{};
+  for (int r0 = FLUX ? r_begin + R : r_begin;; r0 += R) {
     bool done = true;
     do {
-      phase(ic<0>{}, r0);
-      phase(ic<1>{}, r0 + 1);
-      phase(ic<2>{}, r0 + 2);
-      phase(ic<3>{}, r0 + 3);
+      phase(ic<0>{}, r0, run);
+      phase(ic<1>{}, r0 + 1, run);
+      phase(ic<2>{}, r0 + 2, run);
+      phase(ic<3>{}, r0 + 3, run);
       if (EARLY && r0 + 3 >= r_last) break;     // (the last period is left after the strip's last row, see k_ring)
-      phase(ic<4>{}, r0 + 4);
-      phase(ic<5>{}, r0 + 5);
-      phase(ic<6>{}, r0 + 6);
-      phase(ic<7>{}, r0 + 7);
+      phase(ic<4>{}, r0 + 4, run);
+      phase(ic<5>{}, r0 + 5, run);
+      phase(ic<6>{}, r0 + 6, run);
+      phase(ic<7>{}, r0 + 7, run);
       if (EARLY && r0 + 7 >= r_last) break;
-      phase(ic<8>{}, r0 + 8);
-      phase(ic<9>{}, r0 + 9);
-      phase(ic<10>{}, r0 + 10);
-      phase(ic<11>{}, r0 + 11);
+      phase(ic<8>{}, r0 + 8, run);
+      phase(ic<9>{}, r0 + 9, run);
+      phase(ic<10>{}, r0 + 10, run);
+      phase(ic<11>{}, r0 + 11, run);
       done = (r0 + 11 >= r_last);
     } while (false);
     if (WATCH && __any(bad)) return true;
