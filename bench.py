@@ -291,6 +291,9 @@ def run_single(cfg, args, dev, steps, warmup, scale=0.0, levels=None, tuned=Fals
             while time.perf_counter() - t_w < 0.05:   # ... and 50 ms of them: the GPU idled while the host folded the plan and takes tens of
                 outs = run()                          # milliseconds to clock up again (one block in five came out 2-3 x slow without this)
                 torch.cuda.synchronize()
+            for _ in range(min(40, nb_)):             # ... and the one-off stall of a new plan's first unsynchronised burst (see above): 36 ms
+                outs = run()                          # in the block after the re-plan of one full run (55 ms against 19 ms for 20 applications)
+            torch.cuda.synchronize()
             del keep_away
             replans += 1
         t0 = time.perf_counter()
@@ -364,7 +367,7 @@ def roofline_of(cfg, r, steps, default_tuning):
     avg_ms = r["dom_ms"] / r["dom_n"]                       # HIP events around each launch of the dominant kernel
     # recurrence steps one launch of that kernel advances: its last (vector kernels: fourth) template argument
     targs = r["kernel"][r["kernel"].index("<") + 1: r["kernel"].rindex(">")].split(", ")
-    backward = any(k in r["kernel"] for k in ("k_ringc<", "k_ringcs<", "k_cgrid_stream2c<"))
+    backward = any(k in r["kernel"] for k in ("k_ringc<", "k_ringcs<", "k_ringcr<", "k_cgrid_stream2c<"))
     steps_per_launch = float(targs[1] if "k_ringcs<" in r["kernel"] else      # (the early-exit form of short strips: <T, S, FIRST>)
                              targs[2] if backward else
                              targs[3] if any(k in r["kernel"] for k in ("stream2", "k_scalar_multi", "k_ring")) else
