@@ -154,16 +154,8 @@ static int dom_collect(gcmf_plan *pl) {
 // strip-marching kernel, which therefore stops S rows below the seam; the top S rows ("band") are advanced by k_fold_band.
 static int launch_ringc(gcmf_plan *pl, const MultiArgs &m, hipStream_t s) {
   switch (pl->kind) {
-    case K_REG:
-    case K_MASK: {
-      // short strips (small / mid-size grids, row slabs): the form whose levels ramp up over the first ring period (k_ringcr)
-      const int wi = pl->d.dtype == GCMF_F64 ? 112 : 240;
-      const long long nwx = (pl->g.nx + wi - 1) / wi, want = std::max(1LL, 1024 / (nwx * std::max<long long>(1, m.nbatch)));
-      const long long H0 = pl->strip_rows > 0 ? pl->strip_rows : ((long long)(m.row_hi - m.row_lo) + want - 1) / want;
-      const bool ramp = H0 < pl->ringc_ramp_rows;
-      if (pl->kind == K_REG) return ramp ? launch_ringc_reg_ramp(pl, m, s) : launch_ringc_reg(pl, m, s);
-      return ramp ? launch_ringc_maskz_ramp(pl, m, s) : launch_ringc_maskz(pl, m, s);
-    }
+    case K_REG: return launch_ringc_reg(pl, m, s);
+    case K_MASK: return launch_ringc_maskz(pl, m, s);
     case K_FLUX:
       // Nothing has to fit beside the waves where there is no tripole seam -> the early-exit form wherever strips are short: row slabs,
       // and whole grids of up to a few million cells (1024 lone waves on 1080 x 1440 cells own 14-row strips; marching whole 12-row
@@ -385,7 +377,6 @@ int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int 
   if (const char *e = getenv("GCMF_RING")) pl->ring = atoi(e);
   if (const char *e = getenv("GCMF_ZIGZAG")) pl->zigzag = atoi(e);
   if (const char *e = getenv("GCMF_RINGC_XE_ROWS")) pl->ringc_xe_rows = atoi(e);
-  if (const char *e = getenv("GCMF_RINGC_RAMP_ROWS")) pl->ringc_ramp_rows = atoi(e);
   if (const char *e = getenv("GCMF_CLENSHAW")) pl->clenshaw = atoi(e);
   PLAN_HIP(hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking));
   PLAN_HIP(hipEventCreate(&pl->ev0));

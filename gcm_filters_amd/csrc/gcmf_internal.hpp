@@ -150,7 +150,6 @@ struct gcmf_plan {
   int last_launches = 0;
   int rows_per_wave = 0;
   int xcd_remap = 1;
-  int ringc_ramp_rows = 40; // REGULAR / land-mask kinds: strips shorter than this run the ramp form k_ringcr (GCMF_RINGC_RAMP_ROWS)
   int ringc_xe_rows = 64;   // whole f64 flux grids without a seam: strips shorter than this run the early-exit form k_ringcs (GCMF_RINGC_XE_ROWS)
   int zigzag = 1;        // k_ringc (flux kinds): neighbouring strips march in opposite directions (GCMF_ZIGZAG=0: all downwards)
   int multi_s = 8;     // steps fused per pass by the temporally blocked kernel (1 = off); 8 measured best
@@ -206,8 +205,6 @@ bool ring_supported(const gcmf_plan *pl, const MultiArgs &a);
 // the result (last launch), a.pk[t] = the coefficient of level t + 1 of this launch
 int launch_ringc_reg(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_ringc_maskz(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
-int launch_ringc_reg_ramp(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);     // k_ringcr: short strips
-int launch_ringc_maskz_ramp(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_ringc_flux(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_ringc_flux_slab(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);   // f64, slabs without a tripole seam: early exits (k_ringcs)
 int launch_flux_multi2(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);

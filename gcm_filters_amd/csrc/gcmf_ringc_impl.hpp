@@ -37,9 +37,7 @@ template <int VEC> __device__ __forceinline__ unsigned cell_bytes(const uint8_t 
 
 // one march of a strip; returns whether this wave met a non-finite value in its last level (wave-uniform)
 // XE: early exits also for the flux kinds (k_ringcs: slabs that do not own a tripole seam, see below)
-// RAMP: the strip's first ring period is peeled and its levels start one after the other (see `phase`): always for the flux kinds; for the
-// REGULAR / land-mask kinds only in k_ringcr, which short strips run (the peeled period costs them 3-4 % on BASELINE-size grids)
-template <typename T, int KIND, int S, bool FIRST, bool SANI, bool XE = false, bool RAMP = (KIND == K_FLUX)>
+template <typename T, int KIND, int S, bool FIRST, bool SANI, bool XE = false>
 __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int W = 64 * VEC;
@@ -262,8 +260,9 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
 
   auto phase = [&](auto ph_c, int r, auto pro_c) {
     constexpr int ph = decltype(ph_c)::value;
-    // the strip's first period: level t starts with phase 2 t - 1 (below)
-    constexpr bool PRO = decltype(pro_c)::value && RAMP;
+    // the strip's first period: level t starts with phase 2 t - 1 (below).  Flux kinds only: the land-mask / REGULAR kernels lose 3-4 % at
+    // full size with the peeled period (config 2: 82 -> 85 us per launch on one box) and gain 3 % on 1/4-degree grids.
+    constexpr bool PRO = decltype(pro_c)::value && FLUX;
     advance();
     load_centre(ic<(ph + D) % R>{}, ic<(ph + D) % RV>{});
     load_u(ic<(ph + D) % RU>{});
@@ -340,7 +339,7 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
   // The flux kinds march whole periods: every early exit costs this kernel dozens of registers (146 -> 204 AGPRs with an exit
   // every four rows), and on tripolar plans k_fold_band's waves have to fit on the SIMDs NEXT to these (gcmf_foldband.hip).
   constexpr bool EARLY = (KIND != K_FLUX) || XE;
-  if constexpr (RAMP) {  // the first period, peeled: the ramp of the levels
+  if constexpr (FLUX) {  // the first period, peeled: the ramp of the levels
     constexpr std::integral_constant<bool, true> pro{};
     phase(ic<0>{}, r_begin, pro);
     phase(ic<1>{}, r_begin + 1, pro);
@@ -358,7 +357,7 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
     if (r_begin + 11 >= r_last) return false;   // (a last strip of one or two rows at S = 5)
   }
   constexpr std::integral_constant<bool, false> run{};
-  for (int r0 = RAMP ? r_begin + R : r_begin;; r0 += R) {
+  for (int r0 = FLUX ? r_begin + R : r_begin;; r0 += R) {
     bool done = true;
     do {
       phase(ic<0>{}, r0, run);
@@ -397,23 +396,6 @@ __global__ __launch_bounds__(256, 1) void k_ringc(const MultiP<T, T> P) {
   }
 }
 
-// The REGULAR / land-mask kinds with the ramp, for short strips (small and mid-size grids, row slabs): a 4-row strip of BASELINE config 1
-// marches 20 rows for 8 levels, 64 of its 160 level-rows are the ramp.
-template <typename T, int KIND, int S, bool FIRST>
-__global__ __launch_bounds__(256, 1) void k_ringcr(const MultiP<T, T> P) {
-  static_assert(KIND != K_FLUX, "the flux kinds always ramp");
-  int bx = blockIdx.x;
-  if (P.xcd_per > 0 && bx < 8 * P.xcd_per) bx = (bx & 7) * P.xcd_per + (bx >> 3);
-  const int wid = bx * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (wid >= P.nwaves) return;
-  if (ringc_march<T, KIND, S, FIRST, false, false, true>(P, wid)) {
-    if constexpr (KIND != K_REG) {
-      if (P.nfb && (threadIdx.x & 63) == 0) atomicAdd(P.nfb, 1u);
-      ringc_march<T, KIND, S, FIRST, true, false, true>(P, wid);
-    }
-  }
-}
-
 // The flux kinds with early exits: for ROW SLABS that own no tripole seam (the ranks of a multi-GPU run, the row blocks of the host
 // pipeline).  Their strips are short -- 300 rows of an 8-way slab: 11 + 2 S rows per strip -- so rows up to the next whole ring period
 // are a third of the march, and nothing has to fit beside these waves (the extra ~60 registers of the exits are free here).
@@ -429,7 +411,7 @@ __global__ __launch_bounds__(256, 1) void k_ringcs(const MultiP<T, T> P) {
   }
 }
 
-template <typename T, int KIND, int S, bool FIRST, bool XE = false, bool RAMP = false>
+template <typename T, int KIND, int S, bool FIRST, bool XE = false>
 static int launch_ringc_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int W = 64 * VEC;
@@ -494,13 +476,6 @@ static int launch_ringc_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
                 launch_geom(P.H, P.nstrips, P.nwx, P.xcd_per > 0, grid.x, grid.y, nrows));
     return GCMF_OK;
   }
-  if constexpr (RAMP && KIND != K_FLUX) {
-    hipLaunchKernelGGL((k_ringcr<T, KIND, S, FIRST>), grid, block, 0, s, P);
-    GCMF_HIP(hipGetLastError());
-    note_kernel(pl, std::string("gcmf::k_ringcr<") + tyname<T>() + ", " + std::to_string(KIND) + ", " + std::to_string(S) + ", " +
-                        (FIRST ? "true" : "false") + ">", S, launch_geom(P.H, P.nstrips, P.nwx, P.xcd_per > 0, grid.x, grid.y, nrows));
-    return GCMF_OK;
-  }
   hipLaunchKernelGGL((k_ringc<T, KIND, S, FIRST>), grid, block, 0, s, P);
   GCMF_HIP(hipGetLastError());
   note_kernel(pl, std::string("gcmf::k_ringc<") + tyname<T>() + ", " + std::to_string(KIND) + ", " + std::to_string(S) + ", " +
@@ -508,26 +483,26 @@ static int launch_ringc_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   return GCMF_OK;
 }
 
-template <int KIND, bool RAMP = false> static int launch_ringc_kind(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
+template <int KIND> static int launch_ringc_kind(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   if (pl->d.dtype != GCMF_F64) {
     // f32 state, four cells per lane, the whole polynomial carried in f32 (f64 result unless GCMF_OUT_F32): the flux kinds since round 3,
     // the REGULAR / land-mask kinds since round 4
     switch (a.S) {
-      case 5: return a.first ? launch_ringc_sf<float, KIND, 5, true, false, RAMP>(pl, a, s) : launch_ringc_sf<float, KIND, 5, false, false, RAMP>(pl, a, s);
-      case 6: return a.first ? launch_ringc_sf<float, KIND, 6, true, false, RAMP>(pl, a, s) : launch_ringc_sf<float, KIND, 6, false, false, RAMP>(pl, a, s);
-      case 7: return a.first ? launch_ringc_sf<float, KIND, 7, true, false, RAMP>(pl, a, s) : launch_ringc_sf<float, KIND, 7, false, false, RAMP>(pl, a, s);
+      case 5: return a.first ? launch_ringc_sf<float, KIND, 5, true>(pl, a, s) : launch_ringc_sf<float, KIND, 5, false>(pl, a, s);
+      case 6: return a.first ? launch_ringc_sf<float, KIND, 6, true>(pl, a, s) : launch_ringc_sf<float, KIND, 6, false>(pl, a, s);
+      case 7: return a.first ? launch_ringc_sf<float, KIND, 7, true>(pl, a, s) : launch_ringc_sf<float, KIND, 7, false>(pl, a, s);
       case 8:   // (never a first launch: clenshaw_cut starts an f32 filter with at most seven levels -- eight spill there)
         if (a.first) break;
-        return launch_ringc_sf<float, KIND, 8, false, false, RAMP>(pl, a, s);
+        return launch_ringc_sf<float, KIND, 8, false>(pl, a, s);
     }
     set_error("k_ringc<float>: depth %d%s is not offered", a.S, a.first ? " as a first launch" : "");
     return GCMF_ERR_INVALID_ARG;
   }
   switch (a.S) {
-    case 5: return a.first ? launch_ringc_sf<double, KIND, 5, true, false, RAMP>(pl, a, s) : launch_ringc_sf<double, KIND, 5, false, false, RAMP>(pl, a, s);
-    case 6: return a.first ? launch_ringc_sf<double, KIND, 6, true, false, RAMP>(pl, a, s) : launch_ringc_sf<double, KIND, 6, false, false, RAMP>(pl, a, s);
-    case 7: return a.first ? launch_ringc_sf<double, KIND, 7, true, false, RAMP>(pl, a, s) : launch_ringc_sf<double, KIND, 7, false, false, RAMP>(pl, a, s);
-    case 8: return a.first ? launch_ringc_sf<double, KIND, 8, true, false, RAMP>(pl, a, s) : launch_ringc_sf<double, KIND, 8, false, false, RAMP>(pl, a, s);
+    case 5: return a.first ? launch_ringc_sf<double, KIND, 5, true>(pl, a, s) : launch_ringc_sf<double, KIND, 5, false>(pl, a, s);
+    case 6: return a.first ? launch_ringc_sf<double, KIND, 6, true>(pl, a, s) : launch_ringc_sf<double, KIND, 6, false>(pl, a, s);
+    case 7: return a.first ? launch_ringc_sf<double, KIND, 7, true>(pl, a, s) : launch_ringc_sf<double, KIND, 7, false>(pl, a, s);
+    case 8: return a.first ? launch_ringc_sf<double, KIND, 8, true>(pl, a, s) : launch_ringc_sf<double, KIND, 8, false>(pl, a, s);
   }
   return GCMF_ERR_INVALID_ARG;
 }

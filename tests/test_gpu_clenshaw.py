@@ -117,35 +117,6 @@ def test_opposite_marches_give_the_same_bits(grid, dt, kwargs):
     assert np.abs(outs[0][ok] - want[ok]).max() <= (1e-12 if dt == "f8" else 1e-4) * np.abs(want[ok]).max()
 
 
-@pytest.mark.parametrize("grid", ["REGULAR", "REGULAR_WITH_LAND", "REGULAR_WITH_LAND_AREA_WEIGHTED", "TRIPOLAR_REGULAR_WITH_LAND_AREA_WEIGHTED"])
-@pytest.mark.parametrize("dt", ["f8", "f4"])
-def test_ramp_form_of_short_strips_gives_the_same_bits(grid, dt):
-    """Strips shorter than 40 rows of the REGULAR / land-mask kinds run k_ringcr: the first ring period peeled, level t switched on at phase
-    2 t - 1 instead of computing rows nobody reads (the flux kinds always do that).  Same bits as the plain march of taller strips."""
-    import warnings
-    shape = (260, 520)
-    f, gv = T.scalar_case(grid, shape)
-    if "wet_mask" in gv:
-        f = np.where(gv["wet_mask"] == 0, np.nan, f)
-    if dt == "f4":
-        f = f.astype("f4")
-        gv = {k: np.asarray(v).astype("f4") for k, v in gv.items()}
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        flt = Filter(filter_scale=4.0, dx_min=1.0, n_steps=29, filter_shape=FilterShape.TAPER, grid_type=GridType[grid], grid_vars=gv)
-    plan = ALL_KERNELS[GridType[grid]](**gv)._plan(_lib.F64 if dt == "f8" else _lib.F32, shape)
-    outs = {}
-    try:
-        for strip, kern in ((0, "k_ringcr<"), (24, "k_ringcr<"), (48, "k_ringc<"), (64, "k_ringc<")):
-            plan.set_tuning(multi_s=8, strip_rows=strip, xcd_remap=1, clenshaw=2)
-            outs[strip] = flt.apply(f)
-            assert kern in plan.last_kernel(), (strip, plan.last_kernel())
-    finally:
-        plan.set_tuning(multi_s=8, strip_rows=0, xcd_remap=1, clenshaw=2)
-    for strip in (24, 48, 64):
-        assert np.array_equal(outs[0], outs[strip], equal_nan=True), strip
-
-
 def test_default_is_backward_for_flux_kinds_and_forward_for_the_rest():
     """(The name is round 3's.)  Round 4: the default evaluates EVERY f64 scalar kind backwards -- the land-mask / REGULAR kinds gain
     12-20 % from the fused arithmetic and stay within 1e-14 of numpy; Filter(evaluation="reference") is the bit-exact escape."""
