@@ -4,6 +4,8 @@
 OUT=$PWD/gpurun_out/fuzz; mkdir -p "$OUT"; S=${1:-400}
 ( for seed in $S $((S+1)) $((S+2)); do timeout 600 python tools/fuzz_gpu.py $seed 250; done
   timeout 600 python tools/fuzz_gpu.py $((S+3)) 150 --tune
+  timeout 600 python tools/fuzz_gpu.py $((S+20)) 60 --mid
+  timeout 600 python tools/fuzz_gpu.py $((S+21)) 40 --mid --tune
   timeout 600 python tools/fuzz_gpu.py $((S+4)) 120 --cgrid
   timeout 600 python tools/fuzz_gpu.py $((S+5)) 120 --bgrid
   timeout 600 python tools/fuzz_gpu.py $((S+6)) 300 --tiny

@@ -19,6 +19,8 @@ for it in range(ncase):
     vec = grid in T.VECTOR_GRIDS
     if "--tiny" in sys.argv:
         ny = int(rng.integers(1, 14)); nx = int(rng.integers(1, 14))
+    elif "--mid" in sys.argv:   # strips of 5..60 rows on whole grids: early-exit strips, both march directions, the level ramp
+        ny = int(rng.integers(300, 1300)); nx = int(rng.integers(400, 1600))
     else:
         ny = int(rng.integers(3, 200)); nx = int(rng.integers(2, 700))
     if grid.startswith("TRIPOLAR"):
@@ -65,8 +67,8 @@ for it in range(ncase):
                 from gcm_filters_amd import _lib
                 from gcm_filters_amd.kernels import ALL_KERNELS
                 plan = ALL_KERNELS[GridType[grid]](**gv)._plan(_lib.dtype_code(dt), shape)
-                plan.set_tuning(multi_s=int(rng.integers(1, 9)), strip_rows=int(rng.choice([0, 0, 3, 5, 9, 17, 40])),
-                                prefetch_rows=int(rng.choice([0, 0, 1, 2])))
+                plan.set_tuning(multi_s=int(rng.integers(1, 9)), strip_rows=int(rng.choice([0, 0, 3, 5, 9, 17, 40, 70, 100])),
+                                prefetch_rows=int(rng.choice([0, 0, 1, 2])), xcd_remap=int(rng.integers(0, 2)), zigzag=int(rng.integers(0, 2)))
             got = flt.apply_to_vector(*fields) if vec else (flt.apply(fields[0]),)
         spec = O.FilterSpec(flt.n_steps, flt.filter_spec.s_max, np.asarray(flt.filter_spec.p), flt.filter_spec.dx_min_sq)
         with np.errstate(all="ignore"):
