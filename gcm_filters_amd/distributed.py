@@ -143,12 +143,14 @@ class SlabFilter:
         if not self.multi:
             self.halo = 0
         else:
-            # default: 32 ghost rows (four blocked launches between exchanges), 64 on slabs of 2400 rows and more.  An un-overlapped
-            # exchange costs 24-33 us of the stream -- as much as a whole blocked 8-level launch on a 300-row slab -- while deeper
-            # ghost zones cost almost nothing there (the strips of a short slab are latency-bound, not work-bound).  Measured as a
-            # ring of one rank (tools/measure_exchange.py), ms per application at halo 16 / 24 / 32 / 48: 300 rows 0.410 / 0.373 /
-            # 0.323 / 0.333 (RCCL), 0.364 / 0.345 / 0.309 / 0.326 (p2p); 600 rows 0.485 / - / 0.410 / 0.415 (RCCL)
-            auto = max(32, 8 * min(8, min_rows // 300))
+            # default: as many ghost rows as the filter has steps, at most 64 -- ONE exchange per application (the input's ghost rows) for
+            # filters of up to 64 steps, one more every 64 levels beyond.  An un-overlapped exchange costs 23-33 us of the stream -- as much
+            # as a whole blocked 8-level launch on a 300-row slab -- while deeper ghost zones cost little there (the strips of a short slab
+            # are latency-bound, and their levels ramp up, csrc/gcmf_ringc_impl.hpp).  Measured as a ring of one rank
+            # (tools/measure_exchange.py, config 3, n_steps 63), ms per application at halo 32 / 48 / 64: 300 rows 0.300 / 0.312 / 0.267
+            # (RCCL), 0.293 / 0.307 / 0.270 (p2p); 600 rows 0.388 / - / 0.353 (RCCL); 1200 rows 0.615 / - / 0.564 (RCCL).  (Round 3, before
+            # the ramp: 32 was the optimum, 0.323 against 0.333 at 48.)
+            auto = min(64, max(8, int(n)))
             self.halo = int(halo) if halo else auto
             self.halo = max(1, min(self.halo, min_rows))
         planes = [np.ascontiguousarray(np.asarray(grid_vars[k]), dtype=self.np_dtype)
