@@ -157,17 +157,21 @@ static int launch_ringc(gcmf_plan *pl, const MultiArgs &m, hipStream_t s) {
     case K_REG: return launch_ringc_reg(pl, m, s);
     case K_MASK: return launch_ringc_maskz(pl, m, s);
     case K_FLUX:
-      // Nothing has to fit beside the waves where there is no tripole seam -> the early-exit form wherever strips are short: row slabs,
-      // and whole grids of up to a few million cells (1024 lone waves on 1080 x 1440 cells own 14-row strips; marching whole 12-row
-      // periods would make them 20 rows and leave half the SIMDs without a wave: 330 -> 4xx G cell-steps/s, tools/measure_midsize.py).
-      if (!pl->g.fold && pl->d.dtype == GCMF_F64) {
-        bool xe = !pl->full;
-        if (pl->full) {
-          const long long nwx = (pl->g.nx + 111) / 112, want = std::max(1LL, 1024 / (nwx * std::max<long long>(1, m.nbatch)));
-          const long long H0 = pl->strip_rows > 0 ? pl->strip_rows : ((long long)(m.row_hi - m.row_lo) + want - 1) / want;
-          xe = H0 < pl->ringc_xe_rows;
-        }
-        if (xe) return launch_ringc_flux_slab(pl, m, s);
+      // Nothing has to fit beside the waves where there is no tripole seam -> the early-exit form (k_ringcs) wherever it shortens the march:
+      // the plain form marches whole 12-row ring periods, the early-exit form leaves after every fourth row (and costs ~60 registers:
+      // 1.4 % per launch in f64, ~8 % in f32).  1024 lone waves on 1080 x 1440 f64 cells own 14-row strips: 32 rows marched instead of 36,
+      // and every SIMD has a wave (330 -> 364 G cell-steps/s, tools/measure_midsize.py); an 8-way slab 28 instead of 36; BASELINE-size
+      // f64 grids 96 either way (-> k_ringc), BASELINE-size f32 grids 52 instead of 60 (+4 %), 1080 x 1440 f32 24 either way (-> k_ringc,
+      // the early-exit form measured 9 % slower there).
+      if (!pl->g.fold) {
+        const bool f64 = pl->d.dtype == GCMF_F64;
+        const int wi = f64 ? 112 : 240;   // useful columns of a window (f32: four cells per lane)
+        const long long nwx = (pl->g.nx + wi - 1) / wi, want = std::max(1LL, 1024 / (nwx * std::max<long long>(1, m.nbatch)));
+        const long long nrows = m.row_hi - m.row_lo;
+        const long long H0 = std::min(nrows, std::max(4LL, pl->strip_rows > 0 ? (long long)pl->strip_rows : (nrows + want - 1) / want));
+        const long long need = H0 + 2 * m.S;
+        const long long rows_xe = std::max(12LL, (need + 3) / 4 * 4), rows_pad = (need + 11) / 12 * 12;
+        if (H0 < pl->ringc_xe_rows && rows_xe * 100 <= rows_pad * (f64 ? 95 : 90)) return launch_ringc_flux_slab(pl, m, s);
       }
       return launch_ringc_flux(pl, m, s);
     default: break;

@@ -150,7 +150,7 @@ struct gcmf_plan {
   int last_launches = 0;
   int rows_per_wave = 0;
   int xcd_remap = 1;
-  int ringc_xe_rows = 64;   // whole f64 flux grids without a seam: strips shorter than this run the early-exit form k_ringcs (GCMF_RINGC_XE_ROWS)
+  int ringc_xe_rows = 64;   // flux plans without a seam: strips shorter than this MAY run the early-exit form k_ringcs (launch_ringc decides; GCMF_RINGC_XE_ROWS=0: never)
   int zigzag = 1;        // k_ringc (flux kinds): neighbouring strips march in opposite directions (GCMF_ZIGZAG=0: all downwards)
   int multi_s = 8;     // steps fused per pass by the temporally blocked kernel (1 = off); 8 measured best
   int strip_rows = 0;  // rows per wave strip of that kernel (0 = auto)

@@ -1,6 +1,8 @@
 """BASELINE-size checks (2400 x 3600) through size-independent properties, plus a bounded oracle comparison.
 The oracle needs ~1 s per Laplacian step at this size, so the direct comparison uses a short polynomial; the
 full benchmark polynomial (n_steps 63, 8 steps per HBM pass) is pinned to the single-step kernel bit for bit."""
+import re
+
 import numpy as np
 import pytest
 
@@ -255,7 +257,7 @@ def test_f32_state_of_the_flux_configs_at_full_size(fullsize, cfg, key, monkeypa
         assert flt.n_steps == int(fullsize[key + "/meta"][0])
         outs[ev] = flt.apply(f4)
         plan = ALL_KERNELS[GridType[wl["grid"]]](**gv4)._plan(_lib.F32, SHAPE)
-        assert ("k_ringc<float" in plan.last_kernel()) == (ev == "auto"), (ev, plan.last_kernel())
+        assert (re.search(r"k_ringcs?<float", plan.last_kernel()) is not None) == (ev == "auto"), (ev, plan.last_kernel())
         assert outs[ev].dtype == np.float64
     jj, ii = T.probe_points(SHAPE)
     want = np.atleast_2d(fullsize[key + "/probe"])[0]

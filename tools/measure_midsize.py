@@ -23,11 +23,13 @@ grids = sys.argv[1:] or ["IRREGULAR_WITH_LAND", "REGULAR_WITH_LAND"]
 for grid in grids:
     for shape in ((720, 1440), (1080, 1440), (1440, 2880), (2400, 3600)):
         f, gv = T.scalar_case(grid, shape)
+        if os.environ.get("MIDSIZE_DT", "f8") == "f4":   # f32 fields and grid variables
+            f = f.astype("f4"); gv = {k: np.asarray(v).astype("f4") for k, v in gv.items()}
         dx = T.grid_dx_min(grid, gv) if grid.startswith("IRREG") else 1.0
         kw = dict(filter_scale=16.0 * dx, filter_shape=FilterShape.TAPER) if grid.startswith("IRREG") else dict(filter_scale=50.0 * dx)
         flt = Filter(dx_min=dx, grid_type=GridType[grid], grid_vars=gv, **kw)
         d = torch.from_numpy(f).cuda()
-        plan = ALL_KERNELS[GridType[grid]](**gv)._plan(_lib.F64, shape)
+        plan = ALL_KERNELS[GridType[grid]](**gv)._plan(_lib.F64 if f.dtype == np.float64 else _lib.F32, shape)
         out = []
         for depth in (8, 7, 6, 5):
             plan.set_tuning(multi_s=depth)
