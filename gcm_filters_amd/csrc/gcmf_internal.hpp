@@ -206,7 +206,8 @@ bool ring_supported(const gcmf_plan *pl, const MultiArgs &a);
 int launch_ringc_reg(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_ringc_maskz(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_ringc_flux(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
-int launch_ringc_flux_slab(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);   // f64, slabs without a tripole seam: early exits (k_ringcs)
+int launch_ringc_flux_slab(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
+int launch_ringc_flux_slab_f32(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);   // flux plans without a tripole seam, short strips: early exits (k_ringcs)
 int launch_flux_multi2(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 // the on-chip kernel (gcmf_resident.hip): L <= 64 levels of the backward evaluation in ONE launch on a field that fits the register
 // files + LDS of the chip (short slabs, small grids); pk = the L coefficients (a.S / a.pk are ignored)
