@@ -27,7 +27,7 @@ STEP_FIRST, STEP_LAST, STEP_LAND_ZERO, STEP_LAND_FIXED, STEP_CLENSHAW = 0x1, 0x2
 EXPORTS = [
     "gcmf_plan_create", "gcmf_plan_destroy", "gcmf_grid_nplanes", "gcmf_grid_ncomp", "gcmf_grid_is_dimensional",
     "gcmf_grid_is_tripolar", "gcmf_plan_rows", "gcmf_apply", "gcmf_laplacian", "gcmf_cheb_step", "gcmf_prepare",
-    "gcmf_last_timing", "gcmf_set_timing", "gcmf_set_tuning", "gcmf_last_error", "gcmf_version",
+    "gcmf_last_timing", "gcmf_set_timing", "gcmf_set_tuning", "gcmf_set_option", "gcmf_last_error", "gcmf_version",
     "gcmf_multi_supported", "gcmf_cheb_multi", "gcmf_multi_supported_vec", "gcmf_cheb_multi_vec",
     "gcmf_has_land", "gcmf_zero_land", "gcmf_land_fix", "gcmf_last_kernel", "gcmf_last_kernel_timing", "gcmf_ring_fallbacks", "gcmf_clenshaw_cut",
     "gcmf_comm_unique_id", "gcmf_comm_create", "gcmf_comm_destroy", "gcmf_halo_start", "gcmf_halo_finish", "gcmf_comm_info",
@@ -193,6 +193,8 @@ def load() -> C.CDLL:
         lib.gcmf_set_timing.restype = C.c_int
         lib.gcmf_set_tuning.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         lib.gcmf_set_tuning.restype = C.c_int
+        lib.gcmf_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+        lib.gcmf_set_option.restype = C.c_int
         lib.gcmf_last_error.argtypes = []
         lib.gcmf_last_error.restype = C.c_char_p
         lib.gcmf_version.argtypes = []
@@ -433,6 +435,11 @@ class Plan:
         check(load().gcmf_set_tuning(self._h, int(rows_per_wave), int(xcd_remap),
                                      (int(multi_s) & 0xFF) | ((int(strip_rows) & 0xFFFF) << 8)
                                      | ((int(prefetch_rows) & 0xF) << 24) | (((int(clenshaw) + 1) & 3) << 28 if clenshaw >= 0 else 0)))
+
+
+    def set_option(self, name: str, value: int):
+        """Named per-plan switch (gcmf_set_option): "cgrid_ring", "cgrid_ring_smax", "cgrid_ring_d"."""
+        check(load().gcmf_set_option(self._h, name.encode(), int(value)))
 
 
 class Comm:

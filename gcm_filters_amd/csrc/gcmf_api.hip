@@ -375,6 +375,9 @@ int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int 
     }                                                                                  \
   } while (0)
   if (const char *e = getenv("GCMF_CGRID_TILE")) pl->cgrid_tile = atoi(e);
+  if (const char *e = getenv("GCMF_CGRID_RING")) pl->cgrid_ring = atoi(e);
+  if (const char *e = getenv("GCMF_CGRID_RING_SMAX")) pl->cgrid_ring_smax = atoi(e);
+  if (const char *e = getenv("GCMF_CGRID_RING_D")) pl->cgrid_ring_d = atoi(e);
   if (const char *e = getenv("GCMF_HOST_CHUNK_MB")) pl->host_chunk_bytes = (size_t)(atof(e) * 1048576.0);
   if (const char *e = getenv("GCMF_HOST_REGISTER")) pl->host_register = atoi(e);
   if (const char *e = getenv("GCMF_ZERO_LAND")) pl->zero_land = atoi(e);
@@ -507,6 +510,20 @@ int gcmf_set_tuning(gcmf_plan *pl, int rows_per_wave, int xcd_remap, int multi_s
     pl->strip_rows = (multi_s >> 8) & 0xFFFF;   // bits 8..23: rows per strip (0 = auto)
     pl->prefetch_rows = (multi_s >> 24) & 0xF;  // bits 24..27: operand rows in flight per wave (0 = default)
     if ((multi_s >> 28) & 3) pl->clenshaw = ((multi_s >> 28) & 3) - 1;  // bits 28..29: backward evaluation 1 = off, 2 = flux kinds, 3 = all
+  }
+  return GCMF_OK;
+}
+
+int gcmf_set_option(gcmf_plan *pl, const char *name, int value) {
+  if (!pl || !name) return GCMF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(pl->mu);
+  const std::string n(name);
+  if (n == "cgrid_ring") pl->cgrid_ring = value;
+  else if (n == "cgrid_ring_smax") pl->cgrid_ring_smax = value;
+  else if (n == "cgrid_ring_d") pl->cgrid_ring_d = value;
+  else {
+    set_error("gcmf_set_option: unknown option '%s'", name);
+    return GCMF_ERR_INVALID_ARG;
   }
   return GCMF_OK;
 }
@@ -940,7 +957,7 @@ int gcmf_slab_apply_backward_vec(gcmf_plan *pl, gcmf_comm *comm, gcmf_p2p *p2p, 
     if ((rc = exchange(st, 2))) return rc;
   }
   const void *u[2] = {X[0], X[1]}, *v[2] = {nullptr, nullptr};
-  const int smax = std::min(pl->multi_s, 4);
+  const int smax = std::min(pl->multi_s, cgrid_ring_supported(pl, nbatch, 5) ? 5 : 4);   // (as gcmf_apply cuts them)
   int valid = hs, lvl = 1;
   while (lvl <= n_steps) {
     const int left = n_steps - lvl + 1;
@@ -1223,7 +1240,8 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
       void *pool[4][2] = {{A[0], A[1]}, {B[0], B[1]}, {Cb[0], Cb[1]}, {Db[0], Db[1]}};
       // four levels per launch with two operand rows in flight: 353-357 G on config 5; five levels leave one row in flight and
       // spill (305-310 G); the forward kernel at its best (five levels) 280 G
-      const int smax = std::min(pl->multi_s, 4);
+      // (round 5: k_cgrid_ring, gcmf_cgrid_ring.hip, takes batched f32 levels four or five at a time)
+      const int smax = std::min(pl->multi_s, cgrid_ring_supported(pl, nbatch, 5) ? 5 : 4);
       int lvl = 1;
       while (lvl <= n_steps) {
         const int left = n_steps - lvl + 1;

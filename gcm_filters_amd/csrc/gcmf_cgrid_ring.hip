@@ -1,0 +1,489 @@
+// k_cgrid_ring: the C-grid vector Laplacian (reference gcm_filters/kernels.py:630-696) inside the backward (Clenshaw) evaluation of
+// the filter polynomial (reference filter.py:217-291 restated as in gcmf_ringc_impl.hpp), S levels per pass over HBM, for batched
+// levels (BASELINE config 5: 50 levels of 2400 x 3600, f32).  Round 5 rebuild of k_cgrid_stream2c around what its instruction stream
+// showed (440 VALU instructions per row at S = 4 of which 130 are arithmetic: 138 register moves, 117 compare / select of the
+// per-level nan_to_num, 28 address computations):
+//
+//   * same work split: a workgroup = 4 waves = 4 levels of the batch marching one (window, strip) group in lock-step, the 14 coefficient
+//     rows fetched once per workgroup (a quarter per wave) and handed round through an LDS ring, one barrier per row; a wave owns 128
+//     columns (two cells per lane, 8-byte accesses) and time-skews S levels along y, level j one row behind level j - 1;
+//   * STATIC RINGS: every row that outlives an iteration (level outputs: 3 slots, operand rows in flight, the rows of f, the LDS slots)
+//     lives in a ring whose slot is (row) mod (ring size); the row loop is unrolled over the common period 12, so every slot is a
+//     compile-time register / LDS offset and nothing is ever moved;
+//   * PACKED f32: the two cells of a lane are one <2 x float>, every multiply / add / fma is a v_pk_* instruction; only the four
+//     x-differences per level need the neighbour lane (DPP);
+//   * nan_to_num WITHOUT per-level compares: a NaN never leaves its cell and never becomes finite (the "-x", b_{k+2} and p_k f terms
+//     keep it), so the set of NaN cells of a row is the same at every level: it is taken ONCE per row from the delivered state row
+//     (lane masks in scalar registers) and every level zeroes its stencil operands with one select each;
+//   * +-inf (nan_to_num clamps it to +-FLT_MAX in the stencil, kernels.py:651-652) is only WATCHED on the delivered rows; a workgroup
+//     that meets one redoes its strip with the full nan_to_num at every level (SAN = true; same arithmetic);
+//   * scalar addressing: row pointers in SGPRs, one 32-bit lane offset (global_load ... saddr).
+//
+// Arithmetic per level = CgLevel::feed<true> of gcmf_cgrid_stream2.hip operation for operation, so this kernel, k_cgrid_stream2c (which
+// still runs single-level fields, f64 plans and remainders below 4 levels) and the slab drivers give the same bits.
+#include "gcmf_multi_common.hpp"
+#include "gcmf_recurrence.hpp"
+#include <cstdlib>
+
+namespace gcmf {
+
+template <typename T> struct CgV2;
+template <> struct CgV2<float> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct CgV2<double> { typedef double type __attribute__((ext_vector_type(2))); };
+
+template <int N> using cic = std::integral_constant<int, N>;
+constexpr int cmod(int a, int m) { return ((a % m) + m) % m; }
+
+template <typename T> struct CRingP {
+  const T *u0, *v0;    // b_{k+1} (first launch: the input f, scaled by p_n as it is loaded)
+  const T *up, *vp;    // b_{k+2} (first launch: unused, zero)
+  const T *fu, *fv;    // the constant input f
+  T *u1o, *v1o;        // level S - 1: b_{k+2} of the next launch (unused by the last launch)
+  T *u2o, *v2o;        // level S:     b_{k+1} of the next launch; last launch: the result when it has the state's type
+  double *du, *dv;     // last launch: the f64 result of f32 state (or null)
+  const T *coef[MAX_COEF];
+  unsigned *redo;      // counts the workgroups that redid their strip with the full nan_to_num (instrumentation)
+  int nx, rows, out_lo, out_hi;
+  int H, nwx, ngroups, nlev, nlev4, wrap, last;
+  long long bstride;
+  double pn, pk[8], c;
+};
+
+template <typename T> __device__ __forceinline__ T cr_san(T x) {  // numpy.nan_to_num, as c2san of gcmf_cgrid_stream2.hip
+  const bool isn = (x != x);
+  const bool big = (mabs(x) > MLim<T>::big());
+  const T clamped = big ? (x > T(0) ? MLim<T>::big() : -MLim<T>::big()) : x;
+  return isn ? T(0) : clamped;
+}
+
+constexpr int CR_U = 12;  // unroll factor of the row loop = common period of all rings
+
+template <int S> struct CRingGeom {
+  static constexpr int M = (S + 1) / 2 * 2;      // level j is stale j cells per side; windows start on an even column
+  static constexpr int W = 128, WI = W - 2 * M;
+  static constexpr int NS = (S <= 5) ? 6 : 12;   // LDS slots (>= S + 1, divides the period)
+  static constexpr size_t lds_bytes(size_t elem) { return (size_t)NS * 16 * 64 * 2 * elem; }
+};
+
+// The row cursor of a march (scalar registers): issue after issue it walks the rows r_begin, r_begin + 1, ... of the strip (periodic or
+// clamped at the slab's edges), stops at the last delivered row (the padded iterations of the last ring period re-load it), and gives
+// the byte offsets of the row it is on (ro) and of the row before it (rc) inside a level's plane (< 4 GB).
+struct CRingCursor {
+  int nx, rows, r_end, ri, cj;
+  bool wrap;
+  unsigned ro, rc, es;
+  __device__ __forceinline__ CRingCursor(int nx_, int rows_, bool wrap_, int r_begin, int r_end_, unsigned es_)
+      : nx(nx_), rows(rows_), r_end(r_end_), ri(r_begin), wrap(wrap_), es(es_) {
+    int r = r_begin - 1;
+    if (wrap) {
+      r = r < 0 ? r + rows : (r >= rows ? r - rows : r);
+      r = r < 0 ? r + rows : (r >= rows ? r - rows : r);  // |overshoot| <= S + 1 may exceed one period on tiny grids
+    } else {
+      r = r < 0 ? 0 : (r >= rows ? rows - 1 : r);
+    }
+    cj = r;
+    ro = rc = (unsigned)(cj * nx) * es;
+  }
+  __device__ __forceinline__ void advance() {
+    const bool adv = ri < r_end;
+    int nj;
+    if (wrap) {
+      nj = cj + 1;
+      nj = nj >= rows ? nj - rows : nj;
+    } else {
+      nj = ri < 0 ? 0 : (ri >= rows ? rows - 1 : ri);
+    }
+    rc = adv ? ro : rc;
+    cj = adv ? nj : cj;
+    ro = (unsigned)(cj * nx) * es;
+    ri += adv ? 1 : 0;
+  }
+};
+
+// A helper wave (a level that pads the last workgroup of a tile): fetches and publishes its share of the coefficient rows, keeps the
+// barriers, computes nothing.
+template <typename T, int S, int D>
+__device__ __forceinline__ void cgring_helper(const CRingP<T> &P, unsigned char *s_raw, const int lane, const int wv, const unsigned colB,
+                                              const int r_begin, const int r_end, const int n_pad) {
+  typedef typename CgV2<T>::type v2;
+  constexpr int NS = CRingGeom<S>::NS, RSH = D + 1;
+  typedef v2 Slot[16][64];
+  Slot *s_coef = reinterpret_cast<Slot *>(s_raw);
+  const T *cp[4];
+  bool isA[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int pidx = wv + 4 * q;
+    cp[q] = P.coef[pidx < 14 ? pidx : 0];
+    isA[q] = pidx < 7 || pidx >= 14;
+  }
+  v2 SH[RSH][4];
+  CRingCursor cur(P.nx, P.rows, P.wrap, r_begin, r_end, (unsigned)sizeof(T));
+  auto issue = [&](auto ph_c) {
+    constexpr int ph = decltype(ph_c)::value;
+    cur.advance();
+    const unsigned vo = colB + cur.ro, vc = colB + cur.rc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      SH[ph % RSH][q] = *reinterpret_cast<const v2 *>(reinterpret_cast<const char *>(cp[q]) + (isA[q] ? vo : vc));
+  };
+  auto phase = [&](auto ph_c) {
+    constexpr int ph = decltype(ph_c)::value;
+    issue(cic<(ph + D) % CR_U>{});
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_coef[ph % NS][wv + 4 * q][lane] = SH[ph % RSH][q];
+    __syncthreads();
+  };
+  issue(cic<0>{});
+  if constexpr (D >= 2) issue(cic<1>{});
+  if constexpr (D >= 3) issue(cic<2>{});
+  for (int r = r_begin; r < r_begin + n_pad; r += CR_U) {
+    phase(cic<0>{});  phase(cic<1>{});  phase(cic<2>{});  phase(cic<3>{});  phase(cic<4>{});  phase(cic<5>{});
+    phase(cic<6>{});  phase(cic<7>{});  phase(cic<8>{});  phase(cic<9>{});  phase(cic<10>{});  phase(cic<11>{});
+  }
+}
+
+// One march of a strip by one wave (one level of the batch).  Returns whether a +-inf was delivered (wave-uniform); SAN = the redo pass.
+template <typename T, int S, int D, bool FIRST, bool SAN>
+__device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *s_raw, const int lane, const int wv, const long long boff,
+                                             const unsigned colB, const bool keep, const int a, const int b, const int n_pad) {
+  typedef typename CgV2<T>::type v2;
+  constexpr int NS = CRingGeom<S>::NS;
+  constexpr int U = CR_U, RU = 6, RV = D + 1, RF = 12, RSH = D + 1;
+  static_assert(D >= 1 && D <= 3 && S >= 2 && S + D <= RF && S < NS && U % NS == 0 && U % RV == 0, "ring periods");
+  typedef v2 Slot[16][64];
+  Slot *s_coef = reinterpret_cast<Slot *>(s_raw);
+  const int nx = P.nx, rows = P.rows;
+  const bool wrap = P.wrap, last = P.last;
+  const T c = (T)P.c;
+  const int r_begin = a - S, r_end = b + S;  // rows delivered: [a - S, b + S - 1]
+  const T *pu0 = (FIRST ? P.fu : P.u0) + boff, *pv0 = (FIRST ? P.fv : P.v0) + boff;
+  const T *pup = (FIRST ? P.fu : P.up) + boff, *pvp = (FIRST ? P.fv : P.vp) + boff;  // (first launch: never loaded)
+  const T *pfu = P.fu + boff, *pfv = P.fv + boff;
+  const T *cp[4];
+  bool isA[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int pidx = wv + 4 * q;   // planes 0..6 travel with the delivered row, 7..13 with the row before; 14, 15: padding
+    cp[q] = P.coef[pidx < 14 ? pidx : 0];
+    isA[q] = pidx < 7 || pidx >= 14;
+  }
+  // (plane pointer in scalar registers) + (32-bit byte offset of the lane's cells in the row): the global_load saddr form
+  auto ld2 = [&](const T *plane, unsigned voff) { return *reinterpret_cast<const v2 *>(reinterpret_cast<const char *>(plane) + voff); };
+  CRingCursor cur(nx, rows, wrap, r_begin, r_end, (unsigned)sizeof(T));
+
+  const v2 Z = {T(0), T(0)};
+  v2 G0u[RU], G0v[RU];         // delivered rows of b_{k+1} ("level 0"); slot = (row - r_begin) mod RU
+  v2 Vu[RV], Vv[RV];           // rows of b_{k+2}; slot = (iteration) mod RV
+  v2 Fu[RF], Fv[RF];           // rows of f; slot = (iteration that delivered them) mod RF
+  v2 SH[RSH][4];               // this wave's share of the coefficient rows, in flight
+  v2 Xu[S][3], Xv[S][3];       // X[m], m = 1 .. S - 1: rows of level m; slot = (iteration that produced them) mod 3
+  v2 Lvt[S + 1][2], Lvh[S + 1][2], Luh[S + 1][2], LP[S + 1][2], LQ[S + 1][2], LR[S + 1][2];  // per level: what the previous row hands on
+  bool Ku0[U], Ku1[U], Kv0[U], Kv1[U];   // "not NaN" of the delivered rows; slot = (row - r_begin) mod U
+#pragma unroll
+  for (int l = 0; l < RU; ++l) G0u[l] = G0v[l] = Z;
+#pragma unroll
+  for (int l = 0; l < RV; ++l) Vu[l] = Vv[l] = Z;
+#pragma unroll
+  for (int l = 0; l < RF; ++l) Fu[l] = Fv[l] = Z;
+#pragma unroll
+  for (int m = 0; m < S; ++m) {
+#pragma unroll
+    for (int l = 0; l < 3; ++l) Xu[m][l] = Xv[m][l] = Z;
+  }
+#pragma unroll
+  for (int m = 0; m <= S; ++m) {
+#pragma unroll
+    for (int l = 0; l < 2; ++l) Lvt[m][l] = Lvh[m][l] = Luh[m][l] = LP[m][l] = LQ[m][l] = LR[m][l] = Z;
+  }
+#pragma unroll
+  for (int l = 0; l < U; ++l) Ku0[l] = Ku1[l] = Kv0[l] = Kv1[l] = true;
+  bool seen_inf = false;
+
+  auto issue = [&](auto ph_c) {  // the loads of the next iteration, into the slots of its phase
+    constexpr int ph = decltype(ph_c)::value;
+    cur.advance();   // (the padded iterations of the last period re-load the last row and store nothing)
+    const unsigned vo = colB + cur.ro, vc = colB + cur.rc;
+    G0u[ph % RU] = ld2(pu0, vo);
+    G0v[ph % RU] = ld2(pv0, vo);
+    if constexpr (!FIRST) {
+      Vu[ph % RV] = ld2(pup, vc);
+      Vv[ph % RV] = ld2(pvp, vc);
+    }
+    Fu[ph % RF] = ld2(pfu, vc);
+    Fv[ph % RF] = ld2(pfv, vc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) SH[ph % RSH][q] = ld2(cp[q], isA[q] ? vo : vc);
+  };
+
+  v2 out_u = Z, out_v = Z, out_pu = Z, out_pv = Z;
+
+  // level j of iteration r (phase ph): fed with row rho = r - j + 1 of level j - 1, produces row rho - 1 of level j
+  auto level = [&](auto jj, auto ph_c) {
+    constexpr int j = decltype(jj)::value;
+    constexpr int ph = decltype(ph_c)::value;
+    constexpr int sl = cmod(ph - (j - 1), NS);      // the LDS slot published in iteration r - j + 1
+    constexpr int kn = cmod(ph - (j - 1), U);       // NaN masks of row rho
+    constexpr int n3 = ph % 3, o3 = cmod(ph - 1, 3), p3 = cmod(ph - 2, 3);
+    const v2 inu = (j == 1) ? G0u[ph % RU] : Xu[j >= 2 ? j - 1 : 1][n3];
+    const v2 inv = (j == 1) ? G0v[ph % RU] : Xv[j >= 2 ? j - 1 : 1][n3];
+    const v2 xu = (j == 1) ? G0u[cmod(ph - 1, RU)] : Xu[j >= 2 ? j - 1 : 1][o3];   // row rho - 1 of level j - 1: the "-x" term
+    const v2 xv = (j == 1) ? G0v[cmod(ph - 1, RU)] : Xv[j >= 2 ? j - 1 : 1][o3];
+    const v2 x2u = (j == 1) ? Vu[ph % RV] : (j == 2 ? G0u[cmod(ph - 2, RU)] : Xu[j >= 3 ? j - 2 : 1][p3]);   // row rho - 1 of level j - 2
+    const v2 x2v = (j == 1) ? Vv[ph % RV] : (j == 2 ? G0v[cmod(ph - 2, RU)] : Xv[j >= 3 ? j - 2 : 1][p3]);
+    const v2 fu = Fu[cmod(ph - j + 1, RF)], fv = Fv[cmod(ph - j + 1, RF)];        // row rho - 1 of f
+    v2 su, sv;
+    if constexpr (SAN) {
+      su.x = cr_san(inu.x);  su.y = cr_san(inu.y);
+      sv.x = cr_san(inv.x);  sv.y = cr_san(inv.y);
+    } else {
+      su.x = Ku0[kn] ? inu.x : T(0);  su.y = Ku1[kn] ? inu.y : T(0);
+      sv.x = Kv0[kn] ? inv.x : T(0);  sv.y = Kv1[kn] ? inv.y : T(0);
+    }
+    v2 A[7], B[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      A[q] = s_coef[sl][q][lane];
+      B[q] = s_coef[sl][7 + q][lane];
+    }
+    constexpr int lo = cmod(ph - 1, 2), ln = ph % 2;
+    // ---- CgLevel::feed<true> on the pair (gcmf_cgrid_stream2.hip) ----
+    const v2 ut = su * A[0], uh = su * A[1], vt = sv * A[2], vh = sv * A[3];
+    // (the four x-differences as scalar operations: the neighbour lane's value rides on the subtraction as a DPP operand)
+    v2 dut;  dut.x = ut.x - from_lower_lane0(ut.y);  dut.y = ut.y - ut.x;                 // ut - W ut
+    const v2 Pr = __builtin_elementwise_fma(A[4], dut, -(A[5] * (vt - Lvt[j][lo])));
+    const v2 Qr = A[6] * Pr;
+    const v2 vhp = Lvh[j][lo];
+    v2 dvh;  dvh.x = vhp.y - vhp.x;  dvh.y = from_upper_lane0(vhp.x) - vhp.y;             // E vh_p - vh_p
+    const v2 Rm = __builtin_elementwise_fma(B[0], dvh, B[1] * (uh - Luh[j][lo]));
+    const v2 Sm = B[2] * Rm;
+    const v2 Pp = LP[j][lo];
+    v2 dpp;  dpp.x = Pp.x - Pp.y;  dpp.y = Pp.y - from_upper_lane0(Pp.x);                 // P_p - E P_p
+    v2 dsm;  dsm.x = from_lower_lane0(Sm.y) - Sm.x;  dsm.y = Sm.x - Sm.y;                 // W Sm - Sm
+    const v2 lu = __builtin_elementwise_fma(B[3], dpp, B[4] * (LR[j][lo] - Rm));
+    const v2 lv = __builtin_elementwise_fma(B[5], dsm, -(B[6] * (LQ[j][lo] - Qr)));
+    Lvt[j][ln] = vt;  Lvh[j][ln] = vh;  Luh[j][ln] = uh;  LP[j][ln] = Pr;  LQ[j][ln] = Qr;  LR[j][ln] = Rm;
+    // ---- b_k = p_k f + 2 A(b_{k+1}) - b_{k+2},  A(x) = -x - c L(x);  the last level of the last launch is the result: A, not 2 A ----
+    const v2 mc = {-c, -c};
+    const T two_s = (last && j == S) ? T(1) : T(2);
+    const v2 two = {two_s, two_s};
+    const T pk_s = (T)P.pk[j - 1];
+    const v2 pk = {pk_s, pk_s};
+    const v2 afu = __builtin_elementwise_fma(mc, lu, -xu), afv = __builtin_elementwise_fma(mc, lv, -xv);
+    const v2 cu = __builtin_elementwise_fma(pk, fu, __builtin_elementwise_fma(two, afu, -x2u));
+    const v2 cv = __builtin_elementwise_fma(pk, fv, __builtin_elementwise_fma(two, afv, -x2v));
+    if constexpr (j < S) {
+      Xu[j][n3] = cu;
+      Xv[j][n3] = cv;
+    }
+    if constexpr (j == S - 1) { out_pu = cu;  out_pv = cv; }
+    if constexpr (j == S) { out_u = cu;  out_v = cv; }
+  };
+
+  auto phase = [&](auto ph_c, int r) {
+    constexpr int ph = decltype(ph_c)::value;
+    issue(cic<(ph + D) % U>{});
+    // ---- hand this iteration's coefficient rows round ----
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_coef[ph % NS][wv + 4 * q][lane] = SH[ph % RSH][q];
+    __syncthreads();
+    // ---- the delivered row of b_{k+1}: b_n = p_n f in a first launch; its NaN cells; +-inf watched ----
+    {
+      v2 gu = G0u[ph % RU], gv = G0v[ph % RU];
+      if constexpr (FIRST) {
+        const T pn = (T)P.pn;
+        const v2 pn2 = {pn, pn};
+        gu = pn2 * gu;
+        gv = pn2 * gv;
+        G0u[ph % RU] = gu;
+        G0v[ph % RU] = gv;
+      }
+      if constexpr (!SAN) {
+        Ku0[ph % U] = (gu.x == gu.x);  Ku1[ph % U] = (gu.y == gu.y);
+        Kv0[ph % U] = (gv.x == gv.x);  Kv1[ph % U] = (gv.y == gv.y);
+        seen_inf = seen_inf || (mabs(gu.x) > MLim<T>::big()) || (mabs(gu.y) > MLim<T>::big()) || (mabs(gv.x) > MLim<T>::big()) ||
+                   (mabs(gv.y) > MLim<T>::big());
+      }
+    }
+    level(cic<1>{}, ph_c);
+    if constexpr (S >= 2) level(cic<2>{}, ph_c);
+    if constexpr (S >= 3) level(cic<3>{}, ph_c);
+    if constexpr (S >= 4) level(cic<4>{}, ph_c);
+    if constexpr (S >= 5) level(cic<5>{}, ph_c);
+    if constexpr (S >= 6) level(cic<6>{}, ph_c);
+    if constexpr (S >= 7) level(cic<7>{}, ph_c);
+    if constexpr (S >= 8) level(cic<8>{}, ph_c);
+    // ---- stores: row r - S of level S, row r - S + 1 of level S - 1 ----
+    const int ju = r - S;
+    if (ju >= a && ju < b) {   // wave-uniform
+      const unsigned vo = colB + (unsigned)(ju * nx) * (unsigned)sizeof(T);
+      if (keep) {
+        if (P.du) {   // (wave-uniform; last launch) f32 state, f64 result: NumPy >= 2 promotes p[k] * T
+          typedef double d2 __attribute__((ext_vector_type(2)));
+          d2 du, dv;
+          du.x = (double)out_u.x;  du.y = (double)out_u.y;
+          dv.x = (double)out_v.x;  dv.y = (double)out_v.y;
+          *reinterpret_cast<d2 *>(reinterpret_cast<char *>(P.du + boff) + 2 * (size_t)vo) = du;
+          *reinterpret_cast<d2 *>(reinterpret_cast<char *>(P.dv + boff) + 2 * (size_t)vo) = dv;
+        } else {      // the next launch's b_{k+1}; last launch: the result in the state's type
+          *reinterpret_cast<v2 *>(reinterpret_cast<char *>(P.u2o + boff) + vo) = out_u;
+          *reinterpret_cast<v2 *>(reinterpret_cast<char *>(P.v2o + boff) + vo) = out_v;
+        }
+      }
+    }
+    const int jv = r - S + 1;
+    if (!last && jv >= a && jv < b) {
+      const unsigned vo = colB + (unsigned)(jv * nx) * (unsigned)sizeof(T);
+      if (keep) {
+        *reinterpret_cast<v2 *>(reinterpret_cast<char *>(P.u1o + boff) + vo) = out_pu;
+        *reinterpret_cast<v2 *>(reinterpret_cast<char *>(P.v1o + boff) + vo) = out_pv;
+      }
+    }
+  };
+
+  issue(cic<0>{});
+  if constexpr (D >= 2) issue(cic<1>{});
+  if constexpr (D >= 3) issue(cic<2>{});
+  for (int r = r_begin; r < r_begin + n_pad; r += U) {
+    phase(cic<0>{}, r);  phase(cic<1>{}, r + 1);  phase(cic<2>{}, r + 2);  phase(cic<3>{}, r + 3);
+    phase(cic<4>{}, r + 4);  phase(cic<5>{}, r + 5);  phase(cic<6>{}, r + 6);  phase(cic<7>{}, r + 7);
+    phase(cic<8>{}, r + 8);  phase(cic<9>{}, r + 9);  phase(cic<10>{}, r + 10);  phase(cic<11>{}, r + 11);
+  }
+  return __any(seen_inf);
+}
+
+template <typename T, int S, int D, bool FIRST, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_cgrid_ring(const CRingP<T> P) {
+  constexpr int M = CRingGeom<S>::M, W = CRingGeom<S>::W, WI = CRingGeom<S>::WI;
+  extern __shared__ __align__(16) unsigned char s_raw[];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // workgroups are dealt to the 8 XCDs round-robin: the 13 workgroups (50 levels) of a group follow each other on ONE XCD, so that the
+  // coefficient rows the first of them fetched are found in that XCD's L2 by the others (as k_cgrid_stream2)
+  const int blk = blockIdx.x;
+  const int xcd = blk & 7, slot = (blk >> 3) * 4 + wv;
+  const int group = (slot / P.nlev4) * 8 + xcd;
+  int lev = slot % P.nlev4;
+  if (group >= P.ngroups) return;  // whole workgroups leave together
+  const bool shadow = lev >= P.nlev;
+  if (shadow) lev = P.nlev - 1;
+  const int wx = group % P.nwx, st = group / P.nwx;
+  const int nx = P.nx;
+  const int a = P.out_lo + st * P.H;
+  const int b = min(a + P.H, P.out_hi);
+  const long long boff = (long long)lev * P.bstride;
+  const int pos = wx * WI - M + lane * 2;
+  int col = pos % nx;
+  if (col < 0) col += nx;
+  const unsigned colB = (unsigned)col * (unsigned)sizeof(T);
+  const bool keep = (lane * 2 >= M) && (lane * 2 < W - M) && (pos < nx);
+  const int n_pad = ((b - a) + 2 * S + CR_U - 1) / CR_U * CR_U;   // the march is padded to whole ring periods
+  bool bad = false;
+  if (shadow) cgring_helper<T, S, D>(P, s_raw, lane, wv, colB, a - S, b + S, n_pad);
+  else bad = cgring_march<T, S, D, FIRST, false>(P, s_raw, lane, wv, boff, colB, keep, a, b, n_pad);
+  if (__syncthreads_or(bad ? 1 : 0)) {   // a +-inf somewhere in the workgroup's rows: the strip again, nan_to_num in full at every level
+    if (threadIdx.x == 0 && P.redo) atomicAdd(P.redo, 1u);
+    if (shadow) cgring_helper<T, S, D>(P, s_raw, lane, wv, colB, a - S, b + S, n_pad);
+    else cgring_march<T, S, D, FIRST, true>(P, s_raw, lane, wv, boff, colB, keep, a, b, n_pad);
+  }
+}
+
+static bool cr_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+bool cgrid_ring_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
+  if (!pl->cgrid_ring || pl->kind != K_CGRID || pl->cgrid_tile || pl->d.dtype != GCMF_F32) return false;
+  if (nbatch < 2) return false;   // single-level fields: k_cgrid_stream2c's private-ring form
+  if (S < 4 || S > 5 || S > pl->cgrid_ring_smax) return false;
+  if (pl->g.nx % 2 || pl->g.nx < 2 || pl->g.rows < S + 2) return false;
+  if ((long long)pl->g.rows * pl->g.nx * 4 >= (1LL << 32)) return false;   // 32-bit byte offsets inside a level's plane
+  for (int k = 0; k < MAX_COEF; ++k)
+    if (!cr_al16(pl->g.coef[k])) return false;
+  return true;
+}
+
+template <typename T, int S, int D, int WPS> static int launch_cr(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
+  constexpr int WI = CRingGeom<S>::WI;
+  const Geom &g = pl->g;
+  CRingP<T> P;
+  P.u0 = (const T *)a.u0[0];  P.v0 = (const T *)a.u0[1];
+  P.up = (const T *)a.uprev[0];  P.vp = (const T *)a.uprev[1];
+  P.fu = (const T *)a.fb_in[0];  P.fv = (const T *)a.fb_in[1];
+  P.u1o = (T *)a.u1o[0];  P.v1o = (T *)a.u1o[1];
+  P.u2o = (T *)a.u2o[0];  P.v2o = (T *)a.u2o[1];
+  P.du = P.dv = nullptr;
+  if (a.last) {
+    if (sizeof(T) == 4 && !a.fb_is_f32) {  // f32 state, f64 result (NumPy >= 2 promotion of the reference)
+      P.du = (double *)a.fb_out[0];
+      P.dv = (double *)a.fb_out[1];
+    } else {
+      P.u2o = (T *)a.fb_out[0];
+      P.v2o = (T *)a.fb_out[1];
+    }
+  }
+  for (int k = 0; k < MAX_COEF; ++k) P.coef[k] = (const T *)g.coef[k];
+  P.redo = pl->ring_nfb;
+  P.nx = g.nx;
+  P.rows = g.rows;
+  P.out_lo = a.row_lo;
+  P.out_hi = a.row_hi;
+  const int nrows = a.row_hi - a.row_lo;
+  if (nrows <= 0 || a.nbatch <= 0) return GCMF_OK;
+  P.nwx = (g.nx + WI - 1) / WI;
+  P.nlev = (int)a.nbatch;
+  P.nlev4 = (P.nlev + 3) / 4 * 4;
+  int H = pl->strip_rows;
+  if (H <= 0) {
+    // strips as tall as possible (a strip marches H + 2 S rows, padded to whole periods of 12) while the launch still fills whole
+    // rounds of the resident waves: the fewest strips of <= 96 rows fix the number of rounds, then the strip count grows to fill the
+    // last round; then H + 2 S is brought up to a whole number of periods
+    const long long cap = 1024LL * WPS;
+    const long long per_strip = (long long)P.nwx * P.nlev4, hmax = 96;
+    const long long ns_min = (nrows + hmax - 1) / hmax;
+    const long long rounds = (ns_min * per_strip + cap - 1) / cap;
+    long long ns = rounds * cap / per_strip;
+    if (ns < ns_min) ns = ns_min;
+    H = (int)((nrows + ns - 1) / ns);
+    if (H < 16) H = 16;
+    const long long nst = (nrows + H - 1) / H;
+    H = (int)((nrows + nst - 1) / nst);   // (same strip count, evened out)
+  }
+  if (H > nrows) H = nrows;
+  P.H = H;
+  P.ngroups = P.nwx * ((nrows + H - 1) / H);
+  P.wrap = g.south_wrap && g.north_wrap;
+  P.last = a.last;
+  P.bstride = (long long)g.rows * g.nx;
+  P.pn = a.p0;
+  for (int t = 0; t < 8; ++t) P.pk[t] = t < 6 ? a.pk[t] : 0.0;
+  P.c = a.c;
+  const long long groups_per_xcd = (P.ngroups + 7) / 8;
+  const long long blocks_per_xcd = (groups_per_xcd * P.nlev4 + 3) / 4;
+  dim3 block(256), grid((unsigned)(blocks_per_xcd * 8));
+  const size_t lds = CRingGeom<S>::lds_bytes(sizeof(T));
+  auto go = [&](auto kern, bool &attr_set) -> int {
+    if (!attr_set && lds > 48 * 1024) {
+      GCMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, s, P);
+    return GCMF_OK;
+  };
+  static bool set_first = false, set_next = false;  // per instantiation
+  int rc = a.first ? go(&k_cgrid_ring<T, S, D, true, WPS>, set_first) : go(&k_cgrid_ring<T, S, D, false, WPS>, set_next);
+  if (rc) return rc;
+  note_kernel(pl, std::string("gcmf::k_cgrid_ring<") + tyname<T>() + ", " + std::to_string(S) + ", " + std::to_string(D) + ", " +
+                      (a.first ? "true" : "false") + ", " + std::to_string(WPS) + ">", S,
+              launch_geom(P.H, (nrows + H - 1) / H, P.nwx, 1, grid.x, grid.y, nrows));
+  GCMF_HIP(hipGetLastError());
+  return GCMF_OK;
+}
+
+int launch_cgrid_ring(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
+  const int d = pl->cgrid_ring_d;
+  switch (a.S) {
+    case 4: return d == 3 ? launch_cr<float, 4, 3, 2>(pl, a, s) : launch_cr<float, 4, 2, 2>(pl, a, s);
+    case 5: return d == 3 ? launch_cr<float, 5, 3, 2>(pl, a, s) : launch_cr<float, 5, 2, 2>(pl, a, s);
+  }
+  return GCMF_ERR_INVALID_ARG;
+}
+
+}  // namespace gcmf

@@ -55,6 +55,9 @@ template <typename T, int VEC> struct CgLevel {
     for (int k = 0; k < VEC; ++k) vt_p[k] = vh_p[k] = uh_p[k] = P_p[k] = Q_p[k] = R_pp[k] = T(0);
   }
   // cA: rdyCu, rdxCu, rdxCv, rdyCv, a1, a2, rh of the fed row;  cB: b1, b2, rq, cu1, cu2, cv1, cv2 of the row before
+  // FMA (the backward kernels, where nothing is bit-identical with numpy anyway): the second product of every stress / divergence line
+  // rides on a fused multiply-add -- the operation order of k_cgrid_ring (gcmf_cgrid_ring.hip), which gives the same bits
+  template <bool FMA = false>
   __device__ __forceinline__ void feed(const T (&su)[VEC], const T (&sv)[VEC], const T (&cA)[7][VEC], const T (&cB)[7][VEC],
                                        T (&lu)[VEC], T (&lv)[VEC]) {
     T ut[VEC], uh[VEC], vt[VEC], vh[VEC], Pr[VEC], Qr[VEC], Rm[VEC], Sm[VEC];
@@ -70,10 +73,12 @@ template <typename T, int VEC> struct CgLevel {
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       const T utw = (k == 0) ? ut_w : ut[k > 0 ? k - 1 : 0];
-      Pr[k] = cA[4][k] * (ut[k] - utw) - cA[5][k] * (vt[k] - vt_p[k]);
+      if constexpr (FMA) Pr[k] = rfma(cA[4][k], ut[k] - utw, -(cA[5][k] * (vt[k] - vt_p[k])));
+      else Pr[k] = cA[4][k] * (ut[k] - utw) - cA[5][k] * (vt[k] - vt_p[k]);
       Qr[k] = cA[6][k] * Pr[k];
       const T vhe = (k == VEC - 1) ? vh_e : vh_p[k < VEC - 1 ? k + 1 : k];
-      Rm[k] = cB[0][k] * (vhe - vh_p[k]) + cB[1][k] * (uh[k] - uh_p[k]);
+      if constexpr (FMA) Rm[k] = rfma(cB[0][k], vhe - vh_p[k], cB[1][k] * (uh[k] - uh_p[k]));
+      else Rm[k] = cB[0][k] * (vhe - vh_p[k]) + cB[1][k] * (uh[k] - uh_p[k]);
       Sm[k] = cB[2][k] * Rm[k];
     }
     const T P_e = from_upper_lane0(P_p[0]);
@@ -82,8 +87,13 @@ template <typename T, int VEC> struct CgLevel {
     for (int k = 0; k < VEC; ++k) {
       const T pe = (k == VEC - 1) ? P_e : P_p[k < VEC - 1 ? k + 1 : k];
       const T sw = (k == 0) ? S_w : Sm[k > 0 ? k - 1 : 0];
-      lu[k] = cB[3][k] * (P_p[k] - pe) + cB[4][k] * (R_pp[k] - Rm[k]);
-      lv[k] = cB[5][k] * (sw - Sm[k]) - cB[6][k] * (Q_p[k] - Qr[k]);
+      if constexpr (FMA) {
+        lu[k] = rfma(cB[3][k], P_p[k] - pe, cB[4][k] * (R_pp[k] - Rm[k]));
+        lv[k] = rfma(cB[5][k], sw - Sm[k], -(cB[6][k] * (Q_p[k] - Qr[k])));
+      } else {
+        lu[k] = cB[3][k] * (P_p[k] - pe) + cB[4][k] * (R_pp[k] - Rm[k]);
+        lv[k] = cB[5][k] * (sw - Sm[k]) - cB[6][k] * (Q_p[k] - Qr[k]);
+      }
     }
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
@@ -255,7 +265,7 @@ __device__ __forceinline__ void cgrid_stream2_body(const CStream2P<T, FB> &P) {
       T su[VEC], sv[VEC], lu[VEC], lv[VEC];
 #pragma unroll
       for (int k = 0; k < VEC; ++k) { su[k] = c2san(cu[j - 1][k]); sv[k] = c2san(cv[j - 1][k]); }
-      L[j - 1].feed(su, sv, cA, cB, lu, lv);
+      L[j - 1].template feed<CLEN>(su, sv, cA, cB, lu, lv);
       const double pkj = P.pk[j - 1];
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
@@ -506,6 +516,7 @@ template <typename T, typename FB, int S> static int launch_c2_sel(gcmf_plan *pl
 }
 
 int launch_cgrid_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
+  if (a.clen && cgrid_ring_supported(pl, a.nbatch, a.S)) return launch_cgrid_ring(pl, a, s);   // batched f32 levels, deep launches
   if (a.clen) {  // backward evaluation: the conveyor has the state's type; single-level fields: private coefficient rings as above
     static const bool priv_ok = !(getenv("GCMF_VEC_PRIV") && atoi(getenv("GCMF_VEC_PRIV")) == 0);
     const bool priv = a.nbatch == 1 && priv_ok;

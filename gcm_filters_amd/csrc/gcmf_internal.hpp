@@ -156,6 +156,9 @@ struct gcmf_plan {
   int strip_rows = 0;  // rows per wave strip of that kernel (0 = auto)
   int prefetch_rows = 0;  // rows of operands in flight per wave (0 = default per S)
   int cgrid_tile = 0;     // 1: force the LDS-tile C-grid kernel instead of the streaming one (A/B testing)
+  int cgrid_ring = 1;     // k_cgrid_ring (gcmf_cgrid_ring.hip) for batched f32 levels; env GCMF_CGRID_RING, gcmf_set_option
+  int cgrid_ring_smax = 4;  // levels per launch of that kernel (4 / 5); env GCMF_CGRID_RING_SMAX
+  int cgrid_ring_d = 2;     // operand rows in flight (2 / 3); env GCMF_CGRID_RING_D
   // Land kept out of the state (scalar plans; slab-row layout): bit 0 of lbits[cell] = the cell exchanges with a neighbour.
   // A cell that does not (land under a wet mask; a flux-form cell whose four faces are closed) has L = 0 and evolves
   // on its own: gcmf_apply zeroes such cells in the two states the first blocked launch wrote -- NaN on land then never
@@ -222,6 +225,9 @@ bool bgrid_stream_supported(const gcmf_plan *pl, const StepArgs &a);
 bool multi_supported(const gcmf_plan *pl, int S);
 bool cgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S);
 int launch_cgrid_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s);
+// the static-ring form of the backward C-grid kernel (gcmf_cgrid_ring.hip): batched f32 levels, S = 4, 5
+bool cgrid_ring_supported(const gcmf_plan *pl, int64_t nbatch, int S);
+int launch_cgrid_ring(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s);
 bool bgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S);
 int launch_bgrid_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s);
 inline bool vec_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S) {

@@ -1,0 +1,102 @@
+"""k_cgrid_ring (csrc/gcmf_cgrid_ring.hip): the static-ring, packed-f32 form of the backward C-grid kernel for batched f32 levels
+(BASELINE config 5; reference stencil gcm_filters/kernels.py:630-696 inside the recurrence of filter.py:217-291).  It must give the
+SAME BITS as k_cgrid_stream2c (same operation order per level), which the other C-grid tests pin to the oracle and the reference
+vectors -- with NaN in wet cells (the per-row NaN masks), +-inf (the in-kernel redo with the full nan_to_num), ragged windows and
+strips, batches that do not fill their last workgroup, slabs -- and match the oracle itself."""
+import warnings
+
+import numpy as np
+import pytest
+
+from gcm_filters_amd import Filter, GridType, _lib, testing as T
+from gcm_filters_amd.kernels import ALL_KERNELS
+from oracle import gcmf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(shape, nlev, n_steps, scale=10.0, seed=0):
+    gv = {k: v.astype("f4") for k, v in T.vector_grid_vars("VECTOR_C_GRID", shape).items()}
+    u = np.stack([T.random_field(shape, 42 + 2 * l + seed).astype("f4") for l in range(nlev)])
+    v = np.stack([T.random_field(shape, 43 + 2 * l + seed).astype("f4") for l in range(nlev)])
+    dx = T.grid_dx_min("VECTOR_C_GRID", gv)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        flt = Filter(filter_scale=scale * dx, dx_min=dx, n_steps=n_steps, grid_type=GridType.VECTOR_C_GRID, grid_vars=gv)
+    plan = ALL_KERNELS[GridType.VECTOR_C_GRID](**gv)._plan(_lib.F32, shape)
+    return flt, plan, u, v, gv
+
+
+def _both(flt, plan, u, v, smax=4, d=2, strip_rows=0):
+    try:
+        plan.set_option("cgrid_ring", 0)
+        plan.last_kernel()
+        ref = flt.apply_to_vector(u, v)
+        assert "k_cgrid_stream2c<" in plan.last_kernel()
+        plan.set_option("cgrid_ring", 1)
+        plan.set_option("cgrid_ring_smax", smax)
+        plan.set_option("cgrid_ring_d", d)
+        if strip_rows:
+            plan.set_tuning(multi_s=8, strip_rows=strip_rows)
+        got = flt.apply_to_vector(u, v)
+        assert "k_cgrid_ring<" in plan.last_kernel(), plan.last_kernel()
+    finally:
+        plan.set_option("cgrid_ring", 1)
+        plan.set_option("cgrid_ring_smax", 4)
+        plan.set_option("cgrid_ring_d", 2)
+        plan.set_tuning(multi_s=8, strip_rows=0)
+    return ref, got
+
+
+@pytest.mark.parametrize("shape,nlev", [((96, 160), 8), ((64, 256), 12), ((33, 132), 2), ((120, 124), 5), ((48, 64), 50), ((25, 520), 4),
+                                        ((7, 8), 3)])
+@pytest.mark.parametrize("n_steps", [8, 13, 44])
+@pytest.mark.parametrize("smax,d", [(4, 2), (5, 2), (4, 3)])
+def test_same_bits_as_stream2c(shape, nlev, n_steps, smax, d):
+    flt, plan, u, v, gv = _case(shape, nlev, n_steps)
+    u[nlev // 2, 5 % shape[0], 7 % shape[1]] = np.nan     # NaN in wet cells: the stencil sees 0, the cell keeps its NaN
+    v[0, shape[0] - 1, shape[1] - 1] = np.nan
+    v[nlev - 1, 0, 0] = np.nan
+    ref, got = _both(flt, plan, u, v, smax, d)
+    for r, g in zip(ref, got):
+        assert g.dtype == np.float64
+        assert np.array_equal(r, g, equal_nan=True), (shape, nlev, n_steps, np.nanmax(np.abs(r - g)))
+    assert np.isnan(got[0][nlev // 2, 5 % shape[0], 7 % shape[1]])
+
+
+@pytest.mark.parametrize("shape,nlev,n_steps", [((96, 160), 8, 13), ((40, 300), 5, 9)])
+def test_inf_takes_the_redo_pass(shape, nlev, n_steps):
+    """+-inf in a wet cell: nan_to_num clamps it to +-FLT_MAX in the stencil (kernels.py:651-652); the workgroups that meet one redo
+    their strip with the full nan_to_num at every level and give what k_cgrid_stream2c gives."""
+    flt, plan, u, v, gv = _case(shape, nlev, n_steps)
+    u[1, 20, 33] = np.inf
+    v[nlev - 1, 3, 150 % shape[1]] = -np.inf
+    u[0, 9, 9] = np.nan
+    with np.errstate(all="ignore"):
+        ref, got = _both(flt, plan, u, v)
+    for r, g in zip(ref, got):
+        assert np.array_equal(r, g, equal_nan=True)
+
+
+@pytest.mark.parametrize("strip_rows", [16, 20, 31])
+def test_same_bits_however_the_strips_are_cut(strip_rows):
+    flt, plan, u, v, gv = _case((150, 260), 6, 21)
+    ref, got = _both(flt, plan, u, v, 5, 2, strip_rows)
+    for r, g in zip(ref, got):
+        assert np.array_equal(r, g, equal_nan=True)
+
+
+def test_against_the_oracle():
+    shape, nlev, n_steps = (96, 160), 9, 44
+    flt, plan, u, v, gv = _case(shape, nlev, n_steps)
+    u[3, 50, 70] = np.nan
+    fs = flt.filter_spec
+    with np.errstate(all="ignore"):
+        wu, wv = O.filter_func_vec(O.FilterSpec(fs.n_steps, fs.s_max, np.asarray(fs.p), fs.dx_min_sq), "VECTOR_C_GRID",
+                                   u.astype("f8"), v.astype("f8"), {k: x.astype("f8") for k, x in gv.items()})
+    plan.last_kernel()
+    gu, gw = flt.apply_to_vector(u, v)
+    assert "k_cgrid_ring<" in plan.last_kernel()
+    for g, w in ((gu, wu), (gw, wv)):
+        assert np.array_equal(np.isnan(g), np.isnan(w))
+        assert np.nanmax(np.abs(g - w)) <= 1e-5 * np.nanmax(np.abs(w))   # (f32 state: SURVEY 8d's gate is 1e-4)
