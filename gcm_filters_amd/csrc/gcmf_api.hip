@@ -521,6 +521,7 @@ int gcmf_set_option(gcmf_plan *pl, const char *name, int value) {
   if (n == "cgrid_ring") pl->cgrid_ring = value;
   else if (n == "cgrid_ring_smax") pl->cgrid_ring_smax = value;
   else if (n == "cgrid_ring_d") pl->cgrid_ring_d = value;
+  else if (n == "cgrid_ring_hmax") pl->cgrid_ring_hmax = value;
   else {
     set_error("gcmf_set_option: unknown option '%s'", name);
     return GCMF_ERR_INVALID_ARG;
@@ -957,7 +958,7 @@ int gcmf_slab_apply_backward_vec(gcmf_plan *pl, gcmf_comm *comm, gcmf_p2p *p2p, 
     if ((rc = exchange(st, 2))) return rc;
   }
   const void *u[2] = {X[0], X[1]}, *v[2] = {nullptr, nullptr};
-  const int smax = std::min(pl->multi_s, cgrid_ring_supported(pl, nbatch, 5) ? 5 : 4);   // (as gcmf_apply cuts them)
+  const int smax = std::min(std::min(pl->multi_s, std::max(4, cgrid_ring_smax(pl, nbatch))), multi ? std::max(4, halo) : 8);   // (as gcmf_apply cuts them; never deeper than the ghost zone)
   int valid = hs, lvl = 1;
   while (lvl <= n_steps) {
     const int left = n_steps - lvl + 1;
@@ -1107,6 +1108,11 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
     // and the coefficients live in registers / LDS, nothing but the result goes back to memory.  Same bits as the launches below.
     bool resident = false;
     if (n_clen > 0 && nbatch == 1 && !(flags & GCMF_NO_RESIDENT)) {
+      if (resident_take_failure(pl->d.device)) {   // (told once; from here on this process runs the strip-marching launches: same bits)
+        set_error("k_resident: an earlier on-chip launch of this process timed out waiting for a neighbour tile and gave NaN (another "
+                  "process running resident kernels on this GPU outside the lock file's reach?); the strip-marching launches are used from now on");
+        return GCMF_ERR_HIP;
+      }
       resident = resident_supported(pl, 0, rows, std::min(n_steps, 64), n_steps);   // (small whole grids; GCMF_RESIDENT=1: whatever fits)
     }
     if (resident) {
@@ -1241,7 +1247,7 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
       // four levels per launch with two operand rows in flight: 353-357 G on config 5; five levels leave one row in flight and
       // spill (305-310 G); the forward kernel at its best (five levels) 280 G
       // (round 5: k_cgrid_ring, gcmf_cgrid_ring.hip, takes batched f32 levels four or five at a time)
-      const int smax = std::min(pl->multi_s, cgrid_ring_supported(pl, nbatch, 5) ? 5 : 4);
+      const int smax = std::min(pl->multi_s, std::max(4, cgrid_ring_smax(pl, nbatch)));
       int lvl = 1;
       while (lvl <= n_steps) {
         const int left = n_steps - lvl + 1;
@@ -1367,6 +1373,11 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
     for (int k = 0; k < nc; ++k)
       GCMF_HIP(hipMemcpyAsync(out[k], dout[k], ncell * fbs, hipMemcpyDeviceToHost, s));
     GCMF_HIP(hipStreamSynchronize(s));
+    if (resident_take_failure(pl->d.device)) {   // (the synchronising host path can tell for THIS call)
+      set_error("k_resident: the on-chip launch timed out waiting for a neighbour tile: the result is NaN (another process running "
+                "resident kernels on this GPU?); the strip-marching launches are used from now on");
+      return GCMF_ERR_HIP;
+    }
   }
   if (timing) {
     GCMF_HIP(hipEventSynchronize(pl->ev1));

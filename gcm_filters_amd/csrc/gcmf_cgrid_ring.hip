@@ -58,12 +58,27 @@ template <typename T> __device__ __forceinline__ T cr_san(T x) {  // numpy.nan_t
 
 constexpr int CR_U = 12;  // unroll factor of the row loop = common period of all rings
 
-template <int S> struct CRingGeom {
-  static constexpr int M = (S + 1) / 2 * 2;      // level j is stale j cells per side; windows start on an even column
+// DMA = the operand rows come in through LDS-direct loads (global_load_lds_dwordx4, gfx950): 16 bytes per lane -- the access width the
+// memory pipeline likes (8-byte accesses of this pattern stream at ~4.4 TB/s, experiments/cgrid_probe) -- and no registers in flight.
+template <int S, int D, bool DMA> struct CRingGeom {
+  static constexpr int M = DMA ? (S <= 4 ? 4 : 8) : (S + 1) / 2 * 2;   // level j is stale j cells per side; DMA: windows start on a multiple of 4
   static constexpr int W = 128, WI = W - 2 * M;
-  static constexpr int NS = (S <= 5) ? 6 : 12;   // LDS slots (>= S + 1, divides the period)
-  static constexpr size_t lds_bytes(size_t elem) { return (size_t)NS * 16 * 64 * 2 * elem; }
+  // LDS slots of the coefficient ring.  Plain loads: S + 1 (the rows in flight are in registers), a divisor of the period.  DMA: the rows in
+  // flight occupy slots too: S + D, any number (the slot of a row is a scalar that travels with the row).
+  static constexpr int NS = DMA ? S + D : ((S <= 5) ? 6 : 12);
+  static constexpr unsigned SLOTB = (DMA ? 14u : 16u) * 512u;          // bytes per slot (f32: 128 cells x 4 bytes per plane)
+  static constexpr unsigned DUMMY_OFF = NS * SLOTB;                    // DMA: where the fourth wave's padding planes land
+  static constexpr unsigned STG_OFF = DUMMY_OFF + 1024u;               // DMA: the waves' staging slots: D per wave x (u0|v0, up|vp, fu|fv)
+  static constexpr unsigned STGB = 3072u;
+  static constexpr size_t lds_bytes() { return DMA ? (size_t)STG_OFF + 4u * D * STGB : (size_t)NS * SLOTB; }
 };
+
+#pragma clang diagnostic ignored "-Winline-asm"   // (M0 on the clobber list: the compiler has no use of its own for it in these kernels)
+// one LDS-direct load: every lane fetches 16 bytes from its global address, lane l's land at (LDS address in M0) + 16 l
+__device__ __forceinline__ void cr_dma16(const void *gptr, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_addr) : "memory", "m0");
+}
+template <int N> __device__ __forceinline__ void cr_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // The row cursor of a march (scalar registers): issue after issue it walks the rows r_begin, r_begin + 1, ... of the strip (periodic or
 // clamped at the slab's edges), stops at the last delivered row (the padded iterations of the last ring period re-load it), and gives
@@ -102,13 +117,40 @@ struct CRingCursor {
 
 // A helper wave (a level that pads the last workgroup of a tile): fetches and publishes its share of the coefficient rows, keeps the
 // barriers, computes nothing.
-template <typename T, int S, int D>
+template <typename T, int S, int D, bool DMA>
 __device__ __forceinline__ void cgring_helper(const CRingP<T> &P, unsigned char *s_raw, const int lane, const int wv, const unsigned colB,
-                                              const int r_begin, const int r_end, const int n_pad) {
+                                              const int pos0, const int r_begin, const int r_end, const int n_pad) {
   typedef typename CgV2<T>::type v2;
-  constexpr int NS = CRingGeom<S>::NS, RSH = D + 1;
+  typedef CRingGeom<S, D, DMA> G;
+  constexpr int NS = G::NS, RSH = D + 1;
   typedef v2 Slot[16][64];
   Slot *s_coef = reinterpret_cast<Slot *>(s_raw);
+  CRingCursor cur(P.nx, P.rows, P.wrap, r_begin, r_end, (unsigned)sizeof(T));
+  if constexpr (DMA) {
+    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)s_raw);
+    const int half = lane >> 5;
+    int c4 = (pos0 + 4 * (lane & 31)) % P.nx;
+    if (c4 < 0) c4 += P.nx;
+    const int pa0 = 4 * wv + half, pa1 = 4 * wv + 2 + half;
+    const char *q_c0 = reinterpret_cast<const char *>(P.coef[pa0 < 14 ? pa0 : 0]) + (unsigned)c4 * 4u;
+    const char *q_c1 = reinterpret_cast<const char *>(P.coef[pa1 < 14 ? pa1 : 0]) + (unsigned)c4 * 4u;
+    const bool a0 = pa0 < 7 || pa0 >= 14, a1 = pa1 < 7 || pa1 >= 14;
+    unsigned nxt = 0;
+    auto issue = [&]() {
+      cur.advance();
+      cr_dma16(q_c0 + (a0 ? cur.ro : cur.rc), lds0 + nxt + (unsigned)(4 * wv) * 512u);
+      cr_dma16(q_c1 + (a1 ? cur.ro : cur.rc), wv == 3 ? lds0 + G::DUMMY_OFF : lds0 + nxt + (unsigned)(4 * wv + 2) * 512u);
+      nxt = (nxt + G::SLOTB == NS * G::SLOTB) ? 0u : nxt + G::SLOTB;
+    };
+#pragma unroll
+    for (int q = 0; q < D; ++q) issue();
+    for (int r = r_begin; r < r_begin + n_pad; ++r) {
+      cr_wait_vm<2 * (D - 1)>();
+      __syncthreads();
+      issue();
+    }
+    cr_wait_vm<0>();
+  } else {
   const T *cp[4];
   bool isA[4];
 #pragma unroll
@@ -118,7 +160,6 @@ __device__ __forceinline__ void cgring_helper(const CRingP<T> &P, unsigned char 
     isA[q] = pidx < 7 || pidx >= 14;
   }
   v2 SH[RSH][4];
-  CRingCursor cur(P.nx, P.rows, P.wrap, r_begin, r_end, (unsigned)sizeof(T));
   auto issue = [&](auto ph_c) {
     constexpr int ph = decltype(ph_c)::value;
     cur.advance();
@@ -141,16 +182,19 @@ __device__ __forceinline__ void cgring_helper(const CRingP<T> &P, unsigned char 
     phase(cic<0>{});  phase(cic<1>{});  phase(cic<2>{});  phase(cic<3>{});  phase(cic<4>{});  phase(cic<5>{});
     phase(cic<6>{});  phase(cic<7>{});  phase(cic<8>{});  phase(cic<9>{});  phase(cic<10>{});  phase(cic<11>{});
   }
+  }
 }
 
 // One march of a strip by one wave (one level of the batch).  Returns whether a +-inf was delivered (wave-uniform); SAN = the redo pass.
-template <typename T, int S, int D, bool FIRST, bool SAN>
+template <typename T, int S, int D, bool FIRST, bool SAN, bool DMA>
 __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *s_raw, const int lane, const int wv, const long long boff,
-                                             const unsigned colB, const bool keep, const int a, const int b, const int n_pad) {
+                                             const unsigned colB, const int pos0, const bool keep, const int a, const int b, const int n_pad) {
   typedef typename CgV2<T>::type v2;
-  constexpr int NS = CRingGeom<S>::NS;
-  constexpr int U = CR_U, RU = 6, RV = D + 1, RF = 12, RSH = D + 1;
-  static_assert(D >= 1 && D <= 3 && S >= 2 && S + D <= RF && S < NS && U % NS == 0 && U % RV == 0, "ring periods");
+  typedef CRingGeom<S, D, DMA> G;
+  constexpr int NS = G::NS;
+  constexpr int U = CR_U, RU = 6, RV = DMA ? 1 : D + 1, RF = 12, RSH = D + 1;
+  static_assert(D >= 1 && D <= 3 && S >= 2 && S + D <= RF && S < NS && (DMA || (U % NS == 0 && U % RV == 0)) && U % D == 0, "ring periods");
+  static_assert(!DMA || sizeof(T) == 4, "LDS-direct loads: f32 state");
   typedef v2 Slot[16][64];
   Slot *s_coef = reinterpret_cast<Slot *>(s_raw);
   const int nx = P.nx, rows = P.rows;
@@ -216,13 +260,45 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
     for (int q = 0; q < 4; ++q) SH[ph % RSH][q] = ld2(cp[q], isA[q] ? vo : vc);
   };
 
+  // ---- DMA: per-lane global pointers (lanes 0..31 fetch the first plane of a pair, four cells each, lanes 32..63 the second) ----
+  unsigned slot_of[U];   // DMA: byte offset of the coefficient slot a row's planes went to; slot = (row - r_begin) mod U
+#pragma unroll
+  for (int l = 0; l < U; ++l) slot_of[l] = 0u;
+  unsigned nxt_slot = 0u;
+  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)s_raw);
+  const int half = lane >> 5;
+  int c4 = (pos0 + 4 * (lane & 31)) % nx;
+  if (c4 < 0) c4 += nx;
+  const unsigned c4B = (unsigned)c4 * 4u;
+  const char *q_g0 = reinterpret_cast<const char *>(half ? pv0 : pu0) + c4B;
+  const char *q_vp = reinterpret_cast<const char *>(half ? pvp : pup) + c4B;
+  const char *q_ff = reinterpret_cast<const char *>(half ? pfv : pfu) + c4B;
+  const int pa0 = 4 * wv + half, pa1 = 4 * wv + 2 + half;
+  const char *q_c0 = reinterpret_cast<const char *>(P.coef[pa0 < 14 ? pa0 : 0]) + c4B;
+  const char *q_c1 = reinterpret_cast<const char *>(P.coef[pa1 < 14 ? pa1 : 0]) + c4B;
+  const bool a0 = pa0 < 7 || pa0 >= 14, a1 = pa1 < 7 || pa1 >= 14;
+  const unsigned stg0 = G::STG_OFF + (unsigned)(wv * D) * G::STGB;   // this wave's staging slots
+  auto issue_dma = [&](auto ph_c) {  // the LDS-direct loads of the next iteration: its coefficient slot, this wave's staging slot
+    constexpr int ph = decltype(ph_c)::value;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the staging slot about to be refilled has been read out)
+    cur.advance();
+    slot_of[ph] = nxt_slot;
+    cr_dma16(q_c0 + (a0 ? cur.ro : cur.rc), lds0 + nxt_slot + (unsigned)(4 * wv) * 512u);
+    cr_dma16(q_c1 + (a1 ? cur.ro : cur.rc), wv == 3 ? lds0 + G::DUMMY_OFF : lds0 + nxt_slot + (unsigned)(4 * wv + 2) * 512u);
+    nxt_slot = (nxt_slot + G::SLOTB == NS * G::SLOTB) ? 0u : nxt_slot + G::SLOTB;
+    const unsigned st = lds0 + stg0 + (unsigned)(ph % D) * G::STGB;
+    cr_dma16(q_g0 + cur.ro, st);
+    if constexpr (!FIRST) cr_dma16(q_vp + cur.rc, st + 1024u);
+    cr_dma16(q_ff + cur.rc, st + 2048u);
+  };
+
   v2 out_u = Z, out_v = Z, out_pu = Z, out_pv = Z;
 
   // level j of iteration r (phase ph): fed with row rho = r - j + 1 of level j - 1, produces row rho - 1 of level j
   auto level = [&](auto jj, auto ph_c) {
     constexpr int j = decltype(jj)::value;
     constexpr int ph = decltype(ph_c)::value;
-    constexpr int sl = cmod(ph - (j - 1), NS);      // the LDS slot published in iteration r - j + 1
+    constexpr int sl = DMA ? 0 : cmod(ph - (j - 1), NS);      // the LDS slot published in iteration r - j + 1
     constexpr int kn = cmod(ph - (j - 1), U);       // NaN masks of row rho
     constexpr int n3 = ph % 3, o3 = cmod(ph - 1, 3), p3 = cmod(ph - 2, 3);
     const v2 inu = (j == 1) ? G0u[ph % RU] : Xu[j >= 2 ? j - 1 : 1][n3];
@@ -241,10 +317,19 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
       sv.x = Kv0[kn] ? inv.x : T(0);  sv.y = Kv1[kn] ? inv.y : T(0);
     }
     v2 A[7], B[7];
+    if constexpr (DMA) {
+      const v2 *cs = reinterpret_cast<const v2 *>(s_raw + slot_of[cmod(ph - (j - 1), U)]);
 #pragma unroll
-    for (int q = 0; q < 7; ++q) {
-      A[q] = s_coef[sl][q][lane];
-      B[q] = s_coef[sl][7 + q][lane];
+      for (int q = 0; q < 7; ++q) {
+        A[q] = cs[q * 64 + lane];
+        B[q] = cs[(7 + q) * 64 + lane];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        A[q] = s_coef[sl][q][lane];
+        B[q] = s_coef[sl][7 + q][lane];
+      }
     }
     constexpr int lo = cmod(ph - 1, 2), ln = ph % 2;
     // ---- CgLevel::feed<true> on the pair (gcmf_cgrid_stream2.hip) ----
@@ -282,11 +367,27 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
 
   auto phase = [&](auto ph_c, int r) {
     constexpr int ph = decltype(ph_c)::value;
-    issue(cic<(ph + D) % U>{});
-    // ---- hand this iteration's coefficient rows round ----
+    if constexpr (DMA) {
+      // this iteration's rows were asked for D iterations ago; the loads of the D - 1 iterations in between may still be in flight
+      cr_wait_vm<(FIRST ? 4 : 5) * (D - 1)>();
+      __syncthreads();   // ... and the other waves' quarters of the coefficient slot are there too
+      const unsigned char *st = s_raw + stg0 + (unsigned)(ph % D) * G::STGB;
+      G0u[ph % RU] = reinterpret_cast<const v2 *>(st)[lane];
+      G0v[ph % RU] = reinterpret_cast<const v2 *>(st + 512)[lane];
+      if constexpr (!FIRST) {
+        Vu[0] = reinterpret_cast<const v2 *>(st + 1024)[lane];
+        Vv[0] = reinterpret_cast<const v2 *>(st + 1536)[lane];
+      }
+      Fu[ph % RF] = reinterpret_cast<const v2 *>(st + 2048)[lane];
+      Fv[ph % RF] = reinterpret_cast<const v2 *>(st + 2560)[lane];
+      issue_dma(cic<(ph + D) % U>{});
+    } else {
+      issue(cic<(ph + D) % U>{});
+      // ---- hand this iteration's coefficient rows round ----
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s_coef[ph % NS][wv + 4 * q][lane] = SH[ph % RSH][q];
-    __syncthreads();
+      for (int q = 0; q < 4; ++q) s_coef[ph % NS][wv + 4 * q][lane] = SH[ph % RSH][q];
+      __syncthreads();
+    }
     // ---- the delivered row of b_{k+1}: b_n = p_n f in a first launch; its NaN cells; +-inf watched ----
     {
       v2 gu = G0u[ph % RU], gv = G0v[ph % RU];
@@ -341,26 +442,36 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
     }
   };
 
-  issue(cic<0>{});
-  if constexpr (D >= 2) issue(cic<1>{});
-  if constexpr (D >= 3) issue(cic<2>{});
+  if constexpr (DMA) {
+    issue_dma(cic<0>{});
+    if constexpr (D >= 2) issue_dma(cic<1>{});
+    if constexpr (D >= 3) issue_dma(cic<2>{});
+  } else {
+    issue(cic<0>{});
+    if constexpr (D >= 2) issue(cic<1>{});
+    if constexpr (D >= 3) issue(cic<2>{});
+  }
   for (int r = r_begin; r < r_begin + n_pad; r += U) {
     phase(cic<0>{}, r);  phase(cic<1>{}, r + 1);  phase(cic<2>{}, r + 2);  phase(cic<3>{}, r + 3);
     phase(cic<4>{}, r + 4);  phase(cic<5>{}, r + 5);  phase(cic<6>{}, r + 6);  phase(cic<7>{}, r + 7);
     phase(cic<8>{}, r + 8);  phase(cic<9>{}, r + 9);  phase(cic<10>{}, r + 10);  phase(cic<11>{}, r + 11);
   }
+  if constexpr (DMA) cr_wait_vm<0>();   // (nothing of this march may land in LDS after a redo pass -- or the next workgroup -- has taken it over)
   return __any(seen_inf);
 }
 
-template <typename T, int S, int D, bool FIRST, int WPS>
+template <typename T, int S, int D, bool FIRST, int WPS, bool DMA>
 __global__ __launch_bounds__(256, WPS) void k_cgrid_ring(const CRingP<T> P) {
-  constexpr int M = CRingGeom<S>::M, W = CRingGeom<S>::W, WI = CRingGeom<S>::WI;
+  typedef CRingGeom<S, D, DMA> G;
+  constexpr int M = G::M, W = G::W, WI = G::WI;
   extern __shared__ __align__(16) unsigned char s_raw[];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // workgroups are dealt to the 8 XCDs round-robin: the 13 workgroups (50 levels) of a group follow each other on ONE XCD, so that the
   // coefficient rows the first of them fetched are found in that XCD's L2 by the others (as k_cgrid_stream2)
   const int blk = blockIdx.x;
   const int xcd = blk & 7, slot = (blk >> 3) * 4 + wv;
+  // (round 5 measured the other order too -- every XCD a CONTIGUOUS range of groups, so that neighbouring windows share an L2: 4.97 ms per
+  // five-level launch against 4.49 ms; with the groups dealt round-robin all eight XCDs work in the same rows of every plane at a time)
   const int group = (slot / P.nlev4) * 8 + xcd;
   int lev = slot % P.nlev4;
   if (group >= P.ngroups) return;  // whole workgroups leave together
@@ -371,28 +482,29 @@ __global__ __launch_bounds__(256, WPS) void k_cgrid_ring(const CRingP<T> P) {
   const int a = P.out_lo + st * P.H;
   const int b = min(a + P.H, P.out_hi);
   const long long boff = (long long)lev * P.bstride;
-  const int pos = wx * WI - M + lane * 2;
+  const int pos0 = wx * WI - M;
+  const int pos = pos0 + lane * 2;
   int col = pos % nx;
   if (col < 0) col += nx;
   const unsigned colB = (unsigned)col * (unsigned)sizeof(T);
   const bool keep = (lane * 2 >= M) && (lane * 2 < W - M) && (pos < nx);
   const int n_pad = ((b - a) + 2 * S + CR_U - 1) / CR_U * CR_U;   // the march is padded to whole ring periods
   bool bad = false;
-  if (shadow) cgring_helper<T, S, D>(P, s_raw, lane, wv, colB, a - S, b + S, n_pad);
-  else bad = cgring_march<T, S, D, FIRST, false>(P, s_raw, lane, wv, boff, colB, keep, a, b, n_pad);
+  if (shadow) cgring_helper<T, S, D, DMA>(P, s_raw, lane, wv, colB, pos0, a - S, b + S, n_pad);
+  else bad = cgring_march<T, S, D, FIRST, false, DMA>(P, s_raw, lane, wv, boff, colB, pos0, keep, a, b, n_pad);
   if (__syncthreads_or(bad ? 1 : 0)) {   // a +-inf somewhere in the workgroup's rows: the strip again, nan_to_num in full at every level
     if (threadIdx.x == 0 && P.redo) atomicAdd(P.redo, 1u);
-    if (shadow) cgring_helper<T, S, D>(P, s_raw, lane, wv, colB, a - S, b + S, n_pad);
-    else cgring_march<T, S, D, FIRST, true>(P, s_raw, lane, wv, boff, colB, keep, a, b, n_pad);
+    if (shadow) cgring_helper<T, S, D, DMA>(P, s_raw, lane, wv, colB, pos0, a - S, b + S, n_pad);
+    else cgring_march<T, S, D, FIRST, true, DMA>(P, s_raw, lane, wv, boff, colB, pos0, keep, a, b, n_pad);
   }
 }
 
 static bool cr_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 bool cgrid_ring_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
-  if (!pl->cgrid_ring || pl->kind != K_CGRID || pl->cgrid_tile || pl->d.dtype != GCMF_F32) return false;
+  if (pl->cgrid_ring <= 0 || pl->kind != K_CGRID || pl->cgrid_tile || pl->d.dtype != GCMF_F32) return false;
   if (nbatch < 2) return false;   // single-level fields: k_cgrid_stream2c's private-ring form
-  if (S < 4 || S > 5 || S > pl->cgrid_ring_smax) return false;
+  if (S < 4 || S > 8 || S > pl->cgrid_ring_smax) return false;
   if (pl->g.nx % 2 || pl->g.nx < 2 || pl->g.rows < S + 2) return false;
   if ((long long)pl->g.rows * pl->g.nx * 4 >= (1LL << 32)) return false;   // 32-bit byte offsets inside a level's plane
   for (int k = 0; k < MAX_COEF; ++k)
@@ -400,8 +512,8 @@ bool cgrid_ring_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
   return true;
 }
 
-template <typename T, int S, int D, int WPS> static int launch_cr(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
-  constexpr int WI = CRingGeom<S>::WI;
+template <typename T, int S, int D, int WPS, bool DMA> static int launch_cr(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
+  constexpr int WI = CRingGeom<S, D, DMA>::WI;
   const Geom &g = pl->g;
   CRingP<T> P;
   P.u0 = (const T *)a.u0[0];  P.v0 = (const T *)a.u0[1];
@@ -436,7 +548,7 @@ template <typename T, int S, int D, int WPS> static int launch_cr(gcmf_plan *pl,
     // rounds of the resident waves: the fewest strips of <= 96 rows fix the number of rounds, then the strip count grows to fill the
     // last round; then H + 2 S is brought up to a whole number of periods
     const long long cap = 1024LL * WPS;
-    const long long per_strip = (long long)P.nwx * P.nlev4, hmax = 96;
+    const long long per_strip = (long long)P.nwx * P.nlev4, hmax = pl->cgrid_ring_hmax > 0 ? pl->cgrid_ring_hmax : 96;
     const long long ns_min = (nrows + hmax - 1) / hmax;
     const long long rounds = (ns_min * per_strip + cap - 1) / cap;
     long long ns = rounds * cap / per_strip;
@@ -453,12 +565,12 @@ template <typename T, int S, int D, int WPS> static int launch_cr(gcmf_plan *pl,
   P.last = a.last;
   P.bstride = (long long)g.rows * g.nx;
   P.pn = a.p0;
-  for (int t = 0; t < 8; ++t) P.pk[t] = t < 6 ? a.pk[t] : 0.0;
+  for (int t = 0; t < 8; ++t) P.pk[t] = a.pk[t];
   P.c = a.c;
   const long long groups_per_xcd = (P.ngroups + 7) / 8;
   const long long blocks_per_xcd = (groups_per_xcd * P.nlev4 + 3) / 4;
   dim3 block(256), grid((unsigned)(blocks_per_xcd * 8));
-  const size_t lds = CRingGeom<S>::lds_bytes(sizeof(T));
+  const size_t lds = CRingGeom<S, D, DMA>::lds_bytes();
   auto go = [&](auto kern, bool &attr_set) -> int {
     if (!attr_set && lds > 48 * 1024) {
       GCMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -468,20 +580,37 @@ template <typename T, int S, int D, int WPS> static int launch_cr(gcmf_plan *pl,
     return GCMF_OK;
   };
   static bool set_first = false, set_next = false;  // per instantiation
-  int rc = a.first ? go(&k_cgrid_ring<T, S, D, true, WPS>, set_first) : go(&k_cgrid_ring<T, S, D, false, WPS>, set_next);
+  int rc = a.first ? go(&k_cgrid_ring<T, S, D, true, WPS, DMA>, set_first) : go(&k_cgrid_ring<T, S, D, false, WPS, DMA>, set_next);
   if (rc) return rc;
   note_kernel(pl, std::string("gcmf::k_cgrid_ring<") + tyname<T>() + ", " + std::to_string(S) + ", " + std::to_string(D) + ", " +
-                      (a.first ? "true" : "false") + ", " + std::to_string(WPS) + ">", S,
+                      (a.first ? "true" : "false") + ", " + std::to_string(WPS) + ", " + (DMA ? "true" : "false") + ">", S,
               launch_geom(P.H, (nrows + H - 1) / H, P.nwx, 1, grid.x, grid.y, nrows));
   GCMF_HIP(hipGetLastError());
   return GCMF_OK;
 }
 
+int cgrid_ring_smax(const gcmf_plan *pl, int64_t nbatch) {
+  for (int S = 8; S >= 4; --S)
+    if (cgrid_ring_supported(pl, nbatch, S)) return S;
+  return 0;
+}
+
 int launch_cgrid_ring(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
   const int d = pl->cgrid_ring_d;
+  // LDS-direct loads (cgrid_ring = 2): windows start on multiples of four cells, so nx has to be one
+  if (pl->cgrid_ring >= 2 && pl->g.nx % 4 == 0 && a.S <= 5) {
+    switch (a.S) {
+      case 4: return d == 3 ? launch_cr<float, 4, 3, 2, true>(pl, a, s) : launch_cr<float, 4, 2, 2, true>(pl, a, s);
+      case 5: return d == 3 ? launch_cr<float, 5, 3, 2, true>(pl, a, s) : launch_cr<float, 5, 2, 2, true>(pl, a, s);
+    }
+  }
   switch (a.S) {
-    case 4: return d == 3 ? launch_cr<float, 4, 3, 2>(pl, a, s) : launch_cr<float, 4, 2, 2>(pl, a, s);
-    case 5: return d == 3 ? launch_cr<float, 5, 3, 2>(pl, a, s) : launch_cr<float, 5, 2, 2>(pl, a, s);
+    case 4: return d == 3 ? launch_cr<float, 4, 3, 2, false>(pl, a, s) : launch_cr<float, 4, 2, 2, false>(pl, a, s);
+    case 5: return d == 3 ? launch_cr<float, 5, 3, 2, false>(pl, a, s) : launch_cr<float, 5, 2, 2, false>(pl, a, s);
+    // six levels and more: one wave per SIMD (the rings spill over into the accumulation registers), three rows in flight
+    case 6: return d == 2 ? launch_cr<float, 6, 2, 1, false>(pl, a, s) : launch_cr<float, 6, 3, 1, false>(pl, a, s);
+    case 7: return d == 2 ? launch_cr<float, 7, 2, 1, false>(pl, a, s) : launch_cr<float, 7, 3, 1, false>(pl, a, s);
+    case 8: return d == 2 ? launch_cr<float, 8, 2, 1, false>(pl, a, s) : launch_cr<float, 8, 3, 1, false>(pl, a, s);
   }
   return GCMF_ERR_INVALID_ARG;
 }

@@ -405,7 +405,7 @@ bool cgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
   // f32: S = 5 holds 238 VGPRs at two waves per SIMD and measured 282 G against 250 G for S = 4 on the same box
   // (config 5); S = 6 spills (229 G).  f64: S <= 4 (one wave per SIMD from S = 3 on)
   // single-level fields (wave-private LDS rings): S = 5 leaves five waves per CU and measured 90 G against 133 G at S = 4
-  if (S < 2 || S > ((pl->d.dtype == GCMF_F64 || nbatch == 1) ? 4 : 5)) return false;
+  if (S < 2 || (S > ((pl->d.dtype == GCMF_F64 || nbatch == 1) ? 4 : 5) && !cgrid_ring_supported(pl, nbatch, S))) return false;
   const int vec = pl->d.dtype == GCMF_F64 ? 2 : 4;
   if (pl->g.nx % vec || pl->g.nx < vec || pl->g.rows < S + 2) return false;
   // any batch size: the lock-step workgroups of 4 levels are padded with shadow waves that repeat the last level

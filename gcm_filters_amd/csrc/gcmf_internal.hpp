@@ -92,7 +92,7 @@ struct VecMultiArgs {
   void *u2o[2];          // T_{k+S-1} out (must not alias u0 / uprev / u1o)
   const void *fb_in[2];
   void *fb_out[2];
-  double pk[6];          // p[k] .. p[k+S-1]; with `first`: p[1] .. p[S]
+  double pk[8];          // p[k] .. p[k+S-1]; with `first`: p[1] .. p[S]
   double p0, c;
   int S, first, last, fb_is_f32;
   int64_t nbatch;
@@ -156,9 +156,10 @@ struct gcmf_plan {
   int strip_rows = 0;  // rows per wave strip of that kernel (0 = auto)
   int prefetch_rows = 0;  // rows of operands in flight per wave (0 = default per S)
   int cgrid_tile = 0;     // 1: force the LDS-tile C-grid kernel instead of the streaming one (A/B testing)
-  int cgrid_ring = 1;     // k_cgrid_ring (gcmf_cgrid_ring.hip) for batched f32 levels; env GCMF_CGRID_RING, gcmf_set_option
-  int cgrid_ring_smax = 4;  // levels per launch of that kernel (4 / 5); env GCMF_CGRID_RING_SMAX
+  int cgrid_ring = 2;     // k_cgrid_ring (gcmf_cgrid_ring.hip) for batched f32 levels: 0 off, 1 plain loads, 2 LDS-direct loads; env GCMF_CGRID_RING, gcmf_set_option
+  int cgrid_ring_smax = 5;  // levels per launch of that kernel (4 .. 8); env GCMF_CGRID_RING_SMAX
   int cgrid_ring_d = 2;     // operand rows in flight (2 / 3); env GCMF_CGRID_RING_D
+  int cgrid_ring_hmax = 0;  // tallest strip its launcher picks (0 = 96); gcmf_set_option
   // Land kept out of the state (scalar plans; slab-row layout): bit 0 of lbits[cell] = the cell exchanges with a neighbour.
   // A cell that does not (land under a wet mask; a flux-form cell whose four faces are closed) has L = 0 and evolves
   // on its own: gcmf_apply zeroes such cells in the two states the first blocked launch wrote -- NaN on land then never
@@ -218,6 +219,7 @@ bool resident_supported(const gcmf_plan *pl, int row_lo, int row_hi, int L, int 
 bool resident_fits(const gcmf_plan *pl, int row_lo, int row_hi, int L);
 int launch_resident(gcmf_plan *pl, const MultiArgs &a, const double *pk, int L, hipStream_t s);
 void resident_free(gcmf_plan *pl);
+bool resident_take_failure(int dev);   // a resident launch of this process on `dev` timed out since the last call (reported once)
 int launch_cgrid_stream(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 bool cgrid_stream_supported(const gcmf_plan *pl, const StepArgs &a);
 int launch_bgrid_stream(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
@@ -225,8 +227,9 @@ bool bgrid_stream_supported(const gcmf_plan *pl, const StepArgs &a);
 bool multi_supported(const gcmf_plan *pl, int S);
 bool cgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S);
 int launch_cgrid_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s);
-// the static-ring form of the backward C-grid kernel (gcmf_cgrid_ring.hip): batched f32 levels, S = 4, 5
+// the static-ring form of the backward C-grid kernel (gcmf_cgrid_ring.hip): batched f32 levels, S = 4 .. 8
 bool cgrid_ring_supported(const gcmf_plan *pl, int64_t nbatch, int S);
+int cgrid_ring_smax(const gcmf_plan *pl, int64_t nbatch);   // deepest launch it offers this plan / batch (0: none)
 int launch_cgrid_ring(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s);
 bool bgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S);
 int launch_bgrid_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s);

@@ -40,9 +40,16 @@
 #include "gcmf_multi_common.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <string>
+
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace gcmf {
 
@@ -61,7 +68,9 @@ struct ResP {
   const double *area;           // area-weighted types or NULL
   double *ex[2][2];        // exchange planes [parity][state]
   unsigned *flags;         // one epoch word per tile
-  unsigned *fail;          // sticky failure word (device address of mapped host memory)
+  unsigned *fail;          // failure word (device address of mapped host memory): written on a time-out, read by the host only
+  unsigned *dfail;         // failure word in the uncached arena: the serial number of the launch that timed out (tiles read it)
+  unsigned serial;         // this launch's serial number (never 0)
   unsigned epoch0;
   int nx, rows;            // the plan's slab allocation
   int r_lo, r_hi;          // rows this launch keeps alive (the dependency cone of out_lo .. out_hi)
@@ -409,6 +418,8 @@ __global__ __launch_bounds__(NT, NT / 256) void k_resident(const ResP P) {
         e1[o] = sg[i];
         e2[o] = sg2[i];
       }
+      // a tile of this launch has already timed out (its bands are garbage from then on): no more waiting, every tile poisons its result
+      if (tid == 9 && __hip_atomic_load(P.dfail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.serial) s_fail = 1;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_s_waitcnt(0);                             // every store of this wave has been acknowledged by the memory side
       __syncthreads();
@@ -422,7 +433,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_resident(const ResP P) {
           if (P.wrap) ny_ = ny_ < 0 ? ny_ + P.nty : ny_ - P.nty;
           else there = false;                                      // the region ends here: those halo rows are dead
         }
-        if (there) {
+        if (there && !s_fail) {
           const unsigned *fl_ = &P.flags[ny_ * P.ntx + nx_];
           const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
           for (;;) {
@@ -431,6 +442,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_resident(const ResP P) {
             // (the failure word lives in mapped HOST memory: it is written on a time-out, never polled -- a read of it is a PCIe
             // round trip, and 2048 lanes polling it cost 30 us per exchange in the first version)
             if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > P.spin_limit) {
+              __hip_atomic_store(P.dfail, P.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (before any later band of this tile)
               __hip_atomic_store(P.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
               s_fail = 1;
               break;
@@ -473,7 +485,8 @@ __global__ __launch_bounds__(NT, NT / 256) void k_resident(const ResP P) {
   }
 
   // ---- store: owners put their cells into the staged tiles, consecutive lanes write consecutive cells -------------------------------
-  const bool failed = s_fail != 0;
+  // (a neighbour that timed out wrote the launch's failure word BEFORE it posted the garbage bands this tile may have consumed since)
+  if (tid == 0 && __hip_atomic_load(P.dfail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.serial) s_fail = 1;
   const double poison = __longlong_as_double(-1LL);
   if (active) {
 #pragma unroll
@@ -483,6 +496,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_resident(const ResP P) {
     }
   }
   __syncthreads();
+  const bool failed = s_fail != 0;
 #pragma unroll
   for (int k = 0; k < RC; ++k) {
     const int e = k * RES_NT + tid;
@@ -555,9 +569,21 @@ static ResGeom res_geometry(int kind, int Rr, int nx, int K, int max_wg) {
 struct ResArena {
   char *ex = nullptr;
   size_t ex_bytes = 0;
-  unsigned *flags = nullptr;   // 1024 epoch words
+  unsigned *flags = nullptr;   // 1024 words: one epoch word per tile (<= 256 tiles); word 1000 = the serial number of a launch that timed out
   unsigned *fail_host = nullptr, *fail_dev = nullptr;
   unsigned epoch = 0;
+  unsigned serial = 0;
+  hipEvent_t chain_ev = nullptr;   // end of the last resident launch of this process on the device
+  bool chain_set = false;
+  // Two PROCESSES must not run resident kernels on one GPU at the same time (each would hold CUs the other's missing workgroups wait
+  // for).  A process that wants to run them takes an advisory lock on a file named after the GPU (flock, kept until the process ends:
+  // no cost per call); a process that does not get it runs the strip-marching launches instead -- the same bits -- and asks again later.
+  int lock_fd = -1;
+  bool have_lock = false;
+  std::chrono::steady_clock::time_point last_try{};
+  bool tried = false;
+  bool disabled = false;           // a launch of this process timed out all the same (a process outside the lock's reach): strips from now on
+  bool failure_reported = true;    // the time-out has been handed to a caller as an error
 };
 
 }  // namespace gcmf
@@ -573,9 +599,40 @@ void resident_free(gcmf_plan *pl) { pl->resident = nullptr; }   // (nothing per 
 // without touching the host: every resident launch waits for the previous one's end.  (Two PROCESSES on one GPU cannot be chained; see
 // the header of this file.)  The same lock guards the arena.
 static std::mutex g_chain_mu;
-static hipEvent_t g_chain_ev[16] = {nullptr};
-static bool g_chain_set[16] = {false};
-static ResArena g_arena[16];
+static std::map<int, ResArena> g_arena;   // by device ordinal (a node in CPX mode shows 64 devices)
+
+// (g_chain_mu held)  May this process run resident kernels on `dev` now?
+static bool res_process_allowed(int dev) {
+  ResArena &st = g_arena[dev];
+  if (st.fail_host && __atomic_load_n(st.fail_host, __ATOMIC_ACQUIRE)) {   // a launch timed out since the last look
+    __atomic_store_n(st.fail_host, 0u, __ATOMIC_RELEASE);
+    st.disabled = true;
+    st.failure_reported = false;
+  }
+  if (st.disabled) return false;
+  if (st.have_lock) return true;
+  static const bool lock_on = !(getenv("GCMF_RESIDENT_LOCK") && atoi(getenv("GCMF_RESIDENT_LOCK")) == 0);
+  if (!lock_on) { st.have_lock = true; return true; }
+  const auto now = std::chrono::steady_clock::now();
+  if (st.tried && now - st.last_try < std::chrono::seconds(1)) return false;   // (asked a moment ago)
+  st.tried = true;
+  st.last_try = now;
+  if (st.lock_fd < 0) {
+    char bus[64] = "unknown";
+    if (hipDeviceGetPCIBusId(bus, sizeof bus, dev) != hipSuccess) { (void)hipGetLastError(); snprintf(bus, sizeof bus, "dev%d", dev); }
+    for (char *c = bus; *c; ++c) if (*c == ':' || *c == '/') *c = '_';
+    const char *own = getenv("GCMF_RESIDENT_LOCK_DIR");   // (tests: a lock namespace of their own)
+    const char *dirs[2] = {own && *own ? own : "/dev/shm", "/tmp"};
+    for (int q = 0; q < 2 && st.lock_fd < 0; ++q) {
+      const std::string path = std::string(dirs[q]) + "/gcmf_resident_" + bus + ".lock";
+      st.lock_fd = open(path.c_str(), O_RDWR | O_CREAT | O_CLOEXEC, 0666);
+      if (st.lock_fd >= 0) (void)fchmod(st.lock_fd, 0666);   // (other users' processes share the GPU too)
+    }
+    if (st.lock_fd < 0) { st.have_lock = true; return true; }   // nowhere to put a lock file: as before (bounded waits, loud failure)
+  }
+  if (flock(st.lock_fd, LOCK_EX | LOCK_NB) == 0) st.have_lock = true;
+  return st.have_lock;
+}
 
 template <int KIND, int RC, int NT = 512> static int res_launch(const ResP &P, int nwg, hipStream_t s) {
   const size_t lds = (size_t)((KIND == K_FLUX && RC >= 13) ? 3 : 2) * RC * NT * sizeof(double);
@@ -686,6 +743,25 @@ bool resident_supported(const gcmf_plan *pl, int row_lo, int row_hi, int L, int 
     if (max_cells > 0 ? (long long)pl->g.rows * pl->g.nx > max_cells : !(g.rc == 4 && g.nt == 1024)) return false;
     if (pl->kind != K_FLUX && n_total < 24) return false;
   }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> chain(g_chain_mu);
+  return res_process_allowed(dev);   // (another process of this GPU runs resident kernels: the strip-marching launches, same bits)
+}
+
+// A resident launch of this process on `dev` timed out since the last call (its result is NaN): reported once, to whoever asks first.
+bool resident_take_failure(int dev) {
+  std::lock_guard<std::mutex> chain(g_chain_mu);
+  auto it = g_arena.find(dev);
+  if (it == g_arena.end()) return false;
+  ResArena &st = it->second;
+  if (st.fail_host && __atomic_load_n(st.fail_host, __ATOMIC_ACQUIRE)) {
+    __atomic_store_n(st.fail_host, 0u, __ATOMIC_RELEASE);
+    st.disabled = true;
+    st.failure_reported = false;
+  }
+  if (st.failure_reported) return false;
+  st.failure_reported = true;
   return true;
 }
 
@@ -707,11 +783,15 @@ int launch_resident(gcmf_plan *pl, const MultiArgs &a, const double *pk, int L, 
   }
   int dev = 0;
   GCMF_HIP(hipGetDevice(&dev));
-  const int dq = dev & 15;
   std::lock_guard<std::mutex> chain(g_chain_mu);
-  ResArena *st = &g_arena[dq];
+  if (!res_process_allowed(dev)) {
+    set_error("k_resident: another process runs resident kernels on this GPU (or an earlier resident launch of this process timed out): "
+              "use the strip-marching launches (gcmf_apply does by itself)");
+    return GCMF_ERR_UNSUPPORTED;
+  }
+  ResArena *st = &g_arena[dev];
   const size_t plane = (size_t)pl->g.rows * pl->g.nx * sizeof(double);
-  if (!g_chain_ev[dq]) GCMF_HIP(hipEventCreateWithFlags(&g_chain_ev[dq], hipEventDisableTiming));
+  if (!st->chain_ev) GCMF_HIP(hipEventCreateWithFlags(&st->chain_ev, hipEventDisableTiming));
   if (!st->flags) {
     GCMF_HIP(hipExtMallocWithFlags((void **)&st->flags, 1024 * sizeof(unsigned), hipDeviceMallocUncached));
     GCMF_HIP(hipMemset(st->flags, 0, 1024 * sizeof(unsigned)));
@@ -728,16 +808,11 @@ int launch_resident(gcmf_plan *pl, const MultiArgs &a, const double *pk, int L, 
     st->ex = blk;
     st->ex_bytes = want;
   }
-  if (__atomic_load_n(st->fail_host, __ATOMIC_ACQUIRE)) {
-    set_error("k_resident: an earlier resident launch of this process timed out waiting for a neighbour tile (was another process "
-              "running a resident kernel on this GPU?  set GCMF_RESIDENT=0 there); its results are NaN");
-    return GCMF_ERR_HIP;
-  }
-  if (g_chain_set[dq]) GCMF_HIP(hipStreamWaitEvent(s, g_chain_ev[dq], 0));
+  if (st->chain_set) GCMF_HIP(hipStreamWaitEvent(s, st->chain_ev, 0));
   struct Mark {
     hipEvent_t e; hipStream_t s; bool *set;
     ~Mark() { if (hipEventRecord(e, s) == hipSuccess) *set = true; }
-  } mark{g_chain_ev[dq], s, &g_chain_set[dq]};
+  } mark{st->chain_ev, s, &st->chain_set};
   const Geom &gm = pl->g;
   ResP P{};
   P.u0 = (const double *)a.u0; P.v0 = (const double *)a.v0; P.uo = (double *)a.uo; P.vo = (double *)a.vo;
@@ -750,6 +825,9 @@ int launch_resident(gcmf_plan *pl, const MultiArgs &a, const double *pk, int L, 
     for (int q = 0; q < 2; ++q) P.ex[par][q] = (double *)(st->ex + (size_t)(par * 2 + q) * plane);
   P.flags = st->flags;
   P.fail = st->fail_dev;
+  P.dfail = st->flags + 1000;
+  if (++st->serial == 0) st->serial = 1;
+  P.serial = st->serial;
   P.epoch0 = st->epoch;
   P.nx = gm.nx; P.rows = gm.rows;
   P.r_lo = r_lo; P.r_hi = r_hi; P.out_lo = a.row_lo; P.out_hi = a.row_hi;

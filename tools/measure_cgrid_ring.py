@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--strip", type=int, default=0)
-    ap.add_argument("--variants", default="stream,r4d2,r5d2,r4d3,r5d3")
+    ap.add_argument("--variants", default="stream,r4d2,m4d2,m5d2,m4d3,m5d3")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     wl = T.baseline_workload(5, (a.ny, a.nx), nlev=a.nlev)
@@ -46,10 +46,13 @@ def main():
         if name == "stream":
             plan.set_option("cgrid_ring", 0)
         else:
-            plan.set_option("cgrid_ring", 1)
+            plan.set_option("cgrid_ring", 2 if name[0] == "m" else 1)   # m: operand rows through LDS-direct loads
             plan.set_option("cgrid_ring_smax", int(name[1]))
             plan.set_option("cgrid_ring_d", int(name[3]))
-        plan.set_tuning(multi_s=8, strip_rows=a.strip)
+            # optional suffixes: x0 = groups dealt round-robin to the XCDs instead of contiguous ranges, hNNN = tallest strip
+            import re
+            plan.set_option("cgrid_ring_hmax", int(re.search(r"h(\d+)", name).group(1)) if re.search(r"h(\d+)", name) else 0)
+        plan.set_tuning(multi_s=8, strip_rows=a.strip, xcd_remap=0 if "x0" in name else 1)
 
     ref = None
     results = {}
