@@ -367,8 +367,8 @@ def roofline_of(cfg, r, steps, default_tuning):
     avg_ms = r["dom_ms"] / r["dom_n"]                       # HIP events around each launch of the dominant kernel
     # recurrence steps one launch of that kernel advances: its last (vector kernels: fourth) template argument
     targs = r["kernel"][r["kernel"].index("<") + 1: r["kernel"].rindex(">")].split(", ")
-    backward = any(k in r["kernel"] for k in ("k_ringc<", "k_ringcs<", "k_cgrid_stream2c<"))
-    steps_per_launch = float(targs[1] if "k_ringcs<" in r["kernel"] else      # (the early-exit form of short strips: <T, S, FIRST>)
+    backward = any(k in r["kernel"] for k in ("k_ringc<", "k_ringcs<", "k_cgrid_stream2c<", "k_cgrid_ring<"))
+    steps_per_launch = float(targs[1] if ("k_ringcs<" in r["kernel"] or "k_cgrid_ring<" in r["kernel"]) else   # (<T, S, ...>: the early-exit form of short strips, the static-ring C-grid kernel)
                              targs[2] if backward else
                              targs[3] if any(k in r["kernel"] for k in ("stream2", "k_scalar_multi", "k_ring")) else
                              (targs[-1] if "k_flux_multi2" in r["kernel"] else 1))
@@ -506,6 +506,71 @@ def run_small_onchip(dev, no_cpu):
         got = out.cpu().numpy()
         rec["parity"] = {"rel_err": float(np.abs(got - want).max() / np.abs(want).max()), "tolerance": 1e-6,
                          "checked_against": "oracle, same grid / field / whole polynomial"}
+    return rec
+
+
+def run_host_path(dev, args):
+    """SURVEY 8d "H2D / D2H reported separately": BASELINE config 3 with HOST (numpy) buffers, the reference's default call shape
+    (`filter_func(field, *grid_args)` on host arrays, reference filter.py:181-214) -- PCIe-inclusive, never `value`.  Milliseconds per
+    2400 x 3600 f64 field (69.12 MB): the copies alone (pageable and page-locked), the recurrence alone (field resident in HBM), the
+    three in sequence through gcmf_apply with host pointers (one plan), Filter.apply's row-block pipeline that overlaps them
+    (gcm_filters_amd/host_blocks.py), and a batch of 8 fields streamed through two HBM staging slots."""
+    import torch
+
+    from gcm_filters_amd import Filter, FilterShape, GridType, testing as T
+
+    wl = T.baseline_workload(3, (args.ny, args.nx))
+    fk = wl["fk"]
+    flt = Filter(grid_type=GridType[wl["grid"]], grid_vars=wl["grid_vars"], filter_scale=fk["filter_scale"], dx_min=fk["dx_min"],
+                 filter_shape=FilterShape[fk["filter_shape"]])
+    f = wl["fields"][0]
+    mb = f.nbytes / 1e6
+
+    def best(fn, reps=5, sync=True):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            if sync:
+                torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return 1e3 * min(ts)
+    d = torch.from_numpy(f).to(dev)
+    flt.apply(d)
+    torch.cuda.synchronize()
+    rec = {"what": "config 3 on HOST buffers (numpy in / out), ms per 2400x3600 f64 field; PCIe-inclusive, never `value`", "field_MB": mb}
+    rec["recurrence_ms_field_resident"] = best(lambda: flt.apply(d))
+    hbuf = torch.empty_like(d, device="cpu")
+    rec["h2d_ms_pageable"] = best(lambda: d.copy_(torch.from_numpy(f)))
+    rec["d2h_ms_pageable"] = best(lambda: hbuf.copy_(d))
+    pin = torch.from_numpy(f).pin_memory()
+    rec["h2d_ms_page_locked"] = best(lambda: d.copy_(pin, non_blocking=True))
+    rec["d2h_ms_page_locked"] = best(lambda: pin.copy_(d, non_blocking=True))
+    rec["h2d_GBps_page_locked"] = mb / rec["h2d_ms_page_locked"]
+    before = os.environ.get("GCMF_HOST_BLOCKS")
+    try:
+        os.environ["GCMF_HOST_BLOCKS"] = "0"       # one plan: upload, recurrence, download in sequence (gcmf_apply with host pointers)
+        flt.apply(f)
+        rec["one_plan_in_sequence_ms"] = best(lambda: flt.apply(f), sync=False)
+        os.environ.pop("GCMF_HOST_BLOCKS")
+        for _ in range(4):                         # (the row-block pipeline is built at the third single-field host call on a plan)
+            out = flt.apply(f)
+        rec["row_block_pipeline_ms"] = best(lambda: flt.apply(f), sync=False)
+        want = flt.apply(d).cpu().numpy()
+        rec["row_block_pipeline_same_bits"] = bool(np.array_equal(out, want, equal_nan=True))
+    finally:
+        if before is None:
+            os.environ.pop("GCMF_HOST_BLOCKS", None)
+        else:
+            os.environ["GCMF_HOST_BLOCKS"] = before
+    fb = np.ascontiguousarray(np.broadcast_to(f, (8,) + f.shape))
+    flt.apply(fb)
+    rec["batch_of_8_ms_per_field"] = best(lambda: flt.apply(fb), reps=2, sync=False) / 8
+    n = int(flt.n_steps)
+    rec["n_steps"] = n
+    rec["cells_steps_per_s_host_buffers"] = {"one_plan_in_sequence": f.size * n / (rec["one_plan_in_sequence_ms"] * 1e-3),
+                                             "row_block_pipeline": f.size * n / (rec["row_block_pipeline_ms"] * 1e-3),
+                                             "batch_of_8": f.size * n / (rec["batch_of_8_ms_per_field"] * 1e-3)}
     return rec
 
 
@@ -710,6 +775,24 @@ def main_single(args):
                     failed.append(f"config {cfg} reference probes: rel_err {rec['parity']['rel_err']:.3e}")
             if cfg == 5 and not args.no_cpu:
                 rec["cpu_baseline_pool"] = cpu_baseline_pool(5, args.ny, args.nx, r["nbatch"], 4)
+            if cfg == 5:
+                # The default carries the whole polynomial in f32 (backward evaluation, k_cgrid_ring); the reference sums f32 fields in an f64
+                # running sum (NumPy >= 2 promotion, reference filter.py:192-206).  Filter(evaluation="reference") runs exactly that scheme
+                # (forward recurrence, f64 fbar): measured here so that the like-for-like figure is on record next to the default.
+                r2 = None
+                free_gpu()
+                r2 = run_single(cfg, args, dev, steps=xs, warmup=xw, evaluation="reference")
+                osp = spread_of(r2)
+                opt = {"what": "Filter(evaluation=\"reference\"): forward recurrence, f32 T_k, f64 running sum -- the reference's own precision (NOT the default)",
+                       "kernel": r2["kernel"], "value": osp["value"], "value_min": osp["value_min"], "value_max": osp["value_max"], "unit": "cell-steps/s",
+                       "ms_per_step": osp["ms_per_step"], "roofline": roofline_of(cfg, r2, xs, True)}
+                chk2 = golden_probe_check(cfg, 0.0, (args.ny, args.nx), r2["outs"])
+                if chk2 is not None:
+                    opt["parity"] = dict(finish_probe_check(chk2), tolerance=tol(r2["itemsize"]))
+                    if not opt["parity"]["rel_err"] <= opt["parity"]["tolerance"]:
+                        failed.append(f"config {cfg} forward (reference) evaluation: rel_err {opt['parity']['rel_err']:.3e}")
+                rec["forward_reference_opt_in"] = opt
+                r2 = None
             if cfg == 2:
                 # The default since round 4 evaluates the land-mask (and REGULAR) types backwards too (k_ringc: fused multiply-adds,
                 # one plane less, <= 1e-14 from numpy).  Filter(evaluation="reference") is the escape that stays bit-exact with
@@ -730,6 +813,10 @@ def main_single(args):
             extras.append(rec)
         extras.append(small)
         out["extra_configs"] = extras
+        if args.config == 3 and (args.ny, args.nx) == (2400, 3600):
+            r = None
+            free_gpu()
+            out["host_path"] = run_host_path(dev, args)
     if args.config == 5 and not args.no_cpu:
         out["cpu_baseline_pool"] = cpu_baseline_pool(5, args.ny, args.nx, nbatch_main, 4)
     print(json.dumps(out))

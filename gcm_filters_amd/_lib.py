@@ -438,7 +438,7 @@ class Plan:
 
 
     def set_option(self, name: str, value: int):
-        """Named per-plan switch (gcmf_set_option): "cgrid_ring", "cgrid_ring_smax", "cgrid_ring_d"."""
+        """Named per-plan switch (gcmf_set_option): "cgrid_ring", "cgrid_ring_smax", "cgrid_ring_hmax"."""
         check(load().gcmf_set_option(self._h, name.encode(), int(value)))
 
 

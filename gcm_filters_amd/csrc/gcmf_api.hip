@@ -163,7 +163,7 @@ static int launch_ringc(gcmf_plan *pl, const MultiArgs &m, hipStream_t s) {
       // and every SIMD has a wave (330 -> 364 G cell-steps/s, tools/measure_midsize.py); an 8-way slab 28 instead of 36; BASELINE-size
       // f64 grids 96 either way (-> k_ringc), BASELINE-size f32 grids 52 instead of 60 (+4 %), 1080 x 1440 f32 24 either way (-> k_ringc,
       // the early-exit form measured 9 % slower there).
-      if (!pl->g.fold) {
+      if (!pl->g.fold && m.S <= 8) {
         const bool f64 = pl->d.dtype == GCMF_F64;
         const int wi = f64 ? 112 : 240;   // useful columns of a window (f32: four cells per lane)
         const long long nwx = (pl->g.nx + wi - 1) / wi, want = std::max(1LL, 1024 / (nwx * std::max<long long>(1, m.nbatch)));
@@ -173,6 +173,7 @@ static int launch_ringc(gcmf_plan *pl, const MultiArgs &m, hipStream_t s) {
         const long long rows_xe = std::max(12LL, (need + 3) / 4 * 4), rows_pad = (need + 11) / 12 * 12;
         if (H0 < pl->ringc_xe_rows && rows_xe * 100 <= rows_pad * (f64 ? 95 : 90)) return launch_ringc_flux_slab(pl, m, s);
       }
+      if (m.S == 9) return launch_ringc_flux9(pl, m, s);
       return launch_ringc_flux(pl, m, s);
     default: break;
   }
@@ -377,7 +378,6 @@ int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int 
   if (const char *e = getenv("GCMF_CGRID_TILE")) pl->cgrid_tile = atoi(e);
   if (const char *e = getenv("GCMF_CGRID_RING")) pl->cgrid_ring = atoi(e);
   if (const char *e = getenv("GCMF_CGRID_RING_SMAX")) pl->cgrid_ring_smax = atoi(e);
-  if (const char *e = getenv("GCMF_CGRID_RING_D")) pl->cgrid_ring_d = atoi(e);
   if (const char *e = getenv("GCMF_HOST_CHUNK_MB")) pl->host_chunk_bytes = (size_t)(atof(e) * 1048576.0);
   if (const char *e = getenv("GCMF_HOST_REGISTER")) pl->host_register = atoi(e);
   if (const char *e = getenv("GCMF_ZERO_LAND")) pl->zero_land = atoi(e);
@@ -385,6 +385,7 @@ int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int 
   if (const char *e = getenv("GCMF_ZIGZAG")) pl->zigzag = atoi(e);
   if (const char *e = getenv("GCMF_RINGC_XE_ROWS")) pl->ringc_xe_rows = atoi(e);
   if (const char *e = getenv("GCMF_CLENSHAW")) pl->clenshaw = atoi(e);
+  if (const char *e = getenv("GCMF_RINGC9")) pl->ringc9 = atoi(e);
   PLAN_HIP(hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking));
   PLAN_HIP(hipEventCreate(&pl->ev0));
   PLAN_HIP(hipEventCreate(&pl->ev1));
@@ -520,8 +521,8 @@ int gcmf_set_option(gcmf_plan *pl, const char *name, int value) {
   const std::string n(name);
   if (n == "cgrid_ring") pl->cgrid_ring = value;
   else if (n == "cgrid_ring_smax") pl->cgrid_ring_smax = value;
-  else if (n == "cgrid_ring_d") pl->cgrid_ring_d = value;
   else if (n == "cgrid_ring_hmax") pl->cgrid_ring_hmax = value;
+  else if (n == "ringc9") pl->ringc9 = value;
   else {
     set_error("gcmf_set_option: unknown option '%s'", name);
     return GCMF_ERR_INVALID_ARG;
@@ -570,6 +571,11 @@ int gcmf_multi_supported(const gcmf_plan *pl, int S) { return (pl && multi_suppo
 // kernel is bound by its instruction stream and gains nothing: 93 -> 92-95 us per launch).  Needs the isolated cells fixed up
 // by k_land_fix when there is land (land_ok).
 static bool land_ok(const gcmf_plan *pl, int n_steps);
+// Nine levels per launch (k_ringc<double, K_FLUX, 9>): whole f64 flux-form grids without a tripole seam (the seam's k_fold_band and the
+// slabs' early-exit form stop at eight), tall enough for the deeper ghost zone.
+static bool ringc9_ok(const gcmf_plan *pl) {
+  return pl && pl->ringc9 && pl->kind == K_FLUX && pl->d.dtype == GCMF_F64 && pl->full && !pl->tripolar && !pl->g.fold && pl->g.rows >= 64;
+}
 static int clenshaw_cut(const gcmf_plan *pl, int n_steps, int *depths, int max_depths) {
   if (!pl || pl->ncomp != 1 || !(pl->clenshaw >= 2 || (pl->clenshaw == 1 && pl->kind == K_FLUX))) return 0;
   // (tripolar: of the GRID, not of this slab -- every rank of a slab run must take the same decision)
@@ -579,7 +585,14 @@ static int clenshaw_cut(const gcmf_plan *pl, int n_steps, int *depths, int max_d
   // (f32 state: the flux kinds since round 3, the REGULAR / land-mask kinds since round 4)
   if (!pl->ring || !pl->zero_row || pl->multi_s < 8 || !multi_supported(pl, 8)) return 0;
   if (pl->n_land > 0 && !land_ok(pl, n_steps)) return 0;
-  if (!(n_steps >= 10 || (n_steps >= 5 && n_steps <= 8))) return 0;
+  if (!(n_steps >= 10 || (n_steps >= 5 && n_steps <= 8) || (n_steps == 9 && ringc9_ok(pl)))) return 0;
+  if (ringc9_ok(pl) && (n_steps + 8) / 9 < (n_steps + 7) / 8) {
+    // one launch fewer with up to nine levels each: as even as possible (63 = 7 x 9, 65 = 9 + 7 x 8), the nines first
+    const int L = (n_steps + 8) / 9, q = n_steps / L, r = n_steps % L;
+    if (L > max_depths) return 0;
+    for (int k = 0; k < L; ++k) depths[k] = q + (k < r ? 1 : 0);
+    return L;
+  }
   int n = 0, left = n_steps;
   while (left > 0) {
     int S = 0;
@@ -610,7 +623,7 @@ int gcmf_cheb_multi(gcmf_plan *pl, const void *u, const void *v, void *uo, void 
     int probe[2];
     // (is the backward evaluation on offer for this plan at all: a 10-level polynomial can always be cut, [5, 5]; an f32 filter never
     // starts with eight levels, see clenshaw_cut)
-    if (pl->ncomp != 1 || S < 5 || S > 8 || !pl->ring || !pl->zero_row || clenshaw_cut(pl, 10, probe, 2) != 2 ||
+    if (pl->ncomp != 1 || S < 5 || S > (ringc9_ok(pl) ? 9 : 8) || !pl->ring || !pl->zero_row || clenshaw_cut(pl, 10, probe, 2) != 2 ||
         (first && S == 8 && pl->d.dtype != GCMF_F64)) {
       set_error("gcmf_cheb_multi: the backward evaluation is not available for this plan / depth %d", S);
       return GCMF_ERR_UNSUPPORTED;

@@ -44,7 +44,7 @@ template <typename T> struct CRingP {
   const T *coef[MAX_COEF];
   unsigned *redo;      // counts the workgroups that redid their strip with the full nan_to_num (instrumentation)
   int nx, rows, out_lo, out_hi;
-  int H, nwx, ngroups, nlev, nlev4, wrap, last;
+  int H, nwx, ngroups, nlev, nlevp, wrap, last;
   long long bstride;
   double pn, pk[8], c;
 };
@@ -60,7 +60,9 @@ constexpr int CR_U = 12;  // unroll factor of the row loop = common period of al
 
 // DMA = the operand rows come in through LDS-direct loads (global_load_lds_dwordx4, gfx950): 16 bytes per lane -- the access width the
 // memory pipeline likes (8-byte accesses of this pattern stream at ~4.4 TB/s, experiments/cgrid_probe) -- and no registers in flight.
-template <int S, int D, bool DMA> struct CRingGeom {
+// WPB = waves (= levels of the batch) per workgroup: 4, or 8 in the LDS-direct form (one workgroup per CU, the 14 coefficient rows fetched once
+// per EIGHT levels: the coefficient rows were 40 % of the bytes the L2 was asked for)
+template <int S, int D, bool DMA, int WPB = 4> struct CRingGeom {
   static constexpr int M = DMA ? (S <= 4 ? 4 : 8) : (S + 1) / 2 * 2;   // level j is stale j cells per side; DMA: windows start on a multiple of 4
   static constexpr int W = 128, WI = W - 2 * M;
   // LDS slots of the coefficient ring.  Plain loads: S + 1 (the rows in flight are in registers), a divisor of the period.  DMA: the rows in
@@ -70,7 +72,8 @@ template <int S, int D, bool DMA> struct CRingGeom {
   static constexpr unsigned DUMMY_OFF = NS * SLOTB;                    // DMA: where the fourth wave's padding planes land
   static constexpr unsigned STG_OFF = DUMMY_OFF + 1024u;               // DMA: the waves' staging slots: D per wave x (u0|v0, up|vp, fu|fv)
   static constexpr unsigned STGB = 3072u;
-  static constexpr size_t lds_bytes() { return DMA ? (size_t)STG_OFF + 4u * D * STGB : (size_t)NS * SLOTB; }
+  static constexpr size_t lds_bytes() { return DMA ? (size_t)STG_OFF + (unsigned)WPB * D * STGB : (size_t)NS * SLOTB; }
+  static constexpr int NDC = 8 / WPB;   // DMA: coefficient loads per wave and row (two planes each; 16 plane slots over WPB waves)
 };
 
 #pragma clang diagnostic ignored "-Winline-asm"   // (M0 on the clobber list: the compiler has no use of its own for it in these kernels)
@@ -117,40 +120,47 @@ struct CRingCursor {
 
 // A helper wave (a level that pads the last workgroup of a tile): fetches and publishes its share of the coefficient rows, keeps the
 // barriers, computes nothing.
-template <typename T, int S, int D, bool DMA>
+template <typename T, int S, int D, bool DMA, int WPB>
 __device__ __forceinline__ void cgring_helper(const CRingP<T> &P, unsigned char *s_raw, const int lane, const int wv, const unsigned colB,
                                               const int pos0, const int r_begin, const int r_end, const int n_pad) {
   typedef typename CgV2<T>::type v2;
-  typedef CRingGeom<S, D, DMA> G;
+  typedef CRingGeom<S, D, DMA, WPB> G;
   constexpr int NS = G::NS, RSH = D + 1;
   typedef v2 Slot[16][64];
   Slot *s_coef = reinterpret_cast<Slot *>(s_raw);
   CRingCursor cur(P.nx, P.rows, P.wrap, r_begin, r_end, (unsigned)sizeof(T));
   if constexpr (DMA) {
+    constexpr int NDC = G::NDC, PPW = 2 * NDC;   // planes per wave
     const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)s_raw);
     const int half = lane >> 5;
     int c4 = (pos0 + 4 * (lane & 31)) % P.nx;
     if (c4 < 0) c4 += P.nx;
-    const int pa0 = 4 * wv + half, pa1 = 4 * wv + 2 + half;
-    const char *q_c0 = reinterpret_cast<const char *>(P.coef[pa0 < 14 ? pa0 : 0]) + (unsigned)c4 * 4u;
-    const char *q_c1 = reinterpret_cast<const char *>(P.coef[pa1 < 14 ? pa1 : 0]) + (unsigned)c4 * 4u;
-    const bool a0 = pa0 < 7 || pa0 >= 14, a1 = pa1 < 7 || pa1 >= 14;
+    const char *q_c[NDC];
+    bool isa[NDC];
+#pragma unroll
+    for (int h = 0; h < NDC; ++h) {
+      const int pa = PPW * wv + 2 * h + half;
+      q_c[h] = reinterpret_cast<const char *>(P.coef[pa < 14 ? pa : 0]) + (unsigned)c4 * 4u;
+      isa[h] = pa < 7 || pa >= 14;
+    }
     unsigned nxt = 0;
     auto issue = [&]() {
       cur.advance();
-      cr_dma16(q_c0 + (a0 ? cur.ro : cur.rc), lds0 + nxt + (unsigned)(4 * wv) * 512u);
-      cr_dma16(q_c1 + (a1 ? cur.ro : cur.rc), wv == 3 ? lds0 + G::DUMMY_OFF : lds0 + nxt + (unsigned)(4 * wv + 2) * 512u);
+#pragma unroll
+      for (int h = 0; h < NDC; ++h)
+        cr_dma16(q_c[h] + (isa[h] ? cur.ro : cur.rc), (PPW * wv + 2 * h >= 14) ? lds0 + G::DUMMY_OFF : lds0 + nxt + (unsigned)(PPW * wv + 2 * h) * 512u);
       nxt = (nxt + G::SLOTB == NS * G::SLOTB) ? 0u : nxt + G::SLOTB;
     };
 #pragma unroll
     for (int q = 0; q < D; ++q) issue();
     for (int r = r_begin; r < r_begin + n_pad; ++r) {
-      cr_wait_vm<2 * (D - 1)>();
+      cr_wait_vm<NDC * (D - 1)>();
       __syncthreads();
       issue();
     }
     cr_wait_vm<0>();
   } else {
+  static_assert(DMA || WPB == 4, "plain loads: four waves per workgroup");
   const T *cp[4];
   bool isA[4];
 #pragma unroll
@@ -186,13 +196,15 @@ __device__ __forceinline__ void cgring_helper(const CRingP<T> &P, unsigned char 
 }
 
 // One march of a strip by one wave (one level of the batch).  Returns whether a +-inf was delivered (wave-uniform); SAN = the redo pass.
-template <typename T, int S, int D, bool FIRST, bool SAN, bool DMA>
+template <typename T, int S, int D, bool FIRST, bool SAN, bool DMA, int WPB>
 __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *s_raw, const int lane, const int wv, const long long boff,
                                              const unsigned colB, const int pos0, const bool keep, const int a, const int b, const int n_pad) {
   typedef typename CgV2<T>::type v2;
-  typedef CRingGeom<S, D, DMA> G;
+  typedef CRingGeom<S, D, DMA, WPB> G;
   constexpr int NS = G::NS;
   constexpr int U = CR_U, RU = 6, RV = DMA ? 1 : D + 1, RF = 12, RSH = D + 1;
+  constexpr int NDC = G::NDC, PPW = 2 * NDC;
+  static_assert(DMA || WPB == 4, "plain loads: four waves per workgroup");
   static_assert(D >= 1 && D <= 3 && S >= 2 && S + D <= RF && S < NS && (DMA || (U % NS == 0 && U % RV == 0)) && U % D == 0, "ring periods");
   static_assert(!DMA || sizeof(T) == 4, "LDS-direct loads: f32 state");
   typedef v2 Slot[16][64];
@@ -273,18 +285,23 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
   const char *q_g0 = reinterpret_cast<const char *>(half ? pv0 : pu0) + c4B;
   const char *q_vp = reinterpret_cast<const char *>(half ? pvp : pup) + c4B;
   const char *q_ff = reinterpret_cast<const char *>(half ? pfv : pfu) + c4B;
-  const int pa0 = 4 * wv + half, pa1 = 4 * wv + 2 + half;
-  const char *q_c0 = reinterpret_cast<const char *>(P.coef[pa0 < 14 ? pa0 : 0]) + c4B;
-  const char *q_c1 = reinterpret_cast<const char *>(P.coef[pa1 < 14 ? pa1 : 0]) + c4B;
-  const bool a0 = pa0 < 7 || pa0 >= 14, a1 = pa1 < 7 || pa1 >= 14;
+  const char *q_c[NDC];
+  bool isa[NDC];
+#pragma unroll
+  for (int h = 0; h < NDC; ++h) {
+    const int pa = PPW * wv + 2 * h + half;   // this wave's share of the 14 coefficient planes (slots 14, 15: padding)
+    q_c[h] = reinterpret_cast<const char *>(P.coef[pa < 14 ? pa : 0]) + c4B;
+    isa[h] = pa < 7 || pa >= 14;
+  }
   const unsigned stg0 = G::STG_OFF + (unsigned)(wv * D) * G::STGB;   // this wave's staging slots
   auto issue_dma = [&](auto ph_c) {  // the LDS-direct loads of the next iteration: its coefficient slot, this wave's staging slot
     constexpr int ph = decltype(ph_c)::value;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the staging slot about to be refilled has been read out)
     cur.advance();
     slot_of[ph] = nxt_slot;
-    cr_dma16(q_c0 + (a0 ? cur.ro : cur.rc), lds0 + nxt_slot + (unsigned)(4 * wv) * 512u);
-    cr_dma16(q_c1 + (a1 ? cur.ro : cur.rc), wv == 3 ? lds0 + G::DUMMY_OFF : lds0 + nxt_slot + (unsigned)(4 * wv + 2) * 512u);
+#pragma unroll
+    for (int h = 0; h < NDC; ++h)
+      cr_dma16(q_c[h] + (isa[h] ? cur.ro : cur.rc), (PPW * wv + 2 * h >= 14) ? lds0 + G::DUMMY_OFF : lds0 + nxt_slot + (unsigned)(PPW * wv + 2 * h) * 512u);
     nxt_slot = (nxt_slot + G::SLOTB == NS * G::SLOTB) ? 0u : nxt_slot + G::SLOTB;
     const unsigned st = lds0 + stg0 + (unsigned)(ph % D) * G::STGB;
     cr_dma16(q_g0 + cur.ro, st);
@@ -369,7 +386,7 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
     constexpr int ph = decltype(ph_c)::value;
     if constexpr (DMA) {
       // this iteration's rows were asked for D iterations ago; the loads of the D - 1 iterations in between may still be in flight
-      cr_wait_vm<(FIRST ? 4 : 5) * (D - 1)>();
+      cr_wait_vm<((FIRST ? 2 : 3) + NDC) * (D - 1)>();
       __syncthreads();   // ... and the other waves' quarters of the coefficient slot are there too
       const unsigned char *st = s_raw + stg0 + (unsigned)(ph % D) * G::STGB;
       G0u[ph % RU] = reinterpret_cast<const v2 *>(st)[lane];
@@ -460,20 +477,21 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
   return __any(seen_inf);
 }
 
-template <typename T, int S, int D, bool FIRST, int WPS, bool DMA>
-__global__ __launch_bounds__(256, WPS) void k_cgrid_ring(const CRingP<T> P) {
-  typedef CRingGeom<S, D, DMA> G;
+template <typename T, int S, int D, bool FIRST, int WPS, bool DMA, int WPB>
+__global__ __launch_bounds__(64 * WPB, WPS) void k_cgrid_ring(const CRingP<T> P) {
+  typedef CRingGeom<S, D, DMA, WPB> G;
   constexpr int M = G::M, W = G::W, WI = G::WI;
   extern __shared__ __align__(16) unsigned char s_raw[];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // workgroups are dealt to the 8 XCDs round-robin: the 13 workgroups (50 levels) of a group follow each other on ONE XCD, so that the
   // coefficient rows the first of them fetched are found in that XCD's L2 by the others (as k_cgrid_stream2)
   const int blk = blockIdx.x;
-  const int xcd = blk & 7, slot = (blk >> 3) * 4 + wv;
+  const int xcd = blk & 7, slot = (blk >> 3) * WPB + wv;
   // (round 5 measured the other order too -- every XCD a CONTIGUOUS range of groups, so that neighbouring windows share an L2: 4.97 ms per
   // five-level launch against 4.49 ms; with the groups dealt round-robin all eight XCDs work in the same rows of every plane at a time)
-  const int group = (slot / P.nlev4) * 8 + xcd;
-  int lev = slot % P.nlev4;
+  // (dealing the groups to the XCDs 2 / 4 / 8 at a time measured 457 / 450 / 444 G against 481 G, config 5)
+  const int group = (slot / P.nlevp) * 8 + xcd;
+  int lev = slot % P.nlevp;
   if (group >= P.ngroups) return;  // whole workgroups leave together
   const bool shadow = lev >= P.nlev;
   if (shadow) lev = P.nlev - 1;
@@ -490,12 +508,12 @@ __global__ __launch_bounds__(256, WPS) void k_cgrid_ring(const CRingP<T> P) {
   const bool keep = (lane * 2 >= M) && (lane * 2 < W - M) && (pos < nx);
   const int n_pad = ((b - a) + 2 * S + CR_U - 1) / CR_U * CR_U;   // the march is padded to whole ring periods
   bool bad = false;
-  if (shadow) cgring_helper<T, S, D, DMA>(P, s_raw, lane, wv, colB, pos0, a - S, b + S, n_pad);
-  else bad = cgring_march<T, S, D, FIRST, false, DMA>(P, s_raw, lane, wv, boff, colB, pos0, keep, a, b, n_pad);
+  if (shadow) cgring_helper<T, S, D, DMA, WPB>(P, s_raw, lane, wv, colB, pos0, a - S, b + S, n_pad);
+  else bad = cgring_march<T, S, D, FIRST, false, DMA, WPB>(P, s_raw, lane, wv, boff, colB, pos0, keep, a, b, n_pad);
   if (__syncthreads_or(bad ? 1 : 0)) {   // a +-inf somewhere in the workgroup's rows: the strip again, nan_to_num in full at every level
     if (threadIdx.x == 0 && P.redo) atomicAdd(P.redo, 1u);
-    if (shadow) cgring_helper<T, S, D, DMA>(P, s_raw, lane, wv, colB, pos0, a - S, b + S, n_pad);
-    else cgring_march<T, S, D, FIRST, true, DMA>(P, s_raw, lane, wv, boff, colB, pos0, keep, a, b, n_pad);
+    if (shadow) cgring_helper<T, S, D, DMA, WPB>(P, s_raw, lane, wv, colB, pos0, a - S, b + S, n_pad);
+    else cgring_march<T, S, D, FIRST, true, DMA, WPB>(P, s_raw, lane, wv, boff, colB, pos0, keep, a, b, n_pad);
   }
 }
 
@@ -504,7 +522,7 @@ static bool cr_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15
 bool cgrid_ring_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
   if (pl->cgrid_ring <= 0 || pl->kind != K_CGRID || pl->cgrid_tile || pl->d.dtype != GCMF_F32) return false;
   if (nbatch < 2) return false;   // single-level fields: k_cgrid_stream2c's private-ring form
-  if (S < 4 || S > 8 || S > pl->cgrid_ring_smax) return false;
+  if (S < 4 || S > (pl->cgrid_ring >= 2 ? 5 : 4) || S > pl->cgrid_ring_smax) return false;
   if (pl->g.nx % 2 || pl->g.nx < 2 || pl->g.rows < S + 2) return false;
   if ((long long)pl->g.rows * pl->g.nx * 4 >= (1LL << 32)) return false;   // 32-bit byte offsets inside a level's plane
   for (int k = 0; k < MAX_COEF; ++k)
@@ -512,8 +530,8 @@ bool cgrid_ring_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
   return true;
 }
 
-template <typename T, int S, int D, int WPS, bool DMA> static int launch_cr(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
-  constexpr int WI = CRingGeom<S, D, DMA>::WI;
+template <typename T, int S, int D, int WPS, bool DMA, int WPB = 4> static int launch_cr(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
+  constexpr int WI = CRingGeom<S, D, DMA, WPB>::WI;
   const Geom &g = pl->g;
   CRingP<T> P;
   P.u0 = (const T *)a.u0[0];  P.v0 = (const T *)a.u0[1];
@@ -541,14 +559,14 @@ template <typename T, int S, int D, int WPS, bool DMA> static int launch_cr(gcmf
   if (nrows <= 0 || a.nbatch <= 0) return GCMF_OK;
   P.nwx = (g.nx + WI - 1) / WI;
   P.nlev = (int)a.nbatch;
-  P.nlev4 = (P.nlev + 3) / 4 * 4;
+  P.nlevp = (P.nlev + WPB - 1) / WPB * WPB;
   int H = pl->strip_rows;
   if (H <= 0) {
     // strips as tall as possible (a strip marches H + 2 S rows, padded to whole periods of 12) while the launch still fills whole
     // rounds of the resident waves: the fewest strips of <= 96 rows fix the number of rounds, then the strip count grows to fill the
     // last round; then H + 2 S is brought up to a whole number of periods
     const long long cap = 1024LL * WPS;
-    const long long per_strip = (long long)P.nwx * P.nlev4, hmax = pl->cgrid_ring_hmax > 0 ? pl->cgrid_ring_hmax : 96;
+    const long long per_strip = (long long)P.nwx * P.nlevp, hmax = pl->cgrid_ring_hmax > 0 ? pl->cgrid_ring_hmax : 96;
     const long long ns_min = (nrows + hmax - 1) / hmax;
     const long long rounds = (ns_min * per_strip + cap - 1) / cap;
     long long ns = rounds * cap / per_strip;
@@ -568,9 +586,9 @@ template <typename T, int S, int D, int WPS, bool DMA> static int launch_cr(gcmf
   for (int t = 0; t < 8; ++t) P.pk[t] = a.pk[t];
   P.c = a.c;
   const long long groups_per_xcd = (P.ngroups + 7) / 8;
-  const long long blocks_per_xcd = (groups_per_xcd * P.nlev4 + 3) / 4;
-  dim3 block(256), grid((unsigned)(blocks_per_xcd * 8));
-  const size_t lds = CRingGeom<S, D, DMA>::lds_bytes();
+  const long long blocks_per_xcd = (groups_per_xcd * P.nlevp + WPB - 1) / WPB;
+  dim3 block(64 * WPB), grid((unsigned)(blocks_per_xcd * 8));
+  const size_t lds = CRingGeom<S, D, DMA, WPB>::lds_bytes();
   auto go = [&](auto kern, bool &attr_set) -> int {
     if (!attr_set && lds > 48 * 1024) {
       GCMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -580,38 +598,34 @@ template <typename T, int S, int D, int WPS, bool DMA> static int launch_cr(gcmf
     return GCMF_OK;
   };
   static bool set_first = false, set_next = false;  // per instantiation
-  int rc = a.first ? go(&k_cgrid_ring<T, S, D, true, WPS, DMA>, set_first) : go(&k_cgrid_ring<T, S, D, false, WPS, DMA>, set_next);
+  int rc = a.first ? go(&k_cgrid_ring<T, S, D, true, WPS, DMA, WPB>, set_first) : go(&k_cgrid_ring<T, S, D, false, WPS, DMA, WPB>, set_next);
   if (rc) return rc;
   note_kernel(pl, std::string("gcmf::k_cgrid_ring<") + tyname<T>() + ", " + std::to_string(S) + ", " + std::to_string(D) + ", " +
-                      (a.first ? "true" : "false") + ", " + std::to_string(WPS) + ", " + (DMA ? "true" : "false") + ">", S,
+                      (a.first ? "true" : "false") + ", " + std::to_string(WPS) + ", " + (DMA ? "true" : "false") + ", " + std::to_string(WPB) + ">", S,
               launch_geom(P.H, (nrows + H - 1) / H, P.nwx, 1, grid.x, grid.y, nrows));
   GCMF_HIP(hipGetLastError());
   return GCMF_OK;
 }
 
 int cgrid_ring_smax(const gcmf_plan *pl, int64_t nbatch) {
-  for (int S = 8; S >= 4; --S)
+  for (int S = 5; S >= 4; --S)
     if (cgrid_ring_supported(pl, nbatch, S)) return S;
   return 0;
 }
 
 int launch_cgrid_ring(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
-  const int d = pl->cgrid_ring_d;
-  // LDS-direct loads (cgrid_ring = 2): windows start on multiples of four cells, so nx has to be one
-  if (pl->cgrid_ring >= 2 && pl->g.nx % 4 == 0 && a.S <= 5) {
+  // What round 5 measured on config 5 (tools/measure_cgrid_ring.py, same box, alternating; G cells.steps/s): k_cgrid_stream2c 367; plain
+  // loads S = 4: 388 (S = 5 spills: 280); LDS-direct loads S = 4: 407, S = 5: 490 (three rows in flight: one workgroup per CU, 412); one
+  // wave per SIMD with S = 6 / 7 / 8: 378 / 264 / 256; eight levels per workgroup (coefficient rows fetched half as often, one barrier
+  // for eight waves): 460; groups dealt to the XCDs 2 / 4 / 8 at a time or in contiguous ranges: 457 / 450 / 444 / 442; strips of
+  // 64 / 80 / 120 / 144 rows instead of 96: 448 / 461 / 468 / 459.  Only the two forms below are built.
+  if (pl->cgrid_ring >= 2 && pl->g.nx % 4 == 0) {   // LDS-direct loads: windows start on multiples of four cells
     switch (a.S) {
-      case 4: return d == 3 ? launch_cr<float, 4, 3, 2, true>(pl, a, s) : launch_cr<float, 4, 2, 2, true>(pl, a, s);
-      case 5: return d == 3 ? launch_cr<float, 5, 3, 2, true>(pl, a, s) : launch_cr<float, 5, 2, 2, true>(pl, a, s);
+      case 4: return launch_cr<float, 4, 2, 2, true>(pl, a, s);
+      case 5: return launch_cr<float, 5, 2, 2, true>(pl, a, s);
     }
   }
-  switch (a.S) {
-    case 4: return d == 3 ? launch_cr<float, 4, 3, 2, false>(pl, a, s) : launch_cr<float, 4, 2, 2, false>(pl, a, s);
-    case 5: return d == 3 ? launch_cr<float, 5, 3, 2, false>(pl, a, s) : launch_cr<float, 5, 2, 2, false>(pl, a, s);
-    // six levels and more: one wave per SIMD (the rings spill over into the accumulation registers), three rows in flight
-    case 6: return d == 2 ? launch_cr<float, 6, 2, 1, false>(pl, a, s) : launch_cr<float, 6, 3, 1, false>(pl, a, s);
-    case 7: return d == 2 ? launch_cr<float, 7, 2, 1, false>(pl, a, s) : launch_cr<float, 7, 3, 1, false>(pl, a, s);
-    case 8: return d == 2 ? launch_cr<float, 8, 2, 1, false>(pl, a, s) : launch_cr<float, 8, 3, 1, false>(pl, a, s);
-  }
+  if (a.S == 4) return launch_cr<float, 4, 2, 2, false>(pl, a, s);   // plain loads (cgrid_ring = 1): the A/B partner; five levels spill there
   return GCMF_ERR_INVALID_ARG;
 }
 

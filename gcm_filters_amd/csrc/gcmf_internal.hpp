@@ -74,7 +74,7 @@ struct MultiArgs {
   void *uo, *vo;            // T_{k-1+S}, T_{k-2+S}  (must not alias u0 / v0)
   const void *fb_in;
   void *fb_out;
-  double pk[8];             // coefficients of the S steps (p[k] .. p[k+S-1]); with `first`: p[1] .. p[S]
+  double pk[9];             // coefficients of the S steps (p[k] .. p[k+S-1]); with `first`: p[1] .. p[S]
   double p0, c;
   int S, first, last, fb_is_f32;
   int64_t nbatch;
@@ -157,8 +157,7 @@ struct gcmf_plan {
   int prefetch_rows = 0;  // rows of operands in flight per wave (0 = default per S)
   int cgrid_tile = 0;     // 1: force the LDS-tile C-grid kernel instead of the streaming one (A/B testing)
   int cgrid_ring = 2;     // k_cgrid_ring (gcmf_cgrid_ring.hip) for batched f32 levels: 0 off, 1 plain loads, 2 LDS-direct loads; env GCMF_CGRID_RING, gcmf_set_option
-  int cgrid_ring_smax = 5;  // levels per launch of that kernel (4 .. 8); env GCMF_CGRID_RING_SMAX
-  int cgrid_ring_d = 2;     // operand rows in flight (2 / 3); env GCMF_CGRID_RING_D
+  int cgrid_ring_smax = 5;  // levels per launch of that kernel (4 / 5); env GCMF_CGRID_RING_SMAX
   int cgrid_ring_hmax = 0;  // tallest strip its launcher picks (0 = 96); gcmf_set_option
   // Land kept out of the state (scalar plans; slab-row layout): bit 0 of lbits[cell] = the cell exchanges with a neighbour.
   // A cell that does not (land under a wet mask; a flux-form cell whose four faces are closed) has L = 0 and evolves
@@ -171,6 +170,7 @@ struct gcmf_plan {
   int ring = 1;           // env GCMF_RING=0: deep launches stay with k_flux_multi2 / k_scalar_multi
   unsigned *ring_nfb = nullptr;    // device counter behind gcmf_ring_fallbacks (lives behind zero_row)
   const void *zero_row = nullptr;  // nx zeros: what rows beyond a closed boundary read as coefficients / mask bits (k_ring)
+  int ringc9 = 1;         // whole f64 flux-form grids without a tripole seam: up to NINE levels per k_ringc launch (env GCMF_RINGC9, gcmf_set_option "ringc9")
   int clenshaw = 2;       // backward (Clenshaw) evaluation: 0 off, 1 the flux kinds + C-grid, 2 (default since round 4) every kind that has a
                           // backward kernel (f64 REGULAR / land-mask kinds, B-grid too); env GCMF_CLENSHAW.  Per call: GCMF_FORWARD_RECURRENCE
   void *resident = nullptr;  // state of the on-chip (resident) kernel: exchange planes, tile flags (gcmf_resident.hip)
@@ -210,6 +210,7 @@ bool ring_supported(const gcmf_plan *pl, const MultiArgs &a);
 int launch_ringc_reg(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_ringc_maskz(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_ringc_flux(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
+int launch_ringc_flux9(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);   // nine levels: whole f64 flux grids without a seam (gcmf_ringc_flux9.hip)
 int launch_ringc_flux_slab(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_ringc_flux_slab_f32(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);   // flux plans without a tripole seam, short strips: early exits (k_ringcs)
 int launch_flux_multi2(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);

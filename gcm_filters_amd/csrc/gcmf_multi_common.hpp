@@ -90,6 +90,7 @@ __device__ __forceinline__ double mabs(double x) { return __builtin_fabs(x); }
 __device__ __forceinline__ float mabs(float x) { return __builtin_fabsf(x); }
 
 constexpr int MAX_S = 8;
+constexpr int MAX_PK = 9;   // coefficients a launch carries: k_ringc<double, K_FLUX> also runs nine levels per launch (round 5)
 
 template <typename T, typename FB> struct MultiP {
   const T *u0;      // T_{k-1}
@@ -111,7 +112,7 @@ template <typename T, typename FB> struct MultiP {
   int xcd_per;       // k_ring: workgroups per XCD for the XCD-contiguous order (0 = launch order)
   int zigzag;        // k_ringc, flux kinds: odd strips march upwards (gcmf_ringc_impl.hpp)
   long long bstride;
-  double pk[MAX_S];  // coefficient of level t (1-based) at pk[t-1]
+  double pk[MAX_PK];  // coefficient of level t (1-based) at pk[t-1]
   double p0;         // first only
   double c;
 };

@@ -295,6 +295,7 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
     if constexpr (S >= 6 && (!PRO || ph >= 11)) level(ic<6>{}, ph_c);
     if constexpr (S >= 7 && !PRO) level(ic<7>{}, ph_c);
     if constexpr (S >= 8 && !PRO) level(ic<8>{}, ph_c);
+    if constexpr (S >= 9 && !PRO) level(ic<9>{}, ph_c);
     const int ju = up ? mir - (r - S) : r - S;
     if (ju >= a && ju < b) {  // wave-uniform
       const long long off = boff + (long long)ju * nx;
@@ -463,7 +464,7 @@ static int launch_ringc_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   P.last = a.last;
   P.area_weighted = (KIND == K_FLUX) ? 0 : g.area_weighted;
   P.bstride = (long long)g.rows * g.nx;
-  for (int t = 0; t < MAX_S; ++t) P.pk[t] = t < S ? a.pk[t] : 0.0;
+  for (int t = 0; t < MAX_PK; ++t) P.pk[t] = t < S ? a.pk[t] : 0.0;
   P.p0 = a.p0;
   P.c = a.c;
   dim3 block(256), grid((P.nwaves + 3) / 4, (unsigned)a.nbatch);

@@ -492,7 +492,7 @@ static int launch_multi_s(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   P.last = a.last;
   P.area_weighted = g.area_weighted;
   P.bstride = (long long)g.rows * g.nx;
-  for (int t = 0; t < MAX_S; ++t) P.pk[t] = t < S ? a.pk[t] : 0.0;
+  for (int t = 0; t < MAX_PK; ++t) P.pk[t] = t < S ? a.pk[t] : 0.0;
   P.p0 = a.p0;
   P.c = a.c;
   dim3 block(256), grid((P.nwaves + 3) / 4, (unsigned)a.nbatch);

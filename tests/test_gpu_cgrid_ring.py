@@ -27,7 +27,7 @@ def _case(shape, nlev, n_steps, scale=10.0, seed=0):
     return flt, plan, u, v, gv
 
 
-def _both(flt, plan, u, v, smax=4, d=2, strip_rows=0, mode=2):
+def _both(flt, plan, u, v, smax=4, strip_rows=0, mode=2):
     try:
         plan.set_option("cgrid_ring", 0)
         plan.last_kernel()
@@ -35,7 +35,6 @@ def _both(flt, plan, u, v, smax=4, d=2, strip_rows=0, mode=2):
         assert "k_cgrid_stream2c<" in plan.last_kernel()
         plan.set_option("cgrid_ring", mode)    # 1: plain loads, 2: LDS-direct loads (nx a multiple of 4, up to five levels)
         plan.set_option("cgrid_ring_smax", smax)
-        plan.set_option("cgrid_ring_d", d)
         if strip_rows:
             plan.set_tuning(multi_s=8, strip_rows=strip_rows)
         got = flt.apply_to_vector(u, v)
@@ -43,7 +42,6 @@ def _both(flt, plan, u, v, smax=4, d=2, strip_rows=0, mode=2):
     finally:
         plan.set_option("cgrid_ring", 2)
         plan.set_option("cgrid_ring_smax", 5)
-        plan.set_option("cgrid_ring_d", 2)
         plan.set_tuning(multi_s=8, strip_rows=0)
     return ref, got
 
@@ -51,15 +49,15 @@ def _both(flt, plan, u, v, smax=4, d=2, strip_rows=0, mode=2):
 @pytest.mark.parametrize("shape,nlev", [((96, 160), 8), ((64, 256), 12), ((33, 132), 2), ((120, 124), 5), ((48, 64), 50), ((25, 520), 4),
                                         ((7, 8), 3)])
 @pytest.mark.parametrize("n_steps", [8, 13, 44])
-@pytest.mark.parametrize("smax,d,mode", [(4, 2, 1), (5, 2, 1), (4, 3, 1), (4, 2, 2), (5, 2, 2), (5, 3, 2), (8, 3, 1)])
-def test_same_bits_as_stream2c(shape, nlev, n_steps, smax, d, mode):
+@pytest.mark.parametrize("smax,mode", [(4, 1), (4, 2), (5, 2)])
+def test_same_bits_as_stream2c(shape, nlev, n_steps, smax, mode):
     flt, plan, u, v, gv = _case(shape, nlev, n_steps)
     u[nlev // 2, 5 % shape[0], 7 % shape[1]] = np.nan     # NaN in wet cells: the stencil sees 0, the cell keeps its NaN
     v[0, shape[0] - 1, shape[1] - 1] = np.nan
     v[nlev - 1, 0, 0] = np.nan
     if shape[0] < smax + 2:
         pytest.skip("fewer rows than a launch is deep")
-    ref, got = _both(flt, plan, u, v, smax, d, mode=mode)
+    ref, got = _both(flt, plan, u, v, smax, mode=mode)
     for r, g in zip(ref, got):
         assert g.dtype == np.float64
         assert np.array_equal(r, g, equal_nan=True), (shape, nlev, n_steps, np.nanmax(np.abs(r - g)))
@@ -76,7 +74,7 @@ def test_inf_takes_the_redo_pass(shape, nlev, n_steps, mode):
     v[nlev - 1, 3, 150 % shape[1]] = -np.inf
     u[0, 9, 9] = np.nan
     with np.errstate(all="ignore"):
-        ref, got = _both(flt, plan, u, v, 5, 2, mode=mode)
+        ref, got = _both(flt, plan, u, v, 5, mode=mode)
     for r, g in zip(ref, got):
         assert np.array_equal(r, g, equal_nan=True)
 
@@ -85,7 +83,7 @@ def test_inf_takes_the_redo_pass(shape, nlev, n_steps, mode):
 @pytest.mark.parametrize("strip_rows", [16, 20, 31])
 def test_same_bits_however_the_strips_are_cut(strip_rows, mode):
     flt, plan, u, v, gv = _case((150, 260), 6, 21)
-    ref, got = _both(flt, plan, u, v, 5, 2, strip_rows, mode=mode)
+    ref, got = _both(flt, plan, u, v, 5, strip_rows, mode=mode)
     for r, g in zip(ref, got):
         assert np.array_equal(r, g, equal_nan=True)
 

@@ -86,6 +86,36 @@ def test_same_bits_however_the_levels_are_cut(grid):
     assert np.array_equal(outs[0], outs[1], equal_nan=True) and np.array_equal(outs[0], outs[2], equal_nan=True)
 
 
+@pytest.mark.parametrize("grid", ["IRREGULAR_WITH_LAND", "MOM5U", "MOM5T"])
+@pytest.mark.parametrize("n_steps", [9, 17, 27, 63])
+@pytest.mark.parametrize("kwargs", [dict(nanland=True), dict(nanwet=[np.nan, np.nan]), dict(nb=2)])
+def test_nine_levels_per_launch_give_the_same_bits(grid, n_steps, kwargs):
+    """Round 5: whole f64 flux-form grids without a tripole seam run up to NINE levels per k_ringc launch when that saves a launch
+    (63 = 7 x 9, 27 = 3 x 9, 17 = 9 + 8, 9 = one launch; csrc/gcmf_ringc_flux9.hip).  Same arithmetic per level: the same bits as the cut
+    into launches of 5..8 (n = 9: as the forward recurrence within tolerance -- 9 cannot be cut otherwise), and the oracle."""
+    flt, plan, f, want = _case(grid, (200, 392), n_steps, **kwargs)
+    try:
+        plan.set_option("ringc9", 1)
+        cut9 = plan.clenshaw_cut(n_steps)
+        assert 9 in cut9 and len(cut9) == -(-n_steps // 9), cut9
+        plan.last_kernel()
+        got9 = flt.apply(f)
+        assert "k_ringc<double, 2, 9" in plan.last_kernel(), plan.last_kernel()
+        plan.set_option("ringc9", 0)
+        cut8 = plan.clenshaw_cut(n_steps)
+        assert 9 not in cut8
+        plan.last_kernel()
+        got8 = flt.apply(f)
+    finally:
+        plan.set_option("ringc9", 1)
+    ok = ~np.isnan(want)
+    assert np.array_equal(np.isnan(got9), np.isnan(want))
+    assert np.abs(got9[ok] - want[ok]).max() <= 1e-12 * np.abs(want[ok]).max()
+    if n_steps != 9:
+        assert "k_ringc" in plan.last_kernel() and len(cut8) == len(cut9) + 1
+        assert np.array_equal(got9, got8, equal_nan=True)
+
+
 @pytest.mark.parametrize("grid", ["IRREGULAR_WITH_LAND", "MOM5U", "MOM5T", "TRIPOLAR_POP_WITH_LAND"])
 @pytest.mark.parametrize("dt", ["f8", "f4"])
 @pytest.mark.parametrize("kwargs", [dict(nanland=True), dict(nanwet=[np.nan, np.nan]), dict(nb=3)])
@@ -138,9 +168,14 @@ def test_default_is_backward_for_flux_kinds_and_forward_for_the_rest():
         assert np.nanmax(np.abs(ref - want)) <= 1e-12 * np.nanmax(np.abs(want))
     # polynomial lengths that cannot be cut into launches of 5..8, f32 state: the forward recurrence
     flt, plan, f, want = _case("IRREGULAR_WITH_LAND", (120, 256), 9)
-    assert plan.clenshaw_cut(9) == [] and plan.clenshaw_cut(4) == [] and plan.clenshaw_cut(10) == [5, 5] and plan.clenshaw_cut(63) == [8] * 7 + [7]
-    got = flt.apply(f)
-    assert "k_ringc" not in plan.last_kernel()
+    assert plan.clenshaw_cut(9) == [9] and plan.clenshaw_cut(63) == [9] * 7 and plan.clenshaw_cut(65) == [9] + [8] * 7   # (round 5: nine levels where that saves a launch)
+    try:
+        plan.set_option("ringc9", 0)
+        assert plan.clenshaw_cut(9) == [] and plan.clenshaw_cut(4) == [] and plan.clenshaw_cut(10) == [5, 5] and plan.clenshaw_cut(63) == [8] * 7 + [7]
+        got = flt.apply(f)
+        assert "k_ringc" not in plan.last_kernel()
+    finally:
+        plan.set_option("ringc9", 1)
     assert np.nanmax(np.abs(got - want)) <= 1e-12 * np.nanmax(np.abs(want))
     # f32 state: backward too (four cells per lane; the flux kinds since round 3, the REGULAR / land-mask kinds since round 4)
     for grid, backward in (("IRREGULAR_WITH_LAND", True), ("REGULAR_WITH_LAND", True), ("REGULAR", True)):
@@ -174,7 +209,8 @@ def test_cgrid_backward_evaluation(dt, nlev, n_steps):
                                    u.astype("f8"), v.astype("f8"), {k: x.astype("f8") for k, x in gv.items()})
     plan = ALL_KERNELS[GridType.VECTOR_C_GRID](**gv)._plan(_lib.dtype_code(dt), shape)
     gu, gw = flt.apply_to_vector(u, v)
-    assert "k_cgrid_stream2c<" in plan.last_kernel()
+    # (batched f32 levels: k_cgrid_ring, round 5 -- the same bits; single levels and f64 state: k_cgrid_stream2c)
+    assert ("k_cgrid_ring<" if (dt == "f4" and nlev > 1 and n_steps >= 4) else "k_cgrid_stream2c<") in plan.last_kernel(), plan.last_kernel()
     assert gu.dtype == np.float64 and gw.dtype == np.float64
     tol = 1e-4 if dt == "f4" else 1e-12
     for g, w in ((gu, wu), (gw, wv)):
@@ -254,7 +290,7 @@ def test_cgrid_f32_precision_policy(n_steps, scale):
     flts, plan, u, v, ref, truth = _cgrid_f32_case((96, 160), 8, n_steps, scale)
     e_ref = _rel2(ref, truth)                       # what f32 state costs the reference itself: 3e-6 (n 44) ... 1.3e-5 (n 125)
     got = flts["auto"].apply_to_vector(u, v)
-    assert "k_cgrid_stream2c<float" in plan.last_kernel()
+    assert "k_cgrid_ring<float" in plan.last_kernel()
     fwd = flts["reference"].apply_to_vector(u, v)
     assert "k_cgrid_stream2<float, double" in plan.last_kernel()
     assert got[0].dtype == np.float64 and fwd[0].dtype == np.float64

@@ -160,7 +160,7 @@ def main():
         names = demangle([k["name"] for k in kernels])
         for k, d in zip(kernels, names):
             k["dname"] = d.replace("void ", "").split("(")[0]
-        watched = [k for k in kernels if re.search(r"gcmf::k_(ring|ringc|ringcs|fold_band|resident|cgrid_stream2c?|bgrid_stream2)<", k["dname"])]
+        watched = [k for k in kernels if re.search(r"gcmf::k_(ring|ringc|ringcs|fold_band|resident|cgrid_stream2c?|cgrid_ring|bgrid_stream2)<", k["dname"])]
         for k in sorted(watched, key=lambda k: k["dname"]):
             total = k["vgpr"]   # gfx90a and later: .vgpr_count is the unified total (architected + accumulation registers)
             alloc = (total + 7) // 8 * 8

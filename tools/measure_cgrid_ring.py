@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """BASELINE config 5 (VECTOR_C_GRID, 50 x 2400 x 3600 f32, Gaussian n 44) through the variants of the backward C-grid kernel, in ONE
-process, alternating: k_cgrid_stream2c (round 2-4) against k_cgrid_ring (round 5) at S = 4 / 5 levels per launch and 2 / 3 operand
-rows in flight; prints ms per application, G cells.steps/s, the dominant kernel's time per launch, and checks every variant's result
+process, alternating: k_cgrid_stream2c (round 2-4: "stream") against k_cgrid_ring (round 5) with plain loads ("r4", "r5") and with
+LDS-direct loads ("m4", "m5") at 4 / 5 levels per launch (suffix hNNN: tallest strip); prints ms per application, G cells.steps/s, the dominant kernel's time per launch, and checks every variant's result
 against the first one bit for bit.
 
-    python tools/measure_cgrid_ring.py [--nlev 50] [--reps 3] [--variants stream,r4d2,r5d2,r4d3,r5d3] [--strip H]
+    python tools/measure_cgrid_ring.py [--nlev 50] [--reps 3] [--variants stream,r4,m4,m5,m5h120] [--strip H]
 """
 import argparse
 import os
@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--strip", type=int, default=0)
-    ap.add_argument("--variants", default="stream,r4d2,m4d2,m5d2,m4d3,m5d3")
+    ap.add_argument("--variants", default="stream,r4,m4,m5")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     wl = T.baseline_workload(5, (a.ny, a.nx), nlev=a.nlev)
@@ -48,7 +48,6 @@ def main():
         else:
             plan.set_option("cgrid_ring", 2 if name[0] == "m" else 1)   # m: operand rows through LDS-direct loads
             plan.set_option("cgrid_ring_smax", int(name[1]))
-            plan.set_option("cgrid_ring_d", int(name[3]))
             # optional suffixes: x0 = groups dealt round-robin to the XCDs instead of contiguous ranges, hNNN = tallest strip
             import re
             plan.set_option("cgrid_ring_hmax", int(re.search(r"h(\d+)", name).group(1)) if re.search(r"h(\d+)", name) else 0)
