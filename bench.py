@@ -660,6 +660,9 @@ def parse():
                     help="N>1, scalar configs: strong = one (ny, nx) grid cut into N row slabs (reported as value); "
                          "weak = every GPU owns ny rows of an (N*ny, nx) grid")
     ap.add_argument("--no-weak", action="store_true", help="N>1: skip the second (weak-scaling) measurement")
+    ap.add_argument("--batch-levels", type=int, default=16,
+                    help="N>1, scalar configs: time levels of the third measurement -- the same grid cut N ways with a BATCH of fields "
+                         "(strips get tall again on short slabs: the strong-scaling workload that can use 8 GPUs); 0 skips it")
     ap.add_argument("--halo", type=int, default=0, help="N>1: ghost rows per exchange (0 = auto)")
     ap.add_argument("--exchange", choices=["auto", "native", "torch", "p2p"], default="auto",
                     help="N>1 halo exchange: native = RCCL send / recv issued by libgcmf on a side stream; torch = torch.distributed P2P; "
@@ -1023,6 +1026,30 @@ def main_multi(args, world, rank, local_rank):
                              "matched_across_ranks": matched, "backend": dist.get_backend(),
                              "rccl": sf.comm.describe() if getattr(sf, "comm", None) is not None else None})
         weak = None
+        batched = None
+        if args.scaling == "strong" and args.batch_levels > 1:
+            # Third figure: the SAME grid cut N ways, a batch of time levels per application (the reference's own leading dims).  One field
+            # leaves an 8-way slab 11-row strips that march 11 + 2 S rows (bound ~3.6 x); a batch makes the strips tall again.
+            nb = args.batch_levels
+            fb = [np.stack([f + 0.01 * k for k in range(nb)]) for f in wl["fields"]]
+            local_b = sf.scatter_from_global(fb)
+            keep_b = {}
+
+            def one_b():
+                keep_b["o"] = sf.apply_local(local_b)
+            one_b()
+            el_b = timed(one_b)
+            batched = {"levels": nb, "value": nb * cells * n_steps * args.steps / el_b, "unit": "cell-steps/s",
+                       "ms_per_step": 1e3 * el_b / args.steps, "timing": dict(spread["last"]), "scaling": "strong",
+                       "note": f"third figure: the same {ny_global}x{args.nx} grid cut {world} ways, {nb} time levels per application "
+                               "(a batch of fields through the slab path, same exchanges per application as the single field)"}
+            # its level 0 is the timed single field: the slab path must give the same bits for it inside the batch
+            same0 = bool(torch.equal(torch.nan_to_num(keep_b["o"][0][0]), torch.nan_to_num(outs[0].reshape(keep_b["o"][0][0].shape))))
+            batched["level0_same_bits_as_the_single_field"] = same0
+            if not same0:
+                failed.append(f"rank {rank}: level 0 of the batched slab run differs from the single-field run")
+            del local_b, fb
+            keep_b.clear()
         if args.scaling == "strong" and not args.no_weak:
             del sf, outs, local_main
             free_gpu()
@@ -1044,7 +1071,8 @@ def main_multi(args, world, rank, local_rank):
                        "n_steps": n_steps, "global_grid": [ny_global, args.nx], "parallelism": par},
             "timing": main_spread, "value_min": cells * n_steps / (main_spread["ms_per_application_max"] * 1e-3),
             "value_max": cells * n_steps / (main_spread["ms_per_application_min"] * 1e-3),
-            "parity": parity, "weak": weak, "exchange": exchange_rec if cfg not in (5, 6) else None, "cpu_baseline": None,
+            "parity": parity, "weak": weak, "batched_strong": batched if cfg not in (5, 6) else None,
+            "exchange": exchange_rec if cfg not in (5, 6) else None, "cpu_baseline": None,
             # physical, like the N = 1 line: algorithmic bytes of ONE launch (every operand plane read once, every result written once)
             # x the launches of an application over the time between rank 0's first and last launch of it
             "roofline": None if not launches else (lambda per_launch, ms_app: {

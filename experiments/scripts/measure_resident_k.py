@@ -1,5 +1,5 @@
 """Halo depth K of the on-chip kernel on small whole grids: us per Filter.apply with GCMF_RESIDENT_K forced (run once per K: the
-variable is read once per process).   GCMF_RESIDENT_K=8 python tools/measure_resident_k.py"""
+variable is read once per process).   GCMF_RESIDENT_K=8 python experiments/scripts/measure_resident_k.py"""
 import os, sys, time
 os.environ["GCMF_RESIDENT"] = "1"
 import numpy as np

@@ -2,9 +2,9 @@
 of two modes ~10 % apart depending on where its planes landed in HBM)?  Re-creates the config-3 plan NPLANS times in one process (a
 dummy allocation in between, so that the planes land elsewhere), runs a few applications on each and prints the HIP-event time per
 launch of the dominant kernel.  Run it plainly for the times, and under `rocprofv3 --kernel-trace --pmc <counters>` (one counter group per
-run, tools/placement_counters.sh) for per-dispatch counters; tools/placement_counters.sh joins the two by dispatch order.
+run, experiments/scripts/placement_counters.sh) for per-dispatch counters; experiments/scripts/placement_counters.sh joins the two by dispatch order.
 
-    python tools/placement_counters.py [NPLANS=8] [APPS=2]
+    python experiments/scripts/placement_counters.py [NPLANS=8] [APPS=2]
 """
 import os, sys, time
 import numpy as np

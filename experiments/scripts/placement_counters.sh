@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/placement_counters.sh [NPLANS]  (through gpurun): per-plan launch time and per-plan counter means of k_ringc<double, 2, 8, false>
+# experiments/scripts/placement_counters.sh [NPLANS]  (through gpurun): per-plan launch time and per-plan counter means of k_ringc<double, 2, 8, false>
 set -u
 N=${1:-8}
 OUT=$PWD/gpurun_out/placement; mkdir -p "$OUT"; export TMPDIR=/tmp; REPO=$PWD; cd /tmp
@@ -10,7 +10,7 @@ for G in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_TAG_STALL_su
          "GRBM_UTCL2_BUSY GRBM_GUI_ACTIVE"; do
   # (every pass under its own timeout: a counter name this rocprofv3 does not know makes it abort and then sit in its finaliser --
   # round 4 lost 40 GPU-minutes to exactly that)
-  timeout 420 rocprofv3 --kernel-trace --output-format csv --pmc $G -d "$OUT/g$i" -o pmc -- python3 $REPO/tools/placement_counters.py $N 2 > "$OUT/g$i.log" 2>&1
+  timeout 420 rocprofv3 --kernel-trace --output-format csv --pmc $G -d "$OUT/g$i" -o pmc -- python3 $REPO/experiments/scripts/placement_counters.py $N 2 > "$OUT/g$i.log" 2>&1
   i=$((i+1))
 done
 cd $REPO

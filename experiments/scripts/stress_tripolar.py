@@ -2,7 +2,7 @@
 tools/fuzz_gpu.py 407 250 under GCMF_RESIDENT=1, not reproducible with the same seed): tripolar filters (k_ringc + k_fold_band on the side
 stream) interleaved with filters of other small grids (on-chip kernel when GCMF_RESIDENT allows), against the oracle.
 
-    python tools/stress_tripolar.py [seed] [n]"""
+    python experiments/scripts/stress_tripolar.py [seed] [n]"""
 import sys, warnings
 import numpy as np
 sys.path.insert(0, "/root/repo")

@@ -166,8 +166,8 @@ static int launch_ringc(gcmf_plan *pl, const MultiArgs &m, hipStream_t s) {
       if (!pl->g.fold && m.S <= 8) {
         const bool f64 = pl->d.dtype == GCMF_F64;
         const int wi = f64 ? 112 : 240;   // useful columns of a window (f32: four cells per lane)
-        const long long nwx = (pl->g.nx + wi - 1) / wi, want = std::max(1LL, 1024 / (nwx * std::max<long long>(1, m.nbatch)));
         const long long nrows = m.row_hi - m.row_lo;
+        const long long nwx = (pl->g.nx + wi - 1) / wi, want = strips_per_column(nwx * std::max<long long>(1, m.nbatch), nrows, m.S, 12);
         const long long H0 = std::min(nrows, std::max(4LL, pl->strip_rows > 0 ? (long long)pl->strip_rows : (nrows + want - 1) / want));
         const long long need = H0 + 2 * m.S;
         const long long rows_xe = std::max(12LL, (need + 3) / 4 * 4), rows_pad = (need + 11) / 12 * 12;

@@ -199,6 +199,29 @@ inline std::string launch_geom(int H, int nstrips, int nwx, int xcd, unsigned gx
   return b;
 }
 size_t dtype_size(int dtype);
+// How many strips a (window, batch entry) column of the one-wave-per-SIMD strip-marching kernels is cut into: ideally as many as fill ONE
+// resident round of 1024 waves (all strips march in lock-step) -- a single field at BASELINE size: 33 windows x 31 strips.  Batches do
+// not divide that well (33 windows x 16 fields = 528 columns: one strip each left half the SIMDs without a wave -- a batch of 16 ran at
+// 515 G against 811 G for a batch of 4 before round 5): the number of rounds k <= 8 is chosen that minimises k x (rows a wave marches:
+// H + 2 S, rounded up to the exit period), one round being preferred by 4 % per extra round.
+inline long long strips_per_column(long long per_strip, long long nrows, int S, int period) {
+  if (per_strip < 1) per_strip = 1;
+  long long best = 1;
+  double best_cost = -1.0;
+  for (int k = 1; k <= 8; ++k) {
+    long long w = (1024LL * k) / per_strip;
+    if (w < 1) w = 1;
+    if (w > nrows) w = nrows;
+    const long long H = (nrows + w - 1) / w;
+    long long march = H + 2 * S;
+    if (period > 1) march = (march + period - 1) / period * period;
+    const long long rounds = (w * per_strip + 1023) / 1024;
+    const double cost = (double)(rounds * march) * (1.0 + 0.04 * (rounds - 1));
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = w; }
+    if (w >= nrows) break;
+  }
+  return best;
+}
 // kernel launchers (defined in gcmf_scalar.hip / gcmf_vector.hip)
 int launch_scalar_step(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 int launch_vector_step(gcmf_plan *pl, const StepArgs &a, hipStream_t s);

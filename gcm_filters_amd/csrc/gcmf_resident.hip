@@ -21,7 +21,7 @@
 // rides on the level barrier), from then on its stencil operands go through nan_to_num (kernels.py:175, 300) -- what k_ringc's redo
 // pass computes.  REGULAR has no nan_to_num in the reference (NaN spreads, kernels.py:113-121) and none here.
 //
-// WHERE IT STANDS (round 4, MI355X, tools/measure_resident.py / tools/probe_resident.py): correct and bit-identical, NOT
+// WHERE IT STANDS (round 4, MI355X, tools/measure_resident.py / experiments/scripts/probe_resident.py): correct and bit-identical, NOT
 // faster -- therefore opt-in (GCMF_RESIDENT=1).  364 x 3600 IRREGULAR f64: load + store 33 us, ~1.0 us per level (the f64 issue
 // rate of 13 cells x 8 waves per CU), ~9.5 us per tile exchange; 32 levels 132 us, 64 levels 239 us -- the strip-marching launches do
 // 32 levels of the same slab in ~115 us.  The exchange is what costs: 15 of them per 63-level filter, because registers + LDS of a CU
@@ -692,7 +692,7 @@ static bool res_supported(const gcmf_plan *pl, int row_lo, int row_hi, int L, Re
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
   if (const char *e = getenv("GCMF_RESIDENT_MAX_WG")) ncu = std::min(ncu, std::max(1, atoi(e)));
   // The halo depth K = levels between two tile exchanges: deeper halos cost padded cells (every level works on them), shallower ones
-  // cost exchanges.  Measured (tools/measure_resident_k.py, us per application at K = 4 / 8 / 12): IRREGULAR 256 x 256 n 63: 92 / 72 / 138;
+  // cost exchanges.  Measured (experiments/scripts/measure_resident_k.py, us per application at K = 4 / 8 / 12): IRREGULAR 256 x 256 n 63: 92 / 72 / 138;
   // 512 x 512: 110 / 110 / 154; 600 x 640: 143 / 116 / 158; REGULAR 512 x 512 n 36: 55 / 54 / 71; REGULAR_WITH_LAND 720 x 1440 n 56:
   // 200 / 183 / 167.  So: K = 8 where a geometry exists for it, else K = 4 (the 8-way slab of 2400 x 3600 only fits K = 4);
   // GCMF_RESIDENT_K forces one (4, 8, 12).

@@ -433,8 +433,7 @@ static int launch_ring_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   int H = pl->strip_rows;
   if (H <= 0) {  // one resident round of waves at one wave per SIMD (all strips march in lock-step)
     // (tripolar plans: k_fold_band runs beside this launch on a side stream; its 48-register waves fit on the SIMDs next to these)
-    long long want = 1024 / ((long long)P.nwx * a.nbatch);
-    if (want < 1) want = 1;
+    const long long want = strips_per_column((long long)P.nwx * a.nbatch, nrows, S, 4);
     H = (int)((nrows + want - 1) / want);
     // (no rounding to the ring period: the march leaves its last period early, so the slab of one rank of an 8-GPU run marches
     // 11 + 2 S rows, not 36.  Small grids get short strips -- a launch takes as long as ONE strip's march, and a grid that

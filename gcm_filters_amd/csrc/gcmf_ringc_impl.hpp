@@ -449,8 +449,7 @@ static int launch_ringc_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   P.nwx = (g.nx + WI - 1) / WI;
   int H = pl->strip_rows;
   if (H <= 0) {
-    long long want = 1024 / ((long long)P.nwx * a.nbatch);
-    if (want < 1) want = 1;
+    const long long want = strips_per_column((long long)P.nwx * a.nbatch, nrows, S, (KIND == K_FLUX && !XE) ? R : 4);
     H = (int)((nrows + want - 1) / want);
     if (H < 4) H = 4;   // (short strips for small grids: see k_ring)
     if (KIND == K_FLUX && !XE) H += (R - (H + 2 * S) % R) % R;   // whole periods (no early exit here): let the padding carry real rows

@@ -10,11 +10,11 @@ from __future__ import annotations
 import enum
 import warnings
 from dataclasses import dataclass, field
-from typing import Iterable, NamedTuple
+from typing import Iterable, NamedTuple, Optional
 
 import numpy as np
 
-from .kernels import kernels_cache_enabled
+from .kernels import PLAN_CACHE_MODES, plan_cache_mode, kernels_cache_enabled
 from .kernels import (
     ALL_KERNELS,
     AreaWeightedMixin,
@@ -167,30 +167,32 @@ def _compute_filter_spec(filter_scale, dx_min, filter_shape, transition_width=np
 # ------------------------------------------------------------------------------------------------
 # the operator interface xarray.apply_ufunc calls (reference filter.py:154-291)
 # ------------------------------------------------------------------------------------------------
-def _create_filter_func(filter_spec: FilterSpec, Laplacian, evaluation: str = "auto"):
+def _create_filter_func(filter_spec: FilterSpec, Laplacian, evaluation: str = "auto", plan_cache=None):
     """Returns ``filter_func(field, *grid_args)``: first argument the field (last two axes = y, x; leading
     axes are independent batches), then the grid variables in ``Laplacian.required_grid_args()`` order.
-    ``evaluation``: see ``Filter``."""
+    ``evaluation``, ``plan_cache``: see ``Filter``."""
     forward = _forward_only(evaluation)
     memo = _LaplacianMemo(Laplacian)
 
     def filter_func(field, *args):
         assert len(args) == len(Laplacian.required_grid_args())
-        laplacian = memo.get(args)  # device plan: cached while the grid arrays are unchanged
-        return laplacian._run([field], spec=filter_spec, forward=forward)[0]
+        with plan_cache_mode(plan_cache):
+            laplacian = memo.get(args)  # device plan: cached while the grid arrays are unchanged
+            return laplacian._run([field], spec=filter_spec, forward=forward)[0]
 
     return filter_func
 
 
-def _create_filter_func_vec(filter_spec: FilterSpec, Laplacian, evaluation: str = "auto"):
+def _create_filter_func_vec(filter_spec: FilterSpec, Laplacian, evaluation: str = "auto", plan_cache=None):
     """Returns ``filter_func_vec(u, v, *grid_args) -> (u_filtered, v_filtered)``."""
     forward = _forward_only(evaluation)
     memo = _LaplacianMemo(Laplacian)
 
     def filter_func_vec(ufield, vfield, *args):
         assert len(args) == len(Laplacian.required_grid_args())
-        laplacian = memo.get(args)
-        u, v = laplacian._run([ufield, vfield], spec=filter_spec, forward=forward)
+        with plan_cache_mode(plan_cache):
+            laplacian = memo.get(args)
+            u, v = laplacian._run([ufield, vfield], spec=filter_spec, forward=forward)
         return (u, v)
 
     return filter_func_vec
@@ -247,7 +249,8 @@ def _xarray():
 
 
 def _is_bare_array(x) -> bool:
-    return isinstance(x, np.ndarray) or _is_torch(x) or hasattr(x, "__cuda_array_interface__")
+    return (isinstance(x, np.ndarray) or _is_torch(x) or hasattr(x, "__cuda_array_interface__")
+            or (hasattr(x, "__dlpack__") and not hasattr(x, "dims")))
 
 
 @dataclass
@@ -279,7 +282,18 @@ class Filter:
         that is faster (float64 flux-form grids: <= 3e-15 from the forward result; VECTOR_C_GRID: for float32 fields the whole
         polynomial is then carried in float32 -- measured 1.4-1.8 x the error the reference's own float32 path has against
         float64 arithmetic, e.g. 5e-6 instead of 3e-6 at n_steps 44 and 1.8e-5 instead of 1.3e-5 at n_steps 125; the result
-        is float64 either way).  The grid types that are bit-exact with numpy run the forward recurrence under both.
+        is float64 either way).  ``"reference"`` is also the path that is BIT-EXACT with numpy on the REGULAR / land-mask / B-grid types
+        (their default has been the backward evaluation with fused multiply-adds since round 4: <= 1e-14 from numpy, float32 fields
+        carried in float32 throughout) and that reproduces the reference's NaN / inf pattern around a non-finite value in a wet cell.
+    plan_cache : {None, "protect", "verify", "off"}, keyword only (not a field of the reference class)
+        The reference builds (and validates) a fresh Laplacian on every call (gcm_filters/filter.py:183); here the folded grid lives in
+        HBM as a *plan* that is reused while the grid arrays are unchanged.  ``"protect"`` (the default, also ``None`` unless the
+        environment says otherwise): the numpy grid arrays are made READ-ONLY while their plan is cached -- an in-place edit such as
+        ``wet_mask[10, 10] = 0`` raises ``ValueError: assignment destination is read-only`` instead of silently filtering with stale
+        coefficients; call ``gcm_filters_amd.kernels.clear_plan_cache()`` (or drop the Filter and its arrays) to get writability back.
+        ``"verify"``: the arrays stay writable and every plane is hashed on every call (~5 ms per 2400 x 3600 plane): edits between
+        calls just work, as with the reference.  ``"off"``: a fresh plan per call, exactly the reference's behaviour (~10 ms per
+        call at 2400 x 3600).  Process-wide defaults: ``GCMF_PLAN_CACHE=0`` (off), ``GCMF_PLAN_CACHE_VERIFY=full`` (verify).
 
     Attributes
     ----------
@@ -295,6 +309,7 @@ class Filter:
     grid_type: GridType = GridType.REGULAR
     grid_vars: dict = field(default_factory=dict, repr=False)
     evaluation: str = field(default="auto", kw_only=True, repr=False)   # extension, see the docstring
+    plan_cache: Optional[str] = field(default=None, kw_only=True, repr=False)   # extension, see the docstring
 
     # Same fields, defaults, attribute names (Laplacian, filter_spec, n_steps, grid_ds) and exception / warning texts as
     # the reference class (gcm_filters/filter.py:294-393): they are the contract its users and tests rely on.  The
@@ -302,6 +317,8 @@ class Filter:
     def __post_init__(self):
         self.Laplacian = ALL_KERNELS[self.grid_type]
         _forward_only(self.evaluation)   # ValueError for anything else
+        if self.plan_cache is not None and self.plan_cache not in PLAN_CACHE_MODES:
+            raise ValueError(f"plan_cache must be one of {PLAN_CACHE_MODES} or None, not {self.plan_cache!r}")
         self._reject_bad_arguments()
         self.n_steps = self._choose_n_steps()
         self.filter_spec = _compute_filter_spec(self.filter_scale, self.dx_min, self.filter_shape, self.transition_width,
@@ -399,10 +416,11 @@ class Filter:
     def _operator(self, make):
         """``make(filter_spec, Laplacian, evaluation)`` (one of the two factories above), built once per Filter: the closure
         remembers the Laplacian object of its last call (_LaplacianMemo)."""
-        key = (make, id(self.filter_spec), self.Laplacian, self.evaluation)
+        key = (make, id(self.filter_spec), self.Laplacian, self.evaluation, self.plan_cache)
         hit = self.__dict__.get("_op")
         if hit is None or hit[0] != key:
-            hit = (key, make(self.filter_spec, self.Laplacian, self.evaluation))
+            extra = {} if self.plan_cache is None else {"plan_cache": self.plan_cache}
+            hit = (key, make(self.filter_spec, self.Laplacian, self.evaluation, **extra))
             self.__dict__["_op"] = hit
         return hit[1]
 

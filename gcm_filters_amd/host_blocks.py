@@ -200,6 +200,12 @@ class RowBlockPipeline:
             if self.cut:   # the block plans evaluate the way the one-plan path does (whatever their own default would be)
                 for blk in self.blocks:
                     blk.plan.set_tuning(multi_s=8, clenshaw=2)
+                # ... cut as SLABS are cut (launches of 5..8; the one-plan path of a whole flux grid may use nines, round 5): the levels are
+                # the same arithmetic however they are cut into launches, so the bits are the one-plan path's.  A polynomial the slabs
+                # cannot evaluate backwards at all (9 levels) stays on the one-plan path.
+                self.cut = list(self.blocks[0].plan.clenshaw_cut(self.n_steps)) if self.blocks else []
+                if not self.cut or any(list(blk.plan.clenshaw_cut(self.n_steps)) != self.cut for blk in self.blocks):
+                    self.ok = False
             self.s_up, self.s_comp, self.s_down = (torch.cuda.Stream(device) for _ in range(3))
         self.worker = ThreadPoolExecutor(1, thread_name_prefix="gcmf-d2h")
 

@@ -9,6 +9,8 @@ coefficient planes in HBM; calling it launches the HIP stencil.  There is no num
 from __future__ import annotations
 
 import enum
+import contextlib
+import contextvars
 import os
 import threading
 import weakref
@@ -54,10 +56,13 @@ def _unwrap(x):
     """xarray.DataArray / Variable -> its array; everything else unchanged."""
     if _is_torch(x) or isinstance(x, np.ndarray):
         return x
-    if hasattr(x, "__cuda_array_interface__") or (hasattr(x, "__dlpack__") and not hasattr(x, "dims")):
+    if hasattr(x, "__dlpack__") and not hasattr(x, "dims"):
         # other device-array libraries (the reference's cupy path, gpu_compat.py:5-10): zero-copy via DLPack
         import torch
         return torch.from_dlpack(x)
+    if hasattr(x, "__cuda_array_interface__"):
+        import torch
+        return torch.as_tensor(x, device="cuda")
     data = getattr(x, "data", None)
     if data is not None and hasattr(x, "dims"):
         return data if (_is_torch(data) or isinstance(data, np.ndarray)) else np.asarray(data)
@@ -66,6 +71,42 @@ def _unwrap(x):
 
 def _on_gpu(x) -> bool:
     return _is_torch(x) and x.is_cuda
+
+
+def _foreign_device_array(x) -> bool:
+    """A device array of another library (cupy, a DLPack / `__cuda_array_interface__` producer): neither numpy, torch nor xarray."""
+    return (not _is_torch(x) and not isinstance(x, np.ndarray) and not hasattr(x, "dims")
+            and (hasattr(x, "__dlpack__") or hasattr(x, "__cuda_array_interface__")))
+
+
+def _same_kind(out, like):
+    """Hand a result (a torch tensor on the GPU) back as the kind of array the caller passed in -- the reference returns cupy arrays for
+    cupy input (gpu_compat.py:5-10: `get_array_module`).  Zero-copy through the producer's own DLPack consumer: its array-API namespace
+    (`like.__array_namespace__().from_dlpack`), its class (`type(like).from_dlpack`) or its module (`cupy.from_dlpack`), whichever it
+    has; a producer with none of them gets the torch tensor (documented in README: the buffer is shared, `torch.Tensor` is itself a
+    DLPack / `__cuda_array_interface__` producer)."""
+    if not _foreign_device_array(like) or not _is_torch(out):
+        return out
+    import sys
+    cands = []
+    ns = getattr(like, "__array_namespace__", None)
+    if callable(ns):
+        try:
+            cands.append(getattr(ns(), "from_dlpack", None))
+        except Exception:   # noqa: BLE001
+            pass
+    cands.append(getattr(type(like), "from_dlpack", None))
+    mod = sys.modules.get(type(like).__module__)
+    top = sys.modules.get(type(like).__module__.split(".")[0])
+    for m in (mod, top):
+        cands.append(getattr(m, "from_dlpack", None) if m is not None else None)
+    for fn in cands:
+        if callable(fn):
+            try:
+                return fn(out)
+            except Exception:   # noqa: BLE001  (e.g. a consumer that wants a capsule, not an object: try the next one)
+                continue
+    return out
 
 
 def _np_dtype_of(x):
@@ -98,6 +139,32 @@ def compute_dtype(arrays: Sequence) -> int:
 #     every call (~5 ms per 2400x3600 f64 plane), GCMF_PLAN_CACHE=0 rebuilds the plan on every call like the reference.
 _VERIFY_FULL = os.environ.get("GCMF_PLAN_CACHE_VERIFY", "sample") == "full"
 _CACHE_ON = os.environ.get("GCMF_PLAN_CACHE", "1") != "0"
+# The same three behaviours per Filter (keyword `plan_cache`, filter.py) instead of per process:
+#   "protect" (default)  cache the plan, write-protect the host grid planes it was folded from, sampled fingerprint per call
+#   "verify"             cache the plan, leave the planes WRITABLE, hash every plane on every call: an in-place edit of wet_mask between
+#                        two calls just works, as with the reference (a fresh plan is folded), for ~5 ms per 2400x3600 plane and call
+#   "off"                a fresh plan per call, like the reference's per-call Laplacian (gcm_filters/filter.py:183)
+PLAN_CACHE_MODES = ("protect", "verify", "off")
+_MODE = contextvars.ContextVar("gcmf_plan_cache_mode", default=None)
+
+
+def cache_mode() -> str:
+    m = _MODE.get()
+    if m is not None:
+        return m
+    return "protect" if _CACHE_ON else "off"   # (GCMF_PLAN_CACHE_VERIFY=full keeps the protection and hashes whole planes on top)
+
+
+@contextlib.contextmanager
+def plan_cache_mode(mode):
+    """Run the enclosed Laplacian constructions / calls under `mode` (None: the process default from the environment)."""
+    if mode is not None and mode not in PLAN_CACHE_MODES:
+        raise ValueError(f"plan_cache must be one of {PLAN_CACHE_MODES}, not {mode!r}")
+    tok = _MODE.set(mode)
+    try:
+        yield
+    finally:
+        _MODE.reset(tok)
 
 
 def _content_hash(a) -> int:
@@ -115,7 +182,7 @@ def _fingerprint(a) -> Tuple:
     on every filter call, 8 planes of a 2400x3600 grid cost ~40 us) -- or a hash of all of it (GCMF_PLAN_CACHE_VERIFY=full)."""
     if _is_torch(a):
         return ("t", a.data_ptr(), tuple(a.shape), tuple(a.stride()), str(a.dtype), a._version, str(a.device))
-    if _VERIFY_FULL:
+    if _VERIFY_FULL or cache_mode() == "verify":
         return ("n", a.__array_interface__["data"][0], a.shape, a.strides, a.dtype.str, _content_hash(a))
     n = a.size
     flat = a.reshape(-1) if a.flags.c_contiguous else a.ravel()
@@ -315,7 +382,7 @@ def clear_plan_cache():
 def kernels_cache_enabled() -> bool:
     """Plans are cached (GCMF_PLAN_CACHE != 0) and sampled verification is in use: callers may then reuse a Laplacian object
     for unchanged grid arrays (filter._LaplacianMemo); full verification re-hashes the planes on every call."""
-    return _CACHE_ON and not _VERIFY_FULL
+    return cache_mode() == "protect" and not _VERIFY_FULL
 
 
 _VALUE_ERRORS = {_lib.ERR_KAPPA_W_GT1, _lib.ERR_KAPPA_S_GT1, _lib.ERR_KAPPA_NONE_ONE}
@@ -408,6 +475,7 @@ class _DeviceLaplacian:
             self._levels[g] = type(self)(*sub, _skip_kappa_one=True)
 
     def _run_levels(self, fields, spec, out_f32, forward=False):
+        given = list(fields)
         fields = [_unwrap(f) for f in fields]
         shape = tuple(fields[0].shape)
         if len(shape) < 2:
@@ -431,7 +499,7 @@ class _DeviceLaplacian:
                     outs = [np.empty(out_lead + core, dtype=r.dtype) for r in res]
             for o, r in zip(outs, res):
                 o[idx] = r
-        return outs
+        return [_same_kind(o, g) for o, g in zip(outs, given)]
 
     # -- protocol ----------------------------------------------------------------------------
     @classmethod
@@ -464,13 +532,15 @@ class _DeviceLaplacian:
             except _lib.GcmfError as e:
                 raise _translate(e) from None
 
-        if not _CACHE_ON:   # the reference's behaviour: a fresh Laplacian (validation + precompute) per call
+        mode = cache_mode()
+        if mode == "off":   # the reference's behaviour: a fresh Laplacian (validation + precompute) per call
             old = getattr(self, "_own_plan", None)
             if old is not None:
                 old.close()
             self._own_plan = factory()
             return self._own_plan
-        return PLAN_CACHE.get(key, factory, () if on_gpu else self._planes)
+        # ("verify": the key holds a hash of every plane -- nothing to protect, the caller's arrays stay writable)
+        return PLAN_CACHE.get(key, factory, () if (on_gpu or mode == "verify") else self._planes)
 
     def _run(self, fields: Sequence, spec=None, out_f32: bool = False, forward: bool = False):
         """Shared driver of __call__ (spec None: one Laplacian) and of filter_func (spec: whole polynomial).
@@ -478,6 +548,7 @@ class _DeviceLaplacian:
         also for f32 state) even where the library would evaluate it backwards (Filter(evaluation="reference"))."""
         if self._levels is not None:
             return self._run_levels(fields, spec, out_f32, forward)
+        given = list(fields)
         fields = [_unwrap(f) for f in fields]
         shape = tuple(fields[0].shape)
         if len(shape) < 2:
@@ -510,7 +581,7 @@ class _DeviceLaplacian:
                 for t, f in zip(ins, fields):   # inputs converted above are temporaries: keep them alive until the stream is done
                     if t is not f:
                         t.record_stream(cur)
-            return outs
+            return [_same_kind(o, g) for o, g in zip(outs, given)]   # (cupy in, cupy out -- as the reference's gpu_compat path)
         plan = self._plan(dtype, (ny, nx))
         host = [f.detach().cpu().numpy() if _is_torch(f) else np.asarray(f) for f in fields]
         ins = [np.ascontiguousarray(f, dtype=_lib.np_dtype(dtype)) for f in host]

@@ -49,6 +49,9 @@ CASES_8 = [
     ("TRIPOLAR_REGULAR_WITH_LAND_AREA_WEIGHTED", (80, 16), 3, 2),
     ("REGULAR_WITH_LAND", (67, 16), 8, 1),           # uneven slabs (8 or 9 rows), halo as deep as a slab
     ("VECTOR_C_GRID", (64, 16), 3, 4),
+    # the batched strong-scaling workload of `bench.py --gpus 8` (round 5: `batched_strong`, --batch-levels): time levels through the slab path
+    ("TRIPOLAR_POP_WITH_LAND", (96, 16), 4, 8),
+    ("IRREGULAR_WITH_LAND", (64, 16), 2, 16),
 ]
 
 

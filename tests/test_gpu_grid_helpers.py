@@ -107,3 +107,35 @@ print("FRESH" if fresh else "STALE")
     dflt = run({})
     assert dflt.returncode == 0 and ("FRESH" in dflt.stdout or "STALE" in dflt.stdout), dflt.stdout + dflt.stderr
     # (sampled verification may or may not notice -- that is the documented hole; the two remedies above must)
+
+
+@pytest.mark.parametrize("mode", ["verify", "off"])
+def test_plan_cache_keyword_lets_a_drop_in_user_edit_the_mask_in_place(mode):
+    """the reference folds a fresh Laplacian per call (filter.py:183), so a user may edit wet_mask in place between two
+    calls.  Under the default the cached plan write-protects the planes (loud); Filter(plan_cache="verify" | "off") keeps them writable
+    and still filters with what the arrays hold NOW."""
+    f, gv = T.scalar_case("REGULAR_WITH_LAND", (64, 96))
+    flt = Filter(filter_scale=4.0, dx_min=1.0, grid_type=GridType.REGULAR_WITH_LAND, grid_vars=gv, plan_cache=mode)
+    a = flt.apply(f)
+    assert gv["wet_mask"].flags.writeable
+    gv["wet_mask"][10:30, 40:70] = 0
+    b = flt.apply(f)
+    want = O.filter_func(O.make_spec(4.0, 1.0), "REGULAR_WITH_LAND", f, {"wet_mask": np.asarray(gv["wet_mask"])})
+    assert np.abs(b - want).max() <= 1e-12 * np.abs(want).max() and np.abs(a - b).max() > 1e-3
+    again = flt.apply(f)
+    assert np.array_equal(b, again)
+
+
+def test_plan_cache_protect_is_the_default_and_says_so():
+    from gcm_filters_amd.kernels import clear_plan_cache
+    f, gv = T.scalar_case("REGULAR_WITH_LAND", (64, 96))
+    flt = Filter(filter_scale=4.0, dx_min=1.0, grid_type=GridType.REGULAR_WITH_LAND, grid_vars=gv)
+    assert flt.plan_cache is None
+    flt.apply(f)
+    assert not gv["wet_mask"].flags.writeable
+    with pytest.raises(ValueError, match="read-only"):
+        gv["wet_mask"][10, 40] = 0
+    clear_plan_cache()
+    assert gv["wet_mask"].flags.writeable
+    with pytest.raises(ValueError, match="plan_cache"):
+        Filter(filter_scale=4.0, dx_min=1.0, plan_cache="sometimes")

@@ -335,6 +335,93 @@ def test_device_resident_tensors():
     assert np.array_equal(out.cpu().numpy(), host)
 
 
+class _DLPackArray:
+    """A device-array library that is NOT torch (stand-in for cupy, which this image lacks): a DLPack producer over a device buffer,
+    with a module-level `from_dlpack` consumer like cupy's."""
+
+    def __init__(self, tensor):
+        self._t = tensor
+
+    def __dlpack__(self, stream=None):
+        return self._t.__dlpack__()
+
+    def __dlpack_device__(self):
+        return self._t.__dlpack_device__()
+
+    @property
+    def shape(self):
+        return tuple(self._t.shape)
+
+    @property
+    def dtype(self):
+        return self._t.dtype
+
+
+def from_dlpack(obj):   # (what `cupy.from_dlpack` is to cupy: found by gcm_filters_amd through the producer's module)
+    import torch
+    return _DLPackArray(torch.from_dlpack(obj))
+
+
+class _CAIArray:
+    """A `__cuda_array_interface__` producer without DLPack (numba-style), whose class knows how to consume DLPack."""
+
+    def __init__(self, tensor):
+        self._t = tensor
+
+    @property
+    def __cuda_array_interface__(self):
+        return self._t.__cuda_array_interface__
+
+    @classmethod
+    def from_dlpack(cls, obj):
+        import torch
+        return cls(torch.from_dlpack(obj))
+
+
+class _OpaqueCAIArray:
+    """... and one that offers no way back: the result is the torch tensor (documented in README)."""
+
+    def __init__(self, tensor):
+        self._t = tensor
+
+    @property
+    def __cuda_array_interface__(self):
+        return self._t.__cuda_array_interface__
+
+
+_OpaqueCAIArray.__module__ = "a_library_without_a_dlpack_consumer"   # (this test module HAS a `from_dlpack`, as cupy's has)
+
+
+@pytest.mark.parametrize("wrap", [_DLPackArray, _CAIArray, _OpaqueCAIArray])
+def test_foreign_device_arrays_come_back_as_their_own_kind(wrap):
+    """SURVEY 8 (f)2 / VERDICT r4 item 5: the reference returns cupy arrays for cupy input (gpu_compat.py:5-10).  A DLPack or
+    `__cuda_array_interface__` producer that is not torch is filtered in HBM (zero copy in) and handed back through ITS OWN DLPack
+    consumer -- module-level `from_dlpack` (cupy's), a `from_dlpack` classmethod, `__array_namespace__().from_dlpack` -- and as a torch
+    tensor only when it has none.  Scalar and vector Laplacians, and the bare Laplacian call."""
+    import torch
+    f, gv = T.scalar_case("IRREGULAR_WITH_LAND", (48, 64))
+    dx = T.grid_dx_min("IRREGULAR_WITH_LAND", gv)
+    flt = Filter(filter_scale=6 * dx, dx_min=dx, grid_type=GridType.IRREGULAR_WITH_LAND, grid_vars=gv)
+    want = flt.apply(torch.from_numpy(f).cuda())
+    out = flt.apply(wrap(torch.from_numpy(f).cuda()))
+    if wrap is _OpaqueCAIArray:
+        assert isinstance(out, torch.Tensor) and out.is_cuda
+        assert torch.equal(out, want)
+    else:
+        assert isinstance(out, wrap) and not isinstance(out, torch.Tensor)
+        assert torch.equal(out._t, want) and out._t.is_cuda
+    lap = ALL_KERNELS[GridType.IRREGULAR_WITH_LAND](**gv)(wrap(torch.from_numpy(f).cuda()))
+    assert isinstance(lap, torch.Tensor if wrap is _OpaqueCAIArray else wrap)
+    (u, v), gvv = T.vector_case("VECTOR_C_GRID", (40, 64))
+    dxv = T.grid_dx_min("VECTOR_C_GRID", gvv)
+    fv = Filter(filter_scale=4 * dxv, dx_min=dxv, grid_type=GridType.VECTOR_C_GRID, grid_vars=gvv)
+    wu, wv = fv.apply_to_vector(torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda())
+    gu, gw = fv.apply_to_vector(wrap(torch.from_numpy(u).cuda()), wrap(torch.from_numpy(v).cuda()))
+    for g, w in ((gu, wu), (gw, wv)):
+        assert isinstance(g, torch.Tensor if wrap is _OpaqueCAIArray else wrap)
+        assert torch.equal(g if wrap is _OpaqueCAIArray else g._t, w)
+
+
 # ---------------------------------------------------------------------------------------------------
 # temporal blocking (S recurrence steps per HBM pass) must be bit-identical to S single steps
 # ---------------------------------------------------------------------------------------------------

@@ -198,6 +198,26 @@ def test_reference_vectors_under_the_default_policy(name, golden_generated, monk
         assert ("k_resident<" in plan.last_kernel()) == expect, (name, n, plan.last_kernel())
 
 
+@pytest.mark.parametrize("grid", T.REFERENCE_TESTED_GRIDS)
+def test_reference_zarr_goldens_under_the_default_policy(grid, golden_zarr, monkeypatch):
+    """The reference's OWN nine filter goldens (upstream tests/test_data_filter/*.zarr, 128 x 256, Gaussian scale 8 = 9 levels) once more
+    with GCMF_RESIDENT unset: what a user gets by default for grids of this size -- the flux-form kinds run their nine
+    levels in one on-chip launch, the others the strip-marching / vector kernels."""
+    monkeypatch.delenv("GCMF_RESIDENT", raising=False)
+    if grid in T.VECTOR_GRIDS:
+        fields, gv = T.vector_case(grid)
+    else:
+        f, gv = T.scalar_case(grid)
+        fields = (f,)
+    flt = Filter(filter_scale=8.0, dx_min=1.0, filter_shape=FilterShape.GAUSSIAN, grid_type=GridType[grid], grid_vars=gv)
+    res = np.stack(flt.apply_to_vector(*fields)) if len(fields) == 2 else flt.apply(fields[0])
+    want = golden_zarr[f"test_data_filter/{grid}"]
+    np.testing.assert_allclose(want, res.astype("f4"), rtol=2e-7, atol=1e-30)
+    if grid == "IRREGULAR_WITH_LAND":
+        plan = ALL_KERNELS[GridType[grid]](**gv)._plan(_lib.F64, fields[0].shape)
+        assert "k_resident<" in plan.last_kernel(), plan.last_kernel()
+
+
 def _run_two_workers(tmp_path, seconds, extra_env):
     import json
     import subprocess
