@@ -618,7 +618,11 @@ int launch_cgrid_ring(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
   // loads S = 4: 388 (S = 5 spills: 280); LDS-direct loads S = 4: 407, S = 5: 490 (three rows in flight: one workgroup per CU, 412); one
   // wave per SIMD with S = 6 / 7 / 8: 378 / 264 / 256; eight levels per workgroup (coefficient rows fetched half as often, one barrier
   // for eight waves): 460; groups dealt to the XCDs 2 / 4 / 8 at a time or in contiguous ranges: 457 / 450 / 444 / 442; strips of
-  // 64 / 80 / 120 / 144 rows instead of 96: 448 / 461 / 468 / 459.  Only the two forms below are built.
+  // 64 / 80 / 120 / 144 rows instead of 96: 448 / 461 / 468 / 459.  Two attempts at the coefficient re-reads (the counters say the kernel
+  // moves 1.5 x its algorithmic bytes and that only half of the re-reads of a group's 13 workgroups hit in the L2 -- they start up to a
+  // fifth of a strip apart): the non-temporal hint on the state rows' loads, to leave the L2 to the coefficient rows: 388; a persistent
+  // launch of teams (416 workgroups, the 13 of a group walking through their strips together, no waiting between them): 365 -- both
+  // the same bits, both slower (profiles/r05/cfg5_*.txt).  Only the two forms below are built.
   if (pl->cgrid_ring >= 2 && pl->g.nx % 4 == 0) {   // LDS-direct loads: windows start on multiples of four cells
     switch (a.S) {
       case 4: return launch_cr<float, 4, 2, 2, true>(pl, a, s);

@@ -258,6 +258,51 @@ def test_dataarray_with_grid_vars_and_vector(xr_model):
     np.testing.assert_allclose(vo.data, wv, rtol=1e-12)
 
 
+def test_nondimensional_invariance(xr_model):
+    """upstream tests/test_filter.py:219-252: (filter_scale 4, dx_min 1) and (8, 2) are the same non-dimensional filter."""
+    xr = xr_model
+    ds = xr.Dataset(data_vars=dict(spatial=(("y", "x"), np.random.default_rng(1).normal(size=(40, 40)))),
+                    coords=dict(x=np.linspace(0, 1e6, 40), y=np.linspace(0, 1e6, 40)))
+    a = Filter(filter_scale=4, dx_min=1, filter_shape=FilterShape.GAUSSIAN, grid_type=GridType.REGULAR).apply(ds, ["y", "x"])
+    b = Filter(filter_scale=8, dx_min=2, filter_shape=FilterShape.GAUSSIAN, grid_type=GridType.REGULAR).apply(ds, ["y", "x"])
+    xr.testing.assert_allclose(a.spatial, b.spatial)
+
+
+def test_apply_ufunc_contract_of_the_model(xr_model):
+    """What the adapter relies on in xarray.apply_ufunc (reference filter.py:478-486), pinned on the model (README: "xarray semantics
+    assumed"): operands are aligned by dimension NAME, a grid variable with fewer dims arrives with fewer axes, one with dims in the
+    middle missing gets length-1 axes there, an operand without a core dim is an error, and so is a third name in `dims`."""
+    xr = xr_model
+    rng = np.random.default_rng(2)
+    nt, nz, ny, nx = 3, 4, 12, 16
+    fld = xr.DataArray(rng.normal(size=(nt, nz, ny, nx)), dims=["time", "z", "y", "x"])
+    mask3 = (rng.random((nz, ny, nx)) > 0.2).astype(float)          # a depth-dependent wet mask: (z, y, x)
+    mask3[:, 0, :] = 0
+    flt = Filter(filter_scale=3.0, dx_min=1.0, grid_type=GridType.REGULAR_WITH_LAND,
+                 grid_vars={"wet_mask": xr.DataArray(mask3, dims=["z", "y", "x"])})
+    out = flt.apply(fld, dims=["y", "x"])
+    assert out.dims == ("time", "z", "y", "x")
+    spec = O.make_spec(3.0, 1.0)
+    for k in range(nz):
+        np.testing.assert_allclose(out.data[1, k], O.filter_func(spec, "REGULAR_WITH_LAND", fld.data[1, k], {"wet_mask": mask3[k]}), rtol=1e-12)
+    # a (time, y, x) mask next to a (time, z, y, x) field: a length-1 axis is inserted where "z" is missing
+    mask_t = np.broadcast_to(mask3[0], (nt, ny, nx)).copy()
+    flt_t = Filter(filter_scale=3.0, dx_min=1.0, grid_type=GridType.REGULAR_WITH_LAND,
+                   grid_vars={"wet_mask": xr.DataArray(mask_t, dims=["time", "y", "x"])})
+    out_t = flt_t.apply(fld, dims=["y", "x"])
+    np.testing.assert_allclose(out_t.data[2, 3], O.filter_func(spec, "REGULAR_WITH_LAND", fld.data[2, 3], {"wet_mask": mask3[0]}), rtol=1e-12)
+    # dims in another order on the field: core dims are moved to the end, the others keep their order
+    out_p = flt.apply(xr.DataArray(fld.data.transpose(2, 0, 3, 1), dims=["y", "time", "x", "z"]), dims=["y", "x"])
+    assert out_p.dims == ("time", "z", "y", "x")
+    np.testing.assert_allclose(out_p.data, out.data, rtol=1e-12)
+    with pytest.raises(ValueError, match="core dimensions"):        # a field that lacks one of the dims
+        flt.apply(xr.DataArray(rng.normal(size=(nz, ny)), dims=["z", "y"]), dims=["y", "x"])
+    with pytest.raises(AssertionError):                             # reference filter.py:476: assert len(dims) == 2
+        flt.apply(fld, dims=["z", "y", "x"])
+    with pytest.raises(ValueError, match="mismatched lengths"):     # same name, other size
+        flt.apply(xr.DataArray(rng.normal(size=(nt, nz + 1, ny, nx)), dims=["time", "z", "y", "x"]), dims=["y", "x"])
+
+
 def test_plan_cache_fingerprint_and_host_outputs():
     """Host-side plumbing that runs on every call: the plan-cache key of a grid plane (address, layout, 256-value
     sample) and the result allocator (page-locked pool on a GPU box, plain numpy here)."""
