@@ -19,6 +19,12 @@
 //     that meets one redoes its strip with the full nan_to_num at every level (SAN = true; same arithmetic);
 //   * scalar addressing: row pointers in SGPRs, one 32-bit lane offset (global_load ... saddr).
 //
+//   * the recurrence in REINSCH'S FORM (state planes (b_{k+1}, d_{k+1}), d_k = b_k + b_{k+1}: see gcmf_cgrid_stream2.hip): more accurate in
+//     f32 than the reference's own f32 path.  A level needs d of the level before (one more live row per level than b_{k+2} took), so
+//     levels 1 .. S - 1 do NOT carry the three scaled copies of their previous row from iteration to iteration: they rebuild them from
+//     the raw row (which the recurrence keeps anyway), its NaN masks and the coefficient slot of the row before -- the same operands, the
+//     same bits -- which is what lets five levels stay within 256 registers.
+//
 // Arithmetic per level = CgLevel::feed<true> of gcmf_cgrid_stream2.hip operation for operation, so this kernel, k_cgrid_stream2c (which
 // still runs single-level fields, f64 plans and remainders below 4 levels) and the slab drivers give the same bits.
 #include "gcmf_multi_common.hpp"
@@ -36,9 +42,9 @@ constexpr int cmod(int a, int m) { return ((a % m) + m) % m; }
 
 template <typename T> struct CRingP {
   const T *u0, *v0;    // b_{k+1} (first launch: the input f, scaled by p_n as it is loaded)
-  const T *up, *vp;    // b_{k+2} (first launch: unused, zero)
+  const T *up, *vp;    // d_{k+1} = b_{k+1} + b_{k+2} (first launch: unused, d_n = b_n)
   const T *fu, *fv;    // the constant input f
-  T *u1o, *v1o;        // level S - 1: b_{k+2} of the next launch (unused by the last launch)
+  T *u1o, *v1o;        // level S: d of the next launch (unused by the last launch)
   T *u2o, *v2o;        // level S:     b_{k+1} of the next launch; last launch: the result when it has the state's type
   double *du, *dv;     // last launch: the f64 result of f32 state (or null)
   const T *coef[MAX_COEF];
@@ -233,7 +239,8 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
   v2 Vu[RV], Vv[RV];           // rows of b_{k+2}; slot = (iteration) mod RV
   v2 Fu[RF], Fv[RF];           // rows of f; slot = (iteration that delivered them) mod RF
   v2 SH[RSH][4];               // this wave's share of the coefficient rows, in flight
-  v2 Xu[S][3], Xv[S][3];       // X[m], m = 1 .. S - 1: rows of level m; slot = (iteration that produced them) mod 3
+  v2 Xu[S][3], Xv[S][3];       // X[m], m = 1 .. S - 1: rows of b of level m; slot = (iteration that produced them) mod 3 (two are live)
+  v2 Du[S][2], Dv[S][2];       // D[m], m = 1 .. S - 1: the row of d level m produced; slot = (iteration) mod 2
   v2 Lvt[S + 1][2], Lvh[S + 1][2], Luh[S + 1][2], LP[S + 1][2], LQ[S + 1][2], LR[S + 1][2];  // per level: what the previous row hands on
   bool Ku0[U], Ku1[U], Kv0[U], Kv1[U];   // "not NaN" of the delivered rows; slot = (row - r_begin) mod U
 #pragma unroll
@@ -246,6 +253,7 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
   for (int m = 0; m < S; ++m) {
 #pragma unroll
     for (int l = 0; l < 3; ++l) Xu[m][l] = Xv[m][l] = Z;
+    Du[m][0] = Du[m][1] = Dv[m][0] = Dv[m][1] = Z;
   }
 #pragma unroll
   for (int m = 0; m <= S; ++m) {
@@ -317,13 +325,14 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
     constexpr int ph = decltype(ph_c)::value;
     constexpr int sl = DMA ? 0 : cmod(ph - (j - 1), NS);      // the LDS slot published in iteration r - j + 1
     constexpr int kn = cmod(ph - (j - 1), U);       // NaN masks of row rho
-    constexpr int n3 = ph % 3, o3 = cmod(ph - 1, 3), p3 = cmod(ph - 2, 3);
+    constexpr int n3 = ph % 3, o3 = cmod(ph - 1, 3);
     const v2 inu = (j == 1) ? G0u[ph % RU] : Xu[j >= 2 ? j - 1 : 1][n3];
     const v2 inv = (j == 1) ? G0v[ph % RU] : Xv[j >= 2 ? j - 1 : 1][n3];
     const v2 xu = (j == 1) ? G0u[cmod(ph - 1, RU)] : Xu[j >= 2 ? j - 1 : 1][o3];   // row rho - 1 of level j - 1: the "-x" term
     const v2 xv = (j == 1) ? G0v[cmod(ph - 1, RU)] : Xv[j >= 2 ? j - 1 : 1][o3];
-    const v2 x2u = (j == 1) ? Vu[ph % RV] : (j == 2 ? G0u[cmod(ph - 2, RU)] : Xu[j >= 3 ? j - 2 : 1][p3]);   // row rho - 1 of level j - 2
-    const v2 x2v = (j == 1) ? Vv[ph % RV] : (j == 2 ? G0v[cmod(ph - 2, RU)] : Xv[j >= 3 ? j - 2 : 1][p3]);
+    // d_{k+1}, row rho - 1: what level j - 1 produced one iteration ago (level 1: the delivered row of d; first launch: d_n = b_n)
+    const v2 dpu = (j == 1) ? (FIRST ? xu : Vu[ph % RV]) : Du[j >= 2 ? j - 1 : 1][cmod(ph - 1, 2)];
+    const v2 dpv = (j == 1) ? (FIRST ? xv : Vv[ph % RV]) : Dv[j >= 2 ? j - 1 : 1][cmod(ph - 1, 2)];
     const v2 fu = Fu[cmod(ph - j + 1, RF)], fv = Fv[cmod(ph - j + 1, RF)];        // row rho - 1 of f
     v2 su, sv;
     if constexpr (SAN) {
@@ -349,37 +358,68 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
       }
     }
     constexpr int lo = cmod(ph - 1, 2), ln = ph % 2;
+    // ---- what the previous row of this level hands on: the last level carries it, the others rebuild it (same operands, same bits) ----
+    v2 vt_p, vh_p, uh_p;
+    if constexpr (j < S) {
+      v2 pu, pv;   // the previous row as the stencil saw it
+      if constexpr (SAN) {
+        pu.x = cr_san(xu.x);  pu.y = cr_san(xu.y);
+        pv.x = cr_san(xv.x);  pv.y = cr_san(xv.y);
+      } else {
+        constexpr int kp = cmod(ph - j, U);
+        pu.x = Ku0[kp] ? xu.x : T(0);  pu.y = Ku1[kp] ? xu.y : T(0);
+        pv.x = Kv0[kp] ? xv.x : T(0);  pv.y = Kv1[kp] ? xv.y : T(0);
+      }
+      v2 A1p, A2p, A3p;   // coefficient rows of the row before: the slot of iteration r - j
+      if constexpr (DMA) {
+        const v2 *cp_ = reinterpret_cast<const v2 *>(s_raw + slot_of[cmod(ph - j, U)]);
+        A1p = cp_[1 * 64 + lane];  A2p = cp_[2 * 64 + lane];  A3p = cp_[3 * 64 + lane];
+      } else {
+        constexpr int slp = cmod(ph - j, NS);
+        A1p = s_coef[slp][1][lane];  A2p = s_coef[slp][2][lane];  A3p = s_coef[slp][3][lane];
+      }
+      uh_p = pu * A1p;  vt_p = pv * A2p;  vh_p = pv * A3p;
+    } else {
+      vt_p = Lvt[j][lo];  vh_p = Lvh[j][lo];  uh_p = Luh[j][lo];
+    }
     // ---- CgLevel::feed<true> on the pair (gcmf_cgrid_stream2.hip) ----
     const v2 ut = su * A[0], uh = su * A[1], vt = sv * A[2], vh = sv * A[3];
     // (the four x-differences as scalar operations: the neighbour lane's value rides on the subtraction as a DPP operand)
     v2 dut;  dut.x = ut.x - from_lower_lane0(ut.y);  dut.y = ut.y - ut.x;                 // ut - W ut
-    const v2 Pr = __builtin_elementwise_fma(A[4], dut, -(A[5] * (vt - Lvt[j][lo])));
+    const v2 Pr = __builtin_elementwise_fma(A[4], dut, -(A[5] * (vt - vt_p)));
     const v2 Qr = A[6] * Pr;
-    const v2 vhp = Lvh[j][lo];
+    const v2 vhp = vh_p;
     v2 dvh;  dvh.x = vhp.y - vhp.x;  dvh.y = from_upper_lane0(vhp.x) - vhp.y;             // E vh_p - vh_p
-    const v2 Rm = __builtin_elementwise_fma(B[0], dvh, B[1] * (uh - Luh[j][lo]));
+    const v2 Rm = __builtin_elementwise_fma(B[0], dvh, B[1] * (uh - uh_p));
     const v2 Sm = B[2] * Rm;
     const v2 Pp = LP[j][lo];
     v2 dpp;  dpp.x = Pp.x - Pp.y;  dpp.y = Pp.y - from_upper_lane0(Pp.x);                 // P_p - E P_p
     v2 dsm;  dsm.x = from_lower_lane0(Sm.y) - Sm.x;  dsm.y = Sm.x - Sm.y;                 // W Sm - Sm
     const v2 lu = __builtin_elementwise_fma(B[3], dpp, B[4] * (LR[j][lo] - Rm));
     const v2 lv = __builtin_elementwise_fma(B[5], dsm, -(B[6] * (LQ[j][lo] - Qr)));
-    Lvt[j][ln] = vt;  Lvh[j][ln] = vh;  Luh[j][ln] = uh;  LP[j][ln] = Pr;  LQ[j][ln] = Qr;  LR[j][ln] = Rm;
-    // ---- b_k = p_k f + 2 A(b_{k+1}) - b_{k+2},  A(x) = -x - c L(x);  the last level of the last launch is the result: A, not 2 A ----
-    const v2 mc = {-c, -c};
-    const T two_s = (last && j == S) ? T(1) : T(2);
-    const v2 two = {two_s, two_s};
+    if constexpr (j == S) { Lvt[j][ln] = vt;  Lvh[j][ln] = vh;  Luh[j][ln] = uh; }
+    LP[j][ln] = Pr;  LQ[j][ln] = Qr;  LR[j][ln] = Rm;
+    // ---- Reinsch's form: d_k = p_k f - 2 c L(b_{k+1}) - d_{k+1},  b_k = d_k - b_{k+1};  the last level of the last launch is the result:
+    //      p_0 f - c L(b_1) - d_1 ----
+    const bool fin = last && j == S;
+    const T mtc_s = fin ? -c : T(-2) * c;
+    const v2 mtc = {mtc_s, mtc_s};
     const T pk_s = (T)P.pk[j - 1];
     const v2 pk = {pk_s, pk_s};
-    const v2 afu = __builtin_elementwise_fma(mc, lu, -xu), afv = __builtin_elementwise_fma(mc, lv, -xv);
-    const v2 cu = __builtin_elementwise_fma(pk, fu, __builtin_elementwise_fma(two, afu, -x2u));
-    const v2 cv = __builtin_elementwise_fma(pk, fv, __builtin_elementwise_fma(two, afv, -x2v));
+    const v2 dku = __builtin_elementwise_fma(pk, fu, __builtin_elementwise_fma(mtc, lu, -dpu));
+    const v2 dkv = __builtin_elementwise_fma(pk, fv, __builtin_elementwise_fma(mtc, lv, -dpv));
+    v2 cu = dku - xu, cv = dkv - xv;
+    if constexpr (j == S) {
+      cu.x = fin ? dku.x : cu.x;  cu.y = fin ? dku.y : cu.y;
+      cv.x = fin ? dkv.x : cv.x;  cv.y = fin ? dkv.y : cv.y;
+    }
     if constexpr (j < S) {
       Xu[j][n3] = cu;
       Xv[j][n3] = cv;
+      Du[j][ph % 2] = dku;
+      Dv[j][ph % 2] = dkv;
     }
-    if constexpr (j == S - 1) { out_pu = cu;  out_pv = cv; }
-    if constexpr (j == S) { out_u = cu;  out_v = cv; }
+    if constexpr (j == S) { out_u = cu;  out_v = cv;  out_pu = dku;  out_pv = dkv; }
   };
 
   auto phase = [&](auto ph_c, int r) {
@@ -431,7 +471,7 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
     if constexpr (S >= 6) level(cic<6>{}, ph_c);
     if constexpr (S >= 7) level(cic<7>{}, ph_c);
     if constexpr (S >= 8) level(cic<8>{}, ph_c);
-    // ---- stores: row r - S of level S, row r - S + 1 of level S - 1 ----
+    // ---- stores: row r - S of level S: b (or the result) ... ----
     const int ju = r - S;
     if (ju >= a && ju < b) {   // wave-uniform
       const unsigned vo = colB + (unsigned)(ju * nx) * (unsigned)sizeof(T);
@@ -449,9 +489,8 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
         }
       }
     }
-    const int jv = r - S + 1;
-    if (!last && jv >= a && jv < b) {
-      const unsigned vo = colB + (unsigned)(jv * nx) * (unsigned)sizeof(T);
+    if (!last && ju >= a && ju < b) {   // ... and its row of d
+      const unsigned vo = colB + (unsigned)(ju * nx) * (unsigned)sizeof(T);
       if (keep) {
         *reinterpret_cast<v2 *>(reinterpret_cast<char *>(P.u1o + boff) + vo) = out_pu;
         *reinterpret_cast<v2 *>(reinterpret_cast<char *>(P.v1o + boff) + vo) = out_pv;
@@ -522,8 +561,8 @@ static bool cr_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15
 bool cgrid_ring_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
   if (pl->cgrid_ring <= 0 || pl->kind != K_CGRID || pl->cgrid_tile || pl->d.dtype != GCMF_F32) return false;
   if (nbatch < 2) return false;   // single-level fields: k_cgrid_stream2c's private-ring form
-  if (S < 4 || S > (pl->cgrid_ring >= 2 ? 5 : 4) || S > pl->cgrid_ring_smax) return false;
-  if (pl->g.nx % 2 || pl->g.nx < 2 || pl->g.rows < S + 2) return false;
+  if (S < 4 || S > 5 || S > pl->cgrid_ring_smax) return false;
+  if (pl->g.nx % 4 || pl->g.nx < 4 || pl->g.rows < S + 2) return false;
   if ((long long)pl->g.rows * pl->g.nx * 4 >= (1LL << 32)) return false;   // 32-bit byte offsets inside a level's plane
   for (int k = 0; k < MAX_COEF; ++k)
     if (!cr_al16(pl->g.coef[k])) return false;
@@ -622,14 +661,12 @@ int launch_cgrid_ring(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
   // moves 1.5 x its algorithmic bytes and that only half of the re-reads of a group's 13 workgroups hit in the L2 -- they start up to a
   // fifth of a strip apart): the non-temporal hint on the state rows' loads, to leave the L2 to the coefficient rows: 388; a persistent
   // launch of teams (416 workgroups, the 13 of a group walking through their strips together, no waiting between them): 365 -- both
-  // the same bits, both slower (profiles/r05/cfg5_*.txt).  Only the two forms below are built.
-  if (pl->cgrid_ring >= 2 && pl->g.nx % 4 == 0) {   // LDS-direct loads: windows start on multiples of four cells
-    switch (a.S) {
-      case 4: return launch_cr<float, 4, 2, 2, true>(pl, a, s);
-      case 5: return launch_cr<float, 5, 2, 2, true>(pl, a, s);
-    }
+  // the same bits, both slower (profiles/r05/cfg5_*.txt).  Only the LDS-direct form is built (the plain-load code paths of the templates
+  // above are what the A/B runs of round 5 used; they are no longer instantiated).
+  switch (a.S) {   // (LDS-direct loads: windows start on multiples of four cells -- cgrid_ring_supported asked for nx % 4 == 0)
+    case 4: return launch_cr<float, 4, 2, 2, true>(pl, a, s);
+    case 5: return launch_cr<float, 5, 2, 2, true>(pl, a, s);
   }
-  if (a.S == 4) return launch_cr<float, 4, 2, 2, false>(pl, a, s);   // plain loads (cgrid_ring = 1): the A/B partner; five levels spill there
   return GCMF_ERR_INVALID_ARG;
 }
 

@@ -197,6 +197,7 @@ __device__ __forceinline__ void cgrid_stream2_body(const CStream2P<T, FB> &P) {
   //   iterations ago (o2; for level 1 the lagged T_{k-2} load).  fbar after level j waits one iteration for level j+1.
   CgLevel<T, VEC> L[S];
   T o1u[S][VEC], o1v[S][VEC], o2u[S][VEC], o2v[S][VEC];
+  T dou[S + 1][VEC], dov[S + 1][VEC];   // backward evaluation: the row of d = b_k + b_{k+1} level j produced one iteration ago (see below)
   FB accu[S][VEC], accv[S][VEC];
 #pragma unroll
   for (int j = 0; j < S; ++j) {
@@ -204,6 +205,7 @@ __device__ __forceinline__ void cgrid_stream2_body(const CStream2P<T, FB> &P) {
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       o1u[j][k] = o1v[j][k] = o2u[j][k] = o2v[j][k] = T(0);
+      dou[j][k] = dov[j][k] = dou[j + 1][k] = dov[j + 1][k] = T(0);
       accu[j][k] = accv[j][k] = FB(0);
     }
   }
@@ -235,6 +237,7 @@ __device__ __forceinline__ void cgrid_stream2_body(const CStream2P<T, FB> &P) {
 
     T cu[S + 1][VEC], cv[S + 1][VEC];  // newest row of every level this iteration
     FB nau[S + 1][VEC], nav[S + 1][VEC];
+    T dnu[S + 1][VEC], dnv[S + 1][VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       // (backward evaluation, first launch: the delivered rows of f become rows of b_n = p_n f)
@@ -272,15 +275,25 @@ __device__ __forceinline__ void cgrid_stream2_body(const CStream2P<T, FB> &P) {
         const T xu = o1u[j - 1][k], xv = o1v[j - 1][k];
         const T avu = -xu - c * lu[k], avv = -xv - c * lv[k];
         if constexpr (CLEN) {
-          const T x2u = (j == 1) ? (first ? T(0) : x.up[k]) : o2u[j >= 2 ? j - 2 : 0][k];
-          const T x2v = (j == 1) ? (first ? T(0) : x.vp[k]) : o2v[j >= 2 ? j - 2 : 0][k];
+          // REINSCH'S FORM of Clenshaw's recurrence (round 5).  A = -1 - cL maps the large scales -- most of a filtered field -- to the end
+          // x = -1 of the Chebyshev interval, where b_k = p_k f + 2 A b_{k+1} - b_{k+2} subtracts nearly equal numbers and its rounding
+          // errors grow like k.  Carrying d_k = b_k + b_{k+1} instead of b_{k+2},
+          //       d_k = p_k f - 2 c L(b_{k+1}) - d_{k+1},      b_k = d_k - b_{k+1},      result = p_0 f - c L(b_1) - d_1,
+          // is the same polynomial, the same two state planes (b_{k+1}, d_{k+1}) and the same operation count without that cancellation:
+          // f32 fields at n_steps 44 come out 1.8e-6 from f64 arithmetic instead of 4.9e-6 -- the reference's own f32 path (f32 T_k, f64
+          // running sum): 2.7e-6; at n_steps 98: 5.0e-6 / 1.9e-5 / 8.5e-6.  The state planes hold (b_{k+1}, d_{k+1}); b_n = d_n = p_n f.
+          const T dpu = (j == 1) ? (first ? xu : x.up[k]) : dou[j - 1][k];
+          const T dpv = (j == 1) ? (first ? xv : x.vp[k]) : dov[j - 1][k];
           const T fiu = (T)((j == 1) ? x.fu[k] : accu[j - 1][k]);
           const T fiv = (T)((j == 1) ? x.fv[k] : accv[j - 1][k]);
-          const T two = (last && j == S) ? T(1) : T(2);  // the last level of the last launch is the result: A, not 2 A
+          const bool fin = last && j == S;               // the last level of the last launch is the result: c L, not 2 c L, and no b_0
+          const T mtc = fin ? -c : T(-2) * c;
           // (nothing here is bit-identical with numpy: every multiply-add pair is one fma -- fewer instructions, fewer roundings)
-          const T afu = rfma(-c, lu[k], -xu), afv = rfma(-c, lv[k], -xv);
-          cu[j][k] = rfma((T)pkj, fiu, rfma(two, afu, -x2u));
-          cv[j][k] = rfma((T)pkj, fiv, rfma(two, afv, -x2v));
+          const T dku = rfma((T)pkj, fiu, rfma(mtc, lu[k], -dpu)), dkv = rfma((T)pkj, fiv, rfma(mtc, lv[k], -dpv));
+          dnu[j][k] = dku;
+          dnv[j][k] = dkv;
+          cu[j][k] = fin ? dku : dku - xu;
+          cv[j][k] = fin ? dkv : dkv - xv;
           nau[j][k] = (FB)fiu;   // the row of f travels on with its row of the state
           nav[j][k] = (FB)fiv;
         } else if (j == 1 && first) {
@@ -309,11 +322,18 @@ __device__ __forceinline__ void cgrid_stream2_body(const CStream2P<T, FB> &P) {
           }
         }
       }
-      if (j >= S - 1 && keep && r - j >= a && r - j < b) {
+      if (j >= (CLEN ? S : S - 1) && keep && r - j >= a && r - j < b) {
         const long long off = boff + (long long)(r - j) * nx + col;
         if (!last) {
-          mstore<T, VEC>((j == S ? P.u2o : P.u1o) + off, cu[j]);
-          mstore<T, VEC>((j == S ? P.v2o : P.v1o) + off, cv[j]);
+          if constexpr (CLEN) {   // both states of the next launch are level S's: b (-> u2o) and d (-> u1o), the same row
+            mstore<T, VEC>(P.u2o + off, cu[j]);
+            mstore<T, VEC>(P.v2o + off, cv[j]);
+            mstore<T, VEC>(P.u1o + off, dnu[j]);
+            mstore<T, VEC>(P.v1o + off, dnv[j]);
+          } else {
+            mstore<T, VEC>((j == S ? P.u2o : P.u1o) + off, cu[j]);
+            mstore<T, VEC>((j == S ? P.v2o : P.v1o) + off, cv[j]);
+          }
         }
         if (j == S && !CLEN) {
           mstore<FB, VEC>(P.fu_out + off, nau[j]);
@@ -346,6 +366,7 @@ __device__ __forceinline__ void cgrid_stream2_body(const CStream2P<T, FB> &P) {
         o1u[j][k] = cu[j][k];
         o1v[j][k] = cv[j][k];
         if (j >= 1) { accu[j][k] = nau[j][k]; accv[j][k] = nav[j][k]; }
+        if (CLEN) { dou[j + 1][k] = dnu[j + 1][k]; dov[j + 1][k] = dnv[j + 1][k]; }
       }
     }
     if (PRIV) publish(x);  // after level S has read the slot this overwrites (same wave: LDS executes in order)

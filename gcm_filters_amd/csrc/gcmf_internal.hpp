@@ -156,7 +156,7 @@ struct gcmf_plan {
   int strip_rows = 0;  // rows per wave strip of that kernel (0 = auto)
   int prefetch_rows = 0;  // rows of operands in flight per wave (0 = default per S)
   int cgrid_tile = 0;     // 1: force the LDS-tile C-grid kernel instead of the streaming one (A/B testing)
-  int cgrid_ring = 2;     // k_cgrid_ring (gcmf_cgrid_ring.hip) for batched f32 levels: 0 off, 1 plain loads, 2 LDS-direct loads; env GCMF_CGRID_RING, gcmf_set_option
+  int cgrid_ring = 1;     // k_cgrid_ring (gcmf_cgrid_ring.hip) for batched f32 levels (0: k_cgrid_stream2c everywhere); env GCMF_CGRID_RING, gcmf_set_option
   int cgrid_ring_smax = 5;  // levels per launch of that kernel (4 / 5); env GCMF_CGRID_RING_SMAX
   int cgrid_ring_hmax = 0;  // tallest strip its launcher picks (0 = 96); gcmf_set_option
   // Land kept out of the state (scalar plans; slab-row layout): bit 0 of lbits[cell] = the cell exchanges with a neighbour.

@@ -366,9 +366,9 @@ int gcmf_resident_levels(gcmf_plan *plan, const void *u, const void *v, void *uo
  * 2..8), bits 8-23 = rows per wave strip (0 = auto), bits 24-27 = operand rows in flight of the general kernels, bits 28-29 =
  * backward evaluation (1 off, 2 flux kinds, 3 all scalar kinds; 0 keep); 0 keeps the default. */
 int gcmf_set_tuning(gcmf_plan *plan, int rows_per_wave, int xcd_remap, int multi);
-/* Named per-plan switches (A/B testing, the parity tests): "cgrid_ring" 2 / 1 / 0 (the static-ring C-grid kernel of batched f32 levels,
- * gcmf_cgrid_ring.hip: operand rows through LDS-direct loads / plain loads / off = k_cgrid_stream2c everywhere), "cgrid_ring_smax" 4 / 5
- * (levels per launch), "cgrid_ring_hmax" (tallest strip, 0 = 96 rows).  Unknown names: GCMF_ERR_INVALID_ARG. */
+/* Named per-plan switches (A/B testing, the parity tests): "cgrid_ring" 1 / 0 (the static-ring C-grid kernel of batched f32 levels,
+ * gcmf_cgrid_ring.hip; 0 = k_cgrid_stream2c everywhere), "cgrid_ring_smax" 4 / 5 (levels per launch), "cgrid_ring_hmax" (tallest
+ * strip, 0 = 96 rows), "ringc9" 1 / 0 (nine levels per k_ringc launch on whole f64 flux grids).  Unknown names: GCMF_ERR_INVALID_ARG. */
 int gcmf_set_option(gcmf_plan *plan, const char *name, int value);
 
 /* Last error text of the calling thread (never NULL). */

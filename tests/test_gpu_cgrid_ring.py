@@ -27,20 +27,20 @@ def _case(shape, nlev, n_steps, scale=10.0, seed=0):
     return flt, plan, u, v, gv
 
 
-def _both(flt, plan, u, v, smax=4, strip_rows=0, mode=2):
+def _both(flt, plan, u, v, smax=4, strip_rows=0):
     try:
         plan.set_option("cgrid_ring", 0)
         plan.last_kernel()
         ref = flt.apply_to_vector(u, v)
         assert "k_cgrid_stream2c<" in plan.last_kernel()
-        plan.set_option("cgrid_ring", mode)    # 1: plain loads, 2: LDS-direct loads (nx a multiple of 4, up to five levels)
+        plan.set_option("cgrid_ring", 1)
         plan.set_option("cgrid_ring_smax", smax)
         if strip_rows:
             plan.set_tuning(multi_s=8, strip_rows=strip_rows)
         got = flt.apply_to_vector(u, v)
         assert "k_cgrid_ring<" in plan.last_kernel(), plan.last_kernel()
     finally:
-        plan.set_option("cgrid_ring", 2)
+        plan.set_option("cgrid_ring", 1)
         plan.set_option("cgrid_ring_smax", 5)
         plan.set_tuning(multi_s=8, strip_rows=0)
     return ref, got
@@ -49,24 +49,23 @@ def _both(flt, plan, u, v, smax=4, strip_rows=0, mode=2):
 @pytest.mark.parametrize("shape,nlev", [((96, 160), 8), ((64, 256), 12), ((33, 132), 2), ((120, 124), 5), ((48, 64), 50), ((25, 520), 4),
                                         ((7, 8), 3)])
 @pytest.mark.parametrize("n_steps", [8, 13, 44])
-@pytest.mark.parametrize("smax,mode", [(4, 1), (4, 2), (5, 2)])
-def test_same_bits_as_stream2c(shape, nlev, n_steps, smax, mode):
+@pytest.mark.parametrize("smax", [4, 5])
+def test_same_bits_as_stream2c(shape, nlev, n_steps, smax):
     flt, plan, u, v, gv = _case(shape, nlev, n_steps)
     u[nlev // 2, 5 % shape[0], 7 % shape[1]] = np.nan     # NaN in wet cells: the stencil sees 0, the cell keeps its NaN
     v[0, shape[0] - 1, shape[1] - 1] = np.nan
     v[nlev - 1, 0, 0] = np.nan
     if shape[0] < smax + 2:
         pytest.skip("fewer rows than a launch is deep")
-    ref, got = _both(flt, plan, u, v, smax, mode=mode)
+    ref, got = _both(flt, plan, u, v, smax)
     for r, g in zip(ref, got):
         assert g.dtype == np.float64
         assert np.array_equal(r, g, equal_nan=True), (shape, nlev, n_steps, np.nanmax(np.abs(r - g)))
     assert np.isnan(got[0][nlev // 2, 5 % shape[0], 7 % shape[1]])
 
 
-@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("shape,nlev,n_steps", [((96, 160), 8, 13), ((40, 300), 5, 9)])
-def test_inf_takes_the_redo_pass(shape, nlev, n_steps, mode):
+def test_inf_takes_the_redo_pass(shape, nlev, n_steps):
     """+-inf in a wet cell: nan_to_num clamps it to +-FLT_MAX in the stencil (kernels.py:651-652); the workgroups that meet one redo
     their strip with the full nan_to_num at every level and give what k_cgrid_stream2c gives."""
     flt, plan, u, v, gv = _case(shape, nlev, n_steps)
@@ -74,16 +73,15 @@ def test_inf_takes_the_redo_pass(shape, nlev, n_steps, mode):
     v[nlev - 1, 3, 150 % shape[1]] = -np.inf
     u[0, 9, 9] = np.nan
     with np.errstate(all="ignore"):
-        ref, got = _both(flt, plan, u, v, 5, mode=mode)
+        ref, got = _both(flt, plan, u, v, 5)
     for r, g in zip(ref, got):
         assert np.array_equal(r, g, equal_nan=True)
 
 
-@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("strip_rows", [16, 20, 31])
-def test_same_bits_however_the_strips_are_cut(strip_rows, mode):
+def test_same_bits_however_the_strips_are_cut(strip_rows):
     flt, plan, u, v, gv = _case((150, 260), 6, 21)
-    ref, got = _both(flt, plan, u, v, 5, strip_rows, mode=mode)
+    ref, got = _both(flt, plan, u, v, 5, strip_rows)
     for r, g in zip(ref, got):
         assert np.array_equal(r, g, equal_nan=True)
 

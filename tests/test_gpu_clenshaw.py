@@ -284,8 +284,8 @@ def _rel2(a, b):
 @pytest.mark.parametrize("n_steps,scale", [(44, 40), (63, 57), (98, 90), (125, 114)])
 def test_cgrid_f32_precision_policy(n_steps, scale):
     """float32 C-grid fields.  The reference carries T_k in f32 and the running sum in f64; the default here
-    (evaluation="auto": Clenshaw, everything in f32) must stay in the accuracy class of the reference's OWN f32 path measured against
-    f64 arithmetic -- within 2 x its error, growing linearly with n_steps like it (DESIGN.md 3.4 has the table) -- and
+    (evaluation="auto": Clenshaw's recurrence in Reinsch's form, everything in f32) must be AT LEAST as close to f64 arithmetic as the
+    reference's OWN f32 path is (measured 0.55-0.6 x its error; DESIGN.md 3.4 has the table), growing linearly with n_steps like it -- and
     Filter(evaluation="reference") must run the reference's scheme (forward kernel, f64 running sum) without any env var."""
     flts, plan, u, v, ref, truth = _cgrid_f32_case((96, 160), 8, n_steps, scale)
     e_ref = _rel2(ref, truth)                       # what f32 state costs the reference itself: 3e-6 (n 44) ... 1.3e-5 (n 125)
@@ -298,8 +298,8 @@ def test_cgrid_f32_precision_policy(n_steps, scale):
     print(f"n_steps {n_steps}: error against f64 arithmetic -- reference's f32 path {e_ref:.2e}, evaluation='reference' {e_fwd:.2e}, "
           f"'auto' (backward, f32) {e_auto:.2e}; 'auto' against the reference's f32 result {_rel2(got, ref):.2e}")
     assert e_fwd <= 1.5 * e_ref + 1e-6              # the same scheme as the reference: the same error
-    assert e_auto <= 2.0 * e_ref + 1e-6             # the default: same class (measured 1.4-1.8 x)
-    assert e_auto <= 2.5e-5 and _rel2(got, ref) <= 3e-5   # absolute ceilings at the longest polynomial of the tutorials (SURVEY 8d gate: 1e-4)
+    assert e_auto <= 0.8 * e_ref                    # the default: closer to f64 arithmetic than the reference's f32 path (measured 0.55-0.6 x)
+    assert e_auto <= 1e-5 and _rel2(got, ref) <= 2e-5   # absolute ceilings at the longest polynomial of the tutorials (SURVEY 8d gate: 1e-4)
 
 
 def test_evaluation_option_reaches_the_plan_for_scalar_grids_too():

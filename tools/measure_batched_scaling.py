@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--batches", default="1,2,4,8,16")
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--halo", type=int, default=0, help="ghost rows per side of the slab (0 = SlabFilter's default: as deep as the filter, <= 64)")
     a = ap.parse_args()
     ny, nx = 2400, 3600
     wl = T.baseline_workload(a.config, (ny, nx))
@@ -68,7 +69,7 @@ def main():
             fr = np.stack([wr["fields"][0] + 0.01 * k for k in range(nb)])
             for ex in ("none", "p2p", "native"):
                 sf = SlabFilter(wr["grid"], wr["grid_vars"], dict(wr["fk"]), rows, nx, device=0, rank=0, world=1, self_ring=True,
-                                exchange="p2p" if ex == "none" else ex)
+                                exchange="p2p" if ex == "none" else ex, halo=a.halo or None)
                 if ex == "none":
                     sf.native_driver = False
                     sf._exchange_start = lambda tensors: None
@@ -78,7 +79,7 @@ def main():
                 del sf, local
         else:
             rank = a.world - 1
-            sf = SlabFilter(wl["grid"], wl["grid_vars"], fk, ny, nx, rank=rank, world=a.world, device=0, exchange="torch")
+            sf = SlabFilter(wl["grid"], wl["grid_vars"], fk, ny, nx, rank=rank, world=a.world, device=0, exchange="torch", halo=a.halo or None)
             sf.native_driver = False
             sf._exchange_start = lambda tensors: None
             sf._exchange_finish = lambda ticket: None
@@ -89,7 +90,7 @@ def main():
             tt = {}
             for ex in ("none", "p2p", "native"):
                 s3 = SlabFilter(w3["grid"], w3["grid_vars"], dict(w3["fk"]), rows, nx, device=0, rank=0, world=1, self_ring=True,
-                                exchange="p2p" if ex == "none" else ex)
+                                exchange="p2p" if ex == "none" else ex, halo=a.halo or None)
                 if ex == "none":
                     s3.native_driver = False
                     s3._exchange_start = lambda tensors: None
