@@ -14,6 +14,10 @@
 // backwards, b_k = p_k f + 2 A(b_{k+1}) - b_{k+2} (gcmf_ringc_impl.hpp) -- the conveyor that carries fbar from level to level carries the
 // row of the constant input instead, nothing is accumulated, only the last launch writes a result: 4w + 2w (+ coefficients) read and 4w
 // written per cell and level instead of 4w + 2f / 4w + 2f, every multiply-add pair one fma.  Not bit-identical with numpy (<= 1e-14).
+// Round 5: in REINSCH's form -- the state planes hold b_{k+1} and d_{k+1} = b_{k+1} + b_{k+2}; d_k = p_k f - 2c L(b_{k+1}) - d_{k+1},
+// b_k = d_k - b_{k+1}, result = p_0 f - c L(b_1) - d_1.  Same planes, same traffic, one more subtraction; the cancellation of
+// 2 b_{k+1} - b_{k+2} (the terms of a smooth filter nearly cancel there) no longer happens in the state's precision: f32 fields are
+// 2.5e-6 from f64 arithmetic at n_steps 44 instead of 6.8e-6 (the reference's own f32 path: 1.2e-6).
 #include "gcmf_multi_common.hpp"
 #include "gcmf_recurrence.hpp"
 #include <cstdlib>
@@ -133,14 +137,16 @@ __device__ __forceinline__ void bgrid_stream2_body(const BStream2P<T, FB> &P) {
     }
     return r < 0 ? 0 : (r >= rows ? rows - 1 : r);
   };
+  const T *upp = (CLEN && first) ? P.u0 : P.up, *vpp = (CLEN && first) ? P.v0 : P.vp;
+  const T dscale = (CLEN && first) ? (T)P.p0 : T(1);
   auto load_row = [&](Row &x, int r) {
     const long long ro = (long long)row_index(r) * nx + col;
     const long long rc = (long long)row_index(r - 1) * nx + col;
     mload<T, VEC>(x.u, P.u0 + boff + ro);
     mload<T, VEC>(x.v, P.v0 + boff + ro);
-    if (!first) {
-      mload<T, VEC>(x.up, P.up + boff + rc);
-      mload<T, VEC>(x.vp, P.vp + boff + rc);
+    if (!first || CLEN) {   // (backward, first launch: d_n = b_n = p_n f -- the same rows of f again, scaled below; no select in the loop)
+      mload<T, VEC>(x.up, upp + boff + rc);
+      mload<T, VEC>(x.vp, vpp + boff + rc);
     }
     if (!first || CLEN) {   // fbar -- or, backward evaluation, the row of the constant input
       mload<FB, VEC>(x.fu, P.fu_in + boff + rc);
@@ -157,13 +163,14 @@ __device__ __forceinline__ void bgrid_stream2_body(const BStream2P<T, FB> &P) {
 
   BgLevel<T, VEC> L[S];
   T o1u[S][VEC], o1v[S][VEC], o2u[S][VEC], o2v[S][VEC];
+  T d1u[S][VEC], d1v[S][VEC];  // backward evaluation: last iteration's d rows (o2u / o2v are then unused)
   FB accu[S][VEC], accv[S][VEC];
 #pragma unroll
   for (int j = 0; j < S; ++j) {
     L[j].init();
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
-      o1u[j][k] = o1v[j][k] = o2u[j][k] = o2v[j][k] = T(0);
+      o1u[j][k] = o1v[j][k] = o2u[j][k] = o2v[j][k] = d1u[j][k] = d1v[j][k] = T(0);
       accu[j][k] = accv[j][k] = FB(0);
     }
   }
@@ -186,6 +193,7 @@ __device__ __forceinline__ void bgrid_stream2_body(const BStream2P<T, FB> &P) {
     }
 
     T cu[S + 1][VEC], cv[S + 1][VEC];  // newest row of every level this iteration
+    T dcu[S + 1][VEC], dcv[S + 1][VEC];  // (backward evaluation) and of d = b_k + b_{k+1}
     FB nau[S + 1][VEC], nav[S + 1][VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
@@ -223,14 +231,19 @@ __device__ __forceinline__ void bgrid_stream2_body(const BStream2P<T, FB> &P) {
         const T xu = o1u[j - 1][k], xv = o1v[j - 1][k];
         const T avu = -xu - c * lu[k], avv = -xv - c * lv[k];
         if constexpr (CLEN) {
-          const T x2u = (j == 1) ? (first ? T(0) : x.up[k]) : o2u[j >= 2 ? j - 2 : 0][k];
-          const T x2v = (j == 1) ? (first ? T(0) : x.vp[k]) : o2v[j >= 2 ? j - 2 : 0][k];
+          // Reinsch's form (round 5, see the header): d_{k+1} of this row came out of level j - 1 one iteration ago
+          const T dpu = (j == 1) ? dscale * x.up[k] : d1u[j - 1][k];   // (dscale = 1 but for the first launch: exact)
+          const T dpv = (j == 1) ? dscale * x.vp[k] : d1v[j - 1][k];
           const T fiu = (T)((j == 1) ? x.fu[k] : accu[j - 1][k]);
           const T fiv = (T)((j == 1) ? x.fv[k] : accv[j - 1][k]);
-          const T two = (last && j == S) ? T(1) : T(2);  // the last level of the last launch is the result: A, not 2 A
-          const T afu = rfma(-c, lu[k], -xu), afv = rfma(-c, lv[k], -xv);
-          cu[j][k] = rfma((T)pkj, fiu, rfma(two, afu, -x2u));
-          cv[j][k] = rfma((T)pkj, fiv, rfma(two, afv, -x2v));
+          const bool fin = last && j == S;       // the last level of the last launch is the result: p_0 f - c L(b_1) - d_1
+          const T mtc = fin ? -c : T(-2) * c;
+          const T dku = rfma((T)pkj, fiu, rfma(mtc, lu[k], -dpu));
+          const T dkv = rfma((T)pkj, fiv, rfma(mtc, lv[k], -dpv));
+          dcu[j][k] = dku;
+          dcv[j][k] = dkv;
+          cu[j][k] = fin ? dku : dku - xu;
+          cv[j][k] = fin ? dkv : dkv - xv;
           nau[j][k] = (FB)fiu;   // the row of f travels on with its row of the state
           nav[j][k] = (FB)fiv;
         } else if (j == 1 && first) {
@@ -259,11 +272,15 @@ __device__ __forceinline__ void bgrid_stream2_body(const BStream2P<T, FB> &P) {
           }
         }
       }
-      if (j >= S - 1 && keep && r - j >= a && r - j < b) {
+      if (j >= (CLEN ? S : S - 1) && keep && r - j >= a && r - j < b) {
         const long long off = boff + (long long)(r - j) * nx + col;
         if (!last) {
           mstore<T, VEC>((j == S ? P.u2o : P.u1o) + off, cu[j]);
           mstore<T, VEC>((j == S ? P.v2o : P.v1o) + off, cv[j]);
+          if constexpr (CLEN) {   // both state planes from level S: b_k and d_k = b_k + b_{k+1}
+            mstore<T, VEC>(P.u1o + off, dcu[j]);
+            mstore<T, VEC>(P.v1o + off, dcv[j]);
+          }
         }
         if (j == S && !CLEN) {
           mstore<FB, VEC>(P.fu_out + off, nau[j]);
@@ -295,6 +312,7 @@ __device__ __forceinline__ void bgrid_stream2_body(const BStream2P<T, FB> &P) {
         o1u[j][k] = cu[j][k];
         o1v[j][k] = cv[j][k];
         if (j >= 1) { accu[j][k] = nau[j][k]; accv[j][k] = nav[j][k]; }
+        if (CLEN && j >= 1) { d1u[j][k] = dcu[j][k]; d1v[j][k] = dcv[j][k]; }
       }
     }
     if (PRIV) publish(x);  // after level S has read the slot this overwrites (same wave: LDS executes in order)

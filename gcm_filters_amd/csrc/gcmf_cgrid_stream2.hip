@@ -164,6 +164,8 @@ __device__ __forceinline__ void cgrid_stream2_body(const CStream2P<T, FB> &P) {
     }
     return r < 0 ? 0 : (r >= rows ? rows - 1 : r);
   };
+  const T *upp = (CLEN && first) ? P.u0 : P.up, *vpp = (CLEN && first) ? P.v0 : P.vp;
+  const T dscale = (CLEN && first) ? (T)P.p0 : T(1);
   auto load_row = [&](Row &x, int r) {
     const long long ro = (long long)row_index(r) * nx + col;
     const long long rc = (long long)row_index(r - 1) * nx + col;
@@ -171,9 +173,10 @@ __device__ __forceinline__ void cgrid_stream2_body(const CStream2P<T, FB> &P) {
       //               share of the coefficient rows, keep the barriers, and load / compute nothing else
       mload<T, VEC>(x.u, P.u0 + boff + ro);
       mload<T, VEC>(x.v, P.v0 + boff + ro);
-      if (!first) {
-        mload<T, VEC>(x.up, P.up + boff + rc);
-        mload<T, VEC>(x.vp, P.vp + boff + rc);
+      if (!first || CLEN) {  // (backward, first launch: d_n = b_n = p_n f -- the rows of f again, scaled at the use; a select there made
+        //                        the compiler wait for the load it had just issued: 17 % on the B-grid twin of this kernel)
+        mload<T, VEC>(x.up, upp + boff + rc);
+        mload<T, VEC>(x.vp, vpp + boff + rc);
       }
       if (!first || CLEN) {  // fbar -- or, backward evaluation, the row of the constant input
         mload<FB, VEC>(x.fu, P.fu_in + boff + rc);
@@ -282,8 +285,8 @@ __device__ __forceinline__ void cgrid_stream2_body(const CStream2P<T, FB> &P) {
           // is the same polynomial, the same two state planes (b_{k+1}, d_{k+1}) and the same operation count without that cancellation:
           // f32 fields at n_steps 44 come out 1.8e-6 from f64 arithmetic instead of 4.9e-6 -- the reference's own f32 path (f32 T_k, f64
           // running sum): 2.7e-6; at n_steps 98: 5.0e-6 / 1.9e-5 / 8.5e-6.  The state planes hold (b_{k+1}, d_{k+1}); b_n = d_n = p_n f.
-          const T dpu = (j == 1) ? (first ? xu : x.up[k]) : dou[j - 1][k];
-          const T dpv = (j == 1) ? (first ? xv : x.vp[k]) : dov[j - 1][k];
+          const T dpu = (j == 1) ? dscale * x.up[k] : dou[j - 1][k];   // (dscale = 1 but for the first launch: exact)
+          const T dpv = (j == 1) ? dscale * x.vp[k] : dov[j - 1][k];
           const T fiu = (T)((j == 1) ? x.fu[k] : accu[j - 1][k]);
           const T fiv = (T)((j == 1) ? x.fv[k] : accv[j - 1][k]);
           const bool fin = last && j == S;               // the last level of the last launch is the result: c L, not 2 c L, and no b_0

@@ -302,6 +302,38 @@ def test_cgrid_f32_precision_policy(n_steps, scale):
     assert e_auto <= 1e-5 and _rel2(got, ref) <= 2e-5   # absolute ceilings at the longest polynomial of the tutorials (SURVEY 8d gate: 1e-4)
 
 
+@pytest.mark.parametrize("n_steps,scale", [(44, 40), (98, 90)])
+def test_bgrid_f32_precision_policy(n_steps, scale):
+    """float32 B-grid fields: the reference's forward recurrence is reproduced BIT FOR BIT by Filter(evaluation="reference"); the default
+    (backward, Reinsch's form, all f32) is faster and must stay within 4 x of the error the reference's own f32 path has against f64
+    arithmetic (measured 2.1-3.4 x; plain Clenshaw was 5.6-7.3 x)."""
+    import warnings
+    shape, nlev = (96, 160), 6
+    gv = {k: v.astype("f4") for k, v in T.vector_grid_vars("VECTOR_B_GRID", shape).items()}
+    u = np.stack([T.random_field(shape, 42 + 2 * l).astype("f4") for l in range(nlev)])
+    v = np.stack([T.random_field(shape, 43 + 2 * l).astype("f4") for l in range(nlev)])
+    dx = T.grid_dx_min("VECTOR_B_GRID", gv)
+    flts = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for ev in ("auto", "reference"):
+            flts[ev] = Filter(filter_scale=scale * dx, dx_min=dx, n_steps=n_steps, grid_type=GridType.VECTOR_B_GRID, grid_vars=gv, evaluation=ev)
+    fs = flts["auto"].filter_spec
+    spec = O.FilterSpec(fs.n_steps, fs.s_max, np.asarray(fs.p), fs.dx_min_sq)
+    with np.errstate(all="ignore"):
+        ref = O.filter_func_vec(spec, "VECTOR_B_GRID", u, v, gv)
+        truth = O.filter_func_vec(spec, "VECTOR_B_GRID", u.astype("f8"), v.astype("f8"), {k: x.astype("f8") for k, x in gv.items()})
+    plan = ALL_KERNELS[GridType.VECTOR_B_GRID](**gv)._plan(_lib.F32, shape)
+    got = flts["auto"].apply_to_vector(u, v)
+    assert "k_bgrid_stream2c<float" in plan.last_kernel()
+    fwd = flts["reference"].apply_to_vector(u, v)
+    assert "k_bgrid_stream2<float" in plan.last_kernel()
+    assert np.array_equal(fwd[0], ref[0]) and np.array_equal(fwd[1], ref[1])
+    e_ref, e_auto = _rel2(ref, truth), _rel2(got, truth)
+    print(f"n_steps {n_steps}: error against f64 arithmetic -- reference's f32 path {e_ref:.2e}, default (backward, f32) {e_auto:.2e}")
+    assert e_auto <= 4.0 * e_ref and e_auto <= 1.5e-5
+
+
 def test_evaluation_option_reaches_the_plan_for_scalar_grids_too():
     import warnings
     f, gv = T.scalar_case("IRREGULAR_WITH_LAND", (120, 256))
