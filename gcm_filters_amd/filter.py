@@ -279,10 +279,11 @@ class Filter:
         How the filter polynomial is summed.  ``"reference"``: the reference's forward Chebyshev recurrence with its
         accumulation scheme -- for float32 fields a float32 recurrence and a float64 running sum (NumPy >= 2 promotion,
         gcm_filters/filter.py:192-206).  ``"auto"`` (default): the same polynomial by Clenshaw's backward recurrence where
-        that is faster (float64 flux-form grids: <= 3e-15 from the forward result; VECTOR_C_GRID: for float32 fields the whole
-        polynomial is then carried in float32 -- measured 1.4-1.8 x the error the reference's own float32 path has against
-        float64 arithmetic, e.g. 5e-6 instead of 3e-6 at n_steps 44 and 1.8e-5 instead of 1.3e-5 at n_steps 125; the result
-        is float64 either way).  ``"reference"`` is also the path that is BIT-EXACT with numpy on the REGULAR / land-mask / B-grid types
+        that is faster (float64 flux-form grids: <= 3e-15 from the forward result; the vector grids: for float32 fields the whole
+        polynomial is then carried in float32, in Reinsch's form of the recurrence -- VECTOR_C_GRID measures 0.55-0.6 x the error
+        the reference's own float32 path has against float64 arithmetic, e.g. 1.8e-6 instead of 3.2e-6 at n_steps 44 and 7.3e-6
+        instead of 1.3e-5 at n_steps 125; VECTOR_B_GRID 2.1-3.4 x, e.g. 2.5e-6 instead of 1.2e-6 at n_steps 44; the result is float64
+        either way).  ``"reference"`` is also the path that is BIT-EXACT with numpy on the REGULAR / land-mask / B-grid types
         (their default has been the backward evaluation with fused multiply-adds since round 4: <= 1e-14 from numpy, float32 fields
         carried in float32 throughout) and that reproduces the reference's NaN / inf pattern around a non-finite value in a wet cell.
     plan_cache : {None, "protect", "verify", "off"}, keyword only (not a field of the reference class)
