@@ -610,6 +610,10 @@ static bool res_process_allowed(int dev) {
     st.failure_reported = false;
   }
   if (st.disabled) return false;
+  // A CU mask (HSA_CU_MASK, ROC_GLOBAL_CU_MASK) takes compute units away while hipDeviceAttributeMultiprocessorCount still reports all
+  // of them: "one workgroup per CU, all resident" no longer holds (advisor, round 4).  Such a process takes the strip-marching launches.
+  static const bool cu_masked = (getenv("HSA_CU_MASK") && *getenv("HSA_CU_MASK")) || (getenv("ROC_GLOBAL_CU_MASK") && *getenv("ROC_GLOBAL_CU_MASK"));
+  if (cu_masked) return false;
   if (st.have_lock) return true;
   static const bool lock_on = !(getenv("GCMF_RESIDENT_LOCK") && atoi(getenv("GCMF_RESIDENT_LOCK")) == 0);
   if (!lock_on) { st.have_lock = true; return true; }

@@ -218,7 +218,7 @@ def test_reference_zarr_goldens_under_the_default_policy(grid, golden_zarr, monk
         assert "k_resident<" in plan.last_kernel(), plan.last_kernel()
 
 
-def _run_two_workers(tmp_path, seconds, extra_env):
+def _run_two_workers(tmp_path, seconds, extra_env, nproc=2):
     import json
     import subprocess
     import sys
@@ -226,7 +226,7 @@ def _run_two_workers(tmp_path, seconds, extra_env):
     env.pop("GCMF_RESIDENT", None)
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "resident_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(seconds), str(k)], env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE,
-                              stderr=subprocess.PIPE, text=True) for k in range(2)]
+                              stderr=subprocess.PIPE, text=True) for k in range(nproc)]
     try:
         for p in procs:
             assert p.stdout.readline().strip() == "READY", p.stderr.read()[-2000:]
@@ -268,3 +268,12 @@ def test_a_clash_outside_the_lock_is_loud_and_then_falls_back(tmp_path):
         assert o["n"] > 10, outs                           # and the work went on
         if o["errors"] or o["nan_results"]:
             assert any(k.startswith("gcmf::k_ringc") for k in o["kernels"]), outs
+
+
+def test_a_process_with_a_cu_mask_stays_off_the_resident_kernel(tmp_path):
+    """with HSA_CU_MASK / ROC_GLOBAL_CU_MASK the runtime still reports every compute unit while fewer can run workgroups, so
+    "one workgroup per CU, all resident" cannot be promised: such a process runs the strip-marching launches (same bits).  The mask used
+    here names every CU of the device (no actual restriction): only the decision is under test."""
+    (o,) = _run_two_workers(tmp_path, 1.0, {"HSA_CU_MASK": "0:0-255"}, nproc=1)
+    assert o["n"] > 5 and o["wrong"] == 0 and o["nan_results"] == 0 and o["errors"] == [], o
+    assert o["kernels"] and all(k.startswith("gcmf::k_ringc") or k.startswith("gcmf::k_land_fix") for k in o["kernels"]), o
