@@ -216,18 +216,19 @@ def test_config5_cgrid_50_levels_fullsize(fullsize):
         # levels 24 and 49 of the batch against the reference's own outputs for those levels (round 4: the fixture used to pin level 0 only)
         for lev in (24, 49):
             assert int(fullsize[f"cfg5_lev{lev}_n44/meta"][0]) == 44
-            _check_against_fixture(fullsize, f"cfg5_lev{lev}_n44", [cu_[lev].cpu().numpy(), cw_[lev].cpu().numpy()], 1e-4, 1e-4)
+            _check_against_fixture(fullsize, f"cfg5_lev{lev}_n44", [cu_[lev].cpu().numpy(), cw_[lev].cpu().numpy()], 2.5e-6, 1e-5)
         c1u, c1w = flt.apply_to_vector(u[:1], v[:1])           # a level filtered alone gives the same bits as in the batch
         assert np.array_equal(c1u[0].cpu().numpy(), cu0) and np.array_equal(c1w[0].cpu().numpy(), cw0)
         del cu_, cw_, c1u, c1w
-        _check_against_fixture(fullsize, "cfg5_lev0_n44", [cu0, cw0], 1e-4, 1e-4)   # measured 2.2e-6 (f32 state all the way)
+        _check_against_fixture(fullsize, "cfg5_lev0_n44", [cu0, cw0], 2.5e-6, 1e-5)   # measured 1.1e-6 (f32 state all the way, Reinsch's form;
+        #                                                                              SURVEY 8d's gate for f32 state is 1e-4, VERDICT r4 asked for 2.5e-6)
         plan.set_tuning(multi_s=8, clenshaw=0)    # the forward recurrence (f64 fbar): five steps per launch
         gu, gw = flt.apply_to_vector(u, v)
         assert "k_cgrid_stream2<float, double, 2, 5" in plan.last_kernel()
         gu0, gw0 = gu[0].cpu().numpy(), gw[0].cpu().numpy()
         gu_l, gw_l = gu[-1].clone(), gw[-1].clone()
         for lev in (24, 49):   # the reference's scheme (forward, f64 fbar) on the same levels
-            _check_against_fixture(fullsize, f"cfg5_lev{lev}_n44", [gu[lev].cpu().numpy(), gw[lev].cpu().numpy()], 1e-4, 1e-4)
+            _check_against_fixture(fullsize, f"cfg5_lev{lev}_n44", [gu[lev].cpu().numpy(), gw[lev].cpu().numpy()], 2.5e-6, 1e-5)
         del gu, gw
         plan.set_tuning(multi_s=1)
         ru, rw = flt.apply_to_vector(u[-2:], v[-2:])       # single steps on the last two levels
@@ -237,7 +238,7 @@ def test_config5_cgrid_50_levels_fullsize(fullsize):
     finally:
         plan.set_tuning(multi_s=8, clenshaw=2)
     assert gu0.dtype == np.float64                         # NumPy >= 2 promotion of p[k] * T
-    _check_against_fixture(fullsize, "cfg5_lev0_n44", [gu0, gw0], 1e-4, 1e-4)
+    _check_against_fixture(fullsize, "cfg5_lev0_n44", [gu0, gw0], 2.5e-6, 1e-5)   # the reference's own scheme: probes 3.9e-7, the field maximum 1.6e-6
 
 
 @pytest.mark.parametrize("cfg,key", [(3, "cfg3_n63"), (4, "cfg4_n56")])
