@@ -21,7 +21,7 @@ OK, ERR_INVALID_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED, ERR_P2P_TIMEOUT = 
 ERR_KAPPA_W_GT1, ERR_KAPPA_S_GT1, ERR_KAPPA_NONE_ONE = 16, 17, 18
 ERR_WET_SOUTH_ROW, ERR_DXN_FOLD, ERR_DYN_FOLD = 19, 20, 21
 F32, F64 = 0, 1
-DEVICE_PTRS, OUT_F32, FORWARD_RECURRENCE, NO_RESIDENT = 0x1, 0x2, 0x4, 0x8
+DEVICE_PTRS, OUT_F32, FORWARD_RECURRENCE, NO_RESIDENT, BACKWARD_F32 = 0x1, 0x2, 0x4, 0x8, 0x10
 STEP_FIRST, STEP_LAST, STEP_LAND_ZERO, STEP_LAND_FIXED, STEP_CLENSHAW = 0x1, 0x2, 0x4, 0x8, 0x10
 
 EXPORTS = [
@@ -283,9 +283,10 @@ class Plan:
 
     # -- whole-filter / one-Laplacian calls ----------------------------------------------------
     def apply(self, p: np.ndarray, c: float, ins: Sequence[int], outs: Sequence[int], nbatch: int, *,
-              device_ptrs: bool, out_f32: bool = False, stream: int = 0, forward: bool = False):
+              device_ptrs: bool, out_f32: bool = False, stream: int = 0, forward: bool = False, backward_f32: bool = False):
         p = np.ascontiguousarray(p, dtype=np.float64)
-        flags = (DEVICE_PTRS if device_ptrs else 0) | (OUT_F32 if out_f32 else 0) | (FORWARD_RECURRENCE if forward else 0)
+        flags = ((DEVICE_PTRS if device_ptrs else 0) | (OUT_F32 if out_f32 else 0) | (FORWARD_RECURRENCE if forward else 0)
+                 | (BACKWARD_F32 if backward_f32 else 0))
         check(load().gcmf_apply(self._h, p.ctypes.data_as(C.POINTER(C.c_double)), len(p) - 1, float(c),
                                 _ptr_array(ins), _ptr_array(outs), int(nbatch), flags, C.c_void_p(stream or None)))
 

@@ -386,6 +386,7 @@ int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int 
   if (const char *e = getenv("GCMF_RINGC_XE_ROWS")) pl->ringc_xe_rows = atoi(e);
   if (const char *e = getenv("GCMF_CLENSHAW")) pl->clenshaw = atoi(e);
   if (const char *e = getenv("GCMF_RINGC9")) pl->ringc9 = atoi(e);
+  if (const char *e = getenv("GCMF_CLENSHAW_F32")) pl->clenshaw_f32 = atoi(e);
   PLAN_HIP(hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking));
   PLAN_HIP(hipEventCreate(&pl->ev0));
   PLAN_HIP(hipEventCreate(&pl->ev1));
@@ -523,6 +524,7 @@ int gcmf_set_option(gcmf_plan *pl, const char *name, int value) {
   else if (n == "cgrid_ring_smax") pl->cgrid_ring_smax = value;
   else if (n == "cgrid_ring_hmax") pl->cgrid_ring_hmax = value;
   else if (n == "ringc9") pl->ringc9 = value;
+  else if (n == "clenshaw_f32") pl->clenshaw_f32 = value;
   else {
     set_error("gcmf_set_option: unknown option '%s'", name);
     return GCMF_ERR_INVALID_ARG;
@@ -576,8 +578,13 @@ static bool land_ok(const gcmf_plan *pl, int n_steps);
 static bool ringc9_ok(const gcmf_plan *pl) {
   return pl && pl->ringc9 && pl->kind == K_FLUX && pl->d.dtype == GCMF_F64 && pl->full && !pl->tripolar && !pl->g.fold && pl->g.rows >= 64;
 }
-static int clenshaw_cut(const gcmf_plan *pl, int n_steps, int *depths, int max_depths) {
+static int clenshaw_cut(const gcmf_plan *pl, int n_steps, int *depths, int max_depths, bool f32_asked = false) {
   if (!pl || pl->ncomp != 1 || !(pl->clenshaw >= 2 || (pl->clenshaw == 1 && pl->kind == K_FLUX))) return 0;
+  // f32 state (round 5): only when asked for (plan option clenshaw_f32 / GCMF_BACKWARD_F32 per call).  Summed backwards in f32 the
+  // polynomial is 15-45 x further from f64 arithmetic than the reference's own f32 path (f32 T_k, f64 running sum; measured:
+  // tools/measure_scalar_f32_error.py) -- the coefficients b_k grow like n - k where the T_k stay bounded -- and
+  // Reinsch's form only halves that.  The forward kernels are that path itself (bit for bit on the REGULAR / land-mask kinds).
+  if (pl->d.dtype != GCMF_F64 && !(pl->clenshaw_f32 || f32_asked)) return 0;
   // (tripolar: of the GRID, not of this slab -- every rank of a slab run must take the same decision)
   // (tripolar plans: the seam rows run k_fold_band's backward form beside every launch)
   // f32 state: the flux kinds only (four cells per lane; the whole polynomial is then carried in f32 -- Filter(evaluation="reference") /
@@ -934,7 +941,8 @@ land_and_guard:
 // message per neighbour) when fewer are left than the next launch needs.  No edge / interior split.
 int gcmf_slab_backward_vec_supported(const gcmf_plan *pl, int64_t nbatch, int halo) {
   if (!pl || pl->ncomp != 2 || nbatch < 1) return 0;
-  if (!((pl->kind == K_CGRID && pl->clenshaw >= 1) || (pl->kind == K_BGRID && pl->clenshaw >= 2))) return 0;
+  if (!((pl->kind == K_CGRID && pl->clenshaw >= 1) || (pl->kind == K_BGRID && pl->clenshaw >= 2 && (pl->d.dtype == GCMF_F64 || pl->clenshaw_f32))))
+    return 0;
   return (pl->multi_s >= 2 && vec_multi_supported(pl, nbatch, 2) && (halo == 0 || halo >= 4)) ? 1 : 0;
 }
 
@@ -1116,7 +1124,8 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
     const void *x0[2] = {din[0], din[1]};
     int depths[1024];
     const bool fwd_only = flags & GCMF_FORWARD_RECURRENCE;   // the caller wants the reference's forward recurrence / accumulation
-    const int n_clen = (use_multi && !fwd_only) ? clenshaw_cut(pl, n_steps, depths, 1024) : 0;
+    const bool back_f32 = pl->clenshaw_f32 || (flags & GCMF_BACKWARD_F32);   // f32 B-grid / scalar state backwards: only when asked for
+    const int n_clen = (use_multi && !fwd_only) ? clenshaw_cut(pl, n_steps, depths, 1024, back_f32) : 0;
     // Small fields: the whole polynomial on the chip in ONE launch (64 levels at a time; gcmf_resident.hip) -- the field, both states
     // and the coefficients live in registers / LDS, nothing but the result goes back to memory.  Same bits as the launches below.
     bool resident = false;
@@ -1249,7 +1258,8 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
         if ((rc = ensure_dev_p(pl, p, n_steps, s))) return rc;
         if ((rc = launch_land_fix(pl, din[0], dout[0], pl->dev_p, n_steps, c, fb32 ? 1 : 0, nbatch, s))) return rc;
       }
-    } else if (use_vmulti && ((pl->kind == K_CGRID && pl->clenshaw >= 1) || (pl->kind == K_BGRID && pl->clenshaw >= 2)) && !fwd_only &&
+    } else if (use_vmulti && ((pl->kind == K_CGRID && pl->clenshaw >= 1) ||
+                              (pl->kind == K_BGRID && pl->clenshaw >= 2 && (pl->d.dtype == GCMF_F64 || back_f32))) && !fwd_only &&
                n_steps >= 2 && vec_multi_supported(pl, nbatch, 2)) {
       // C-grid (B-grid with GCMF_CLENSHAW=2: it is bit-exact with numpy forward, so backward is an option there like for the land-mask
       // kinds): the polynomial evaluated backwards (k_cgrid_stream2c / k_bgrid_stream2c): state (b_{k+1}, b_{k+2}) in a pool of four

@@ -173,6 +173,11 @@ struct gcmf_plan {
   int ringc9 = 1;         // whole f64 flux-form grids without a tripole seam: up to NINE levels per k_ringc launch (env GCMF_RINGC9, gcmf_set_option "ringc9")
   int clenshaw = 2;       // backward (Clenshaw) evaluation: 0 off, 1 the flux kinds + C-grid, 2 (default since round 4) every kind that has a
                           // backward kernel (f64 REGULAR / land-mask kinds, B-grid too); env GCMF_CLENSHAW.  Per call: GCMF_FORWARD_RECURRENCE
+  int clenshaw_f32 = 0;   // backward evaluation also for f32 SCALAR state and the f32 B-grid (round 5: off by default -- an all-f32 Clenshaw
+                          // sum is 15-45 x less accurate than the reference's own f32 path (f32 T_k, f64 running sum) on the scalar kinds,
+                          // 2-3 x on the B-grid, and the forward kernels reproduce that path bit for bit on the REGULAR / land-mask /
+                          // B-grid kinds; the f32 C-grid stays backward: in Reinsch's form it is MORE accurate than the reference's).
+                          // GCMF_CLENSHAW_F32=1, gcmf_set_option("clenshaw_f32"), or per call GCMF_BACKWARD_F32.
   void *resident = nullptr;  // state of the on-chip (resident) kernel: exchange planes, tile flags (gcmf_resident.hip)
   double *dev_p = nullptr;   // p[0..n_steps] of the last filter, for k_land_fix
   size_t dev_p_n = 0;

@@ -172,13 +172,14 @@ def _create_filter_func(filter_spec: FilterSpec, Laplacian, evaluation: str = "a
     axes are independent batches), then the grid variables in ``Laplacian.required_grid_args()`` order.
     ``evaluation``, ``plan_cache``: see ``Filter``."""
     forward = _forward_only(evaluation)
+    backward = evaluation == "backward"
     memo = _LaplacianMemo(Laplacian)
 
     def filter_func(field, *args):
         assert len(args) == len(Laplacian.required_grid_args())
         with plan_cache_mode(plan_cache):
             laplacian = memo.get(args)  # device plan: cached while the grid arrays are unchanged
-            return laplacian._run([field], spec=filter_spec, forward=forward)[0]
+            return laplacian._run([field], spec=filter_spec, forward=forward, backward_f32=backward)[0]
 
     return filter_func
 
@@ -186,13 +187,14 @@ def _create_filter_func(filter_spec: FilterSpec, Laplacian, evaluation: str = "a
 def _create_filter_func_vec(filter_spec: FilterSpec, Laplacian, evaluation: str = "auto", plan_cache=None):
     """Returns ``filter_func_vec(u, v, *grid_args) -> (u_filtered, v_filtered)``."""
     forward = _forward_only(evaluation)
+    backward = evaluation == "backward"
     memo = _LaplacianMemo(Laplacian)
 
     def filter_func_vec(ufield, vfield, *args):
         assert len(args) == len(Laplacian.required_grid_args())
         with plan_cache_mode(plan_cache):
             laplacian = memo.get(args)
-            u, v = laplacian._run([ufield, vfield], spec=filter_spec, forward=forward)
+            u, v = laplacian._run([ufield, vfield], spec=filter_spec, forward=forward, backward_f32=backward)
         return (u, v)
 
     return filter_func_vec
@@ -231,7 +233,7 @@ class _LaplacianMemo:
         return lap
 
 
-EVALUATIONS = ("auto", "reference")
+EVALUATIONS = ("auto", "reference", "backward")
 
 
 def _forward_only(evaluation: str) -> bool:
@@ -275,17 +277,19 @@ class Filter:
     grid_vars : dict
         Grid variables required by ``grid_type`` (see ``required_grid_vars``); xarray DataArrays, numpy
         arrays or torch tensors (host or MI355X-resident); planes (y, x) or with leading level / time dims
-    evaluation : {"auto", "reference"}, keyword only (not a field of the reference class)
+    evaluation : {"auto", "reference", "backward"}, keyword only (not a field of the reference class)
         How the filter polynomial is summed.  ``"reference"``: the reference's forward Chebyshev recurrence with its
         accumulation scheme -- for float32 fields a float32 recurrence and a float64 running sum (NumPy >= 2 promotion,
-        gcm_filters/filter.py:192-206).  ``"auto"`` (default): the same polynomial by Clenshaw's backward recurrence where
-        that is faster (float64 flux-form grids: <= 3e-15 from the forward result; the vector grids: for float32 fields the whole
-        polynomial is then carried in float32, in Reinsch's form of the recurrence -- VECTOR_C_GRID measures 0.55-0.6 x the error
-        the reference's own float32 path has against float64 arithmetic, e.g. 1.8e-6 instead of 3.2e-6 at n_steps 44 and 7.3e-6
-        instead of 1.3e-5 at n_steps 125; VECTOR_B_GRID 2.1-3.4 x, e.g. 2.5e-6 instead of 1.2e-6 at n_steps 44; the result is float64
-        either way).  ``"reference"`` is also the path that is BIT-EXACT with numpy on the REGULAR / land-mask / B-grid types
-        (their default has been the backward evaluation with fused multiply-adds since round 4: <= 1e-14 from numpy, float32 fields
-        carried in float32 throughout) and that reproduces the reference's NaN / inf pattern around a non-finite value in a wet cell.
+        gcm_filters/filter.py:192-206); BIT-EXACT with numpy on the REGULAR / land-mask / B-grid types, and the path that
+        reproduces the reference's NaN / inf pattern around a non-finite value in a wet cell.
+        ``"auto"`` (default): the same polynomial by Clenshaw's backward recurrence (two state planes, fused multiply-adds)
+        wherever that is at least as close to float64 arithmetic as the reference's own path for the dtype:
+        every float64 field (<= 1e-14 from numpy; flux-form grids <= 3e-15 from the forward result) and float32 VECTOR_C_GRID fields
+        (carried in float32 in Reinsch's form of the recurrence: 0.55-0.6 x the error of the reference's float32 path, e.g.
+        1.8e-6 instead of 3.2e-6 at n_steps 44).  float32 scalar and VECTOR_B_GRID fields take the forward recurrence (round 5):
+        summed backwards in float32 they are 15-45 x (B-grid 2-3 x) further from float64 arithmetic than the reference is.
+        ``"backward"``: backward evaluation for those too -- 1.1-1.8 x faster, all float32 (e.g. 9.5e-6 instead of 2.1e-7 on
+        IRREGULAR_WITH_LAND at n_steps 98; inside SURVEY 8d's 1e-4 for float32).  The result is float64 in every case.
     plan_cache : {None, "protect", "verify", "off"}, keyword only (not a field of the reference class)
         The reference builds (and validates) a fresh Laplacian on every call (gcm_filters/filter.py:183); here the folded grid lives in
         HBM as a *plan* that is reused while the grid arrays are unchanged.  ``"protect"`` (the default, also ``None`` unless the

@@ -474,7 +474,7 @@ class _DeviceLaplacian:
                     sub.append(a[tuple(0 if n == 1 else i for i, n in zip(gi, lead))])
             self._levels[g] = type(self)(*sub, _skip_kappa_one=True)
 
-    def _run_levels(self, fields, spec, out_f32, forward=False):
+    def _run_levels(self, fields, spec, out_f32, forward=False, backward_f32=False):
         given = list(fields)
         fields = [_unwrap(f) for f in fields]
         shape = tuple(fields[0].shape)
@@ -490,7 +490,7 @@ class _DeviceLaplacian:
             for f in fields:
                 fb = f.expand(*out_lead, *core) if _is_torch(f) else np.broadcast_to(f, out_lead + core)
                 sub.append(fb[idx])
-            res = lap._run(sub, spec=spec, out_f32=out_f32, forward=forward)
+            res = lap._run(sub, spec=spec, out_f32=out_f32, forward=forward, backward_f32=backward_f32)
             if outs is None:
                 if _is_torch(res[0]):
                     import torch
@@ -542,12 +542,14 @@ class _DeviceLaplacian:
         # ("verify": the key holds a hash of every plane -- nothing to protect, the caller's arrays stay writable)
         return PLAN_CACHE.get(key, factory, () if (on_gpu or mode == "verify") else self._planes)
 
-    def _run(self, fields: Sequence, spec=None, out_f32: bool = False, forward: bool = False):
+    def _run(self, fields: Sequence, spec=None, out_f32: bool = False, forward: bool = False, backward_f32: bool = False):
         """Shared driver of __call__ (spec None: one Laplacian) and of filter_func (spec: whole polynomial).
         forward: evaluate the polynomial by the reference's forward recurrence with its accumulation scheme (f64 running sum
-        also for f32 state) even where the library would evaluate it backwards (Filter(evaluation="reference"))."""
+        also for f32 state) even where the library would evaluate it backwards (Filter(evaluation="reference")).
+        backward_f32: evaluate it backwards also for f32 scalar / B-grid fields, whose default is the forward recurrence
+        (Filter(evaluation="backward"): faster, all f32)."""
         if self._levels is not None:
-            return self._run_levels(fields, spec, out_f32, forward)
+            return self._run_levels(fields, spec, out_f32, forward, backward_f32)
         given = list(fields)
         fields = [_unwrap(f) for f in fields]
         shape = tuple(fields[0].shape)
@@ -577,7 +579,7 @@ class _DeviceLaplacian:
                 # libgcmf selects the plan's device itself -- no device context manager on this path)
                 cur = torch.cuda.current_stream(dev)
                 self._call(plan, spec, [t.data_ptr() for t in ins], [t.data_ptr() for t in outs], nbatch,
-                           True, out_f32, cur.cuda_stream, forward)
+                           True, out_f32, cur.cuda_stream, forward, backward_f32)
                 for t, f in zip(ins, fields):   # inputs converted above are temporaries: keep them alive until the stream is done
                     if t is not f:
                         t.record_stream(cur)
@@ -586,7 +588,7 @@ class _DeviceLaplacian:
         host = [f.detach().cpu().numpy() if _is_torch(f) else np.asarray(f) for f in fields]
         ins = [np.ascontiguousarray(f, dtype=_lib.np_dtype(dtype)) for f in host]
         outs = [_host_output(shape, out_np) for _ in fields]
-        if nbatch == 1 and spec is not None and self._NCOMP == 1 and ny * nx >= host_blocks.MIN_CELLS and not forward:
+        if nbatch == 1 and spec is not None and self._NCOMP == 1 and ny * nx >= host_blocks.MIN_CELLS and not forward and not backward_f32:
             # one large host field: upload / recurrence / download overlapped by row blocks (host_blocks.py)
             pipe = self._row_blocks(plan, dtype, ny, nx, spec)
             if pipe is not None:
@@ -599,7 +601,7 @@ class _DeviceLaplacian:
                 return outs
         if nbatch:
             self._call(plan, spec, [a.ctypes.data for a in ins], [a.ctypes.data for a in outs], nbatch, False,
-                       out_f32, 0, forward)
+                       out_f32, 0, forward, backward_f32)
         return outs
 
     def _row_blocks(self, plan, dtype, ny, nx, spec):
@@ -632,7 +634,7 @@ class _DeviceLaplacian:
             st["pipes"][n] = pipe
             return pipe
 
-    def _call(self, plan, spec, ins, outs, nbatch, device_ptrs, out_f32, stream, forward=False):
+    def _call(self, plan, spec, ins, outs, nbatch, device_ptrs, out_f32, stream, forward=False, backward_f32=False):
         try:
             if spec is None:
                 plan.laplacian(ins, outs, nbatch, device_ptrs=device_ptrs, stream=stream)
@@ -640,7 +642,7 @@ class _DeviceLaplacian:
                 # shift of the spectrum to [-1, 1]: reference filter.py:170-173
                 c = 2 / spec.s_max if self.is_dimensional else 2 / (spec.s_max * spec.dx_min_sq)
                 plan.apply(np.asarray(spec.p, dtype=np.float64), c, ins, outs, nbatch, device_ptrs=device_ptrs,
-                           out_f32=out_f32, stream=stream, forward=forward)
+                           out_f32=out_f32, stream=stream, forward=forward, backward_f32=backward_f32)
         except _lib.GcmfError as e:
             raise _translate(e) from None
 

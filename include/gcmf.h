@@ -77,6 +77,9 @@ typedef enum gcmf_dtype { GCMF_F32 = 0, GCMF_F64 = 1 } gcmf_dtype;
                               /* (Clenshaw: f64 flux-form plans, C-grid plans)                                  */
 #define GCMF_NO_RESIDENT 0x8u /* gcmf_apply / gcmf_slab_apply_backward: never use the on-chip (resident) kernel,   */
                               /* csrc/gcmf_resident.hip -- the strip-marching launches of 5..8 levels instead (same bits) */
+#define GCMF_BACKWARD_F32 0x10u /* gcmf_apply, f32 scalar and B-grid plans: evaluate backwards (Clenshaw, all f32) like the f64 */
+                              /* plans.  Faster (1.1-1.8 x) and 2-45 x further from f64 arithmetic than the reference's own f32  */
+                              /* path (filter.py:192-206: f32 T_k, f64 running sum), which is the default for these plans.       */
 
 /* Chebyshev step modes for gcmf_cheb_step */
 #define GCMF_STEP_FIRST 0x1u /* T1 = A(T0);            fbar  = p0*T0 + p1*T1                  */
@@ -368,7 +371,8 @@ int gcmf_resident_levels(gcmf_plan *plan, const void *u, const void *v, void *uo
 int gcmf_set_tuning(gcmf_plan *plan, int rows_per_wave, int xcd_remap, int multi);
 /* Named per-plan switches (A/B testing, the parity tests): "cgrid_ring" 1 / 0 (the static-ring C-grid kernel of batched f32 levels,
  * gcmf_cgrid_ring.hip; 0 = k_cgrid_stream2c everywhere), "cgrid_ring_smax" 4 / 5 (levels per launch), "cgrid_ring_hmax" (tallest
- * strip, 0 = 96 rows), "ringc9" 1 / 0 (nine levels per k_ringc launch on whole f64 flux grids).  Unknown names: GCMF_ERR_INVALID_ARG. */
+ * strip, 0 = 96 rows), "ringc9" 1 / 0 (nine levels per k_ringc launch on whole f64 flux grids), "clenshaw_f32" 0 / 1 (GCMF_BACKWARD_F32
+ * for every call of this plan, the slab drivers and gcmf_clenshaw_cut included).  Unknown names: GCMF_ERR_INVALID_ARG. */
 int gcmf_set_option(gcmf_plan *plan, const char *name, int value);
 
 /* Last error text of the calling thread (never NULL). */

@@ -26,14 +26,16 @@ CASES = [
     ("VECTOR_B_GRID", (120, 64), 3, 5, "f8"),   # blocked B-grid kernel (f64: S <= 3), padded batch, overlapped exchange
     ("VECTOR_B_GRID", (49, 64), 4, 2, "f4"),
     ("TRIPOLAR_POP_WITH_LAND", (120, 64), 4, 2, "f8"),   # NaN on land + land kept out of the state + overlapped exchange
-    ("MOM5U", (64, 64), 8, 3, "f4"),
+    ("MOM5U", (64, 64), 8, 3, "f4"),            # f32 scalar fields: the reference's forward scheme by default (round 5) ...
+    ("MOM5U", (64, 64), 8, 3, "f4b"),           # ... "f4b": with GCMF_CLENSHAW_F32=1, the backward f32 slab kernels
     # 58 rows over 3 ranks = 19 / 19 / 20: only the 20-row rank overlaps its exchange with the first launch and sends its
     # rows before zeroing their land; the receivers run the land-mask kernels in LAND_ZERO mode (found by tools/fuzz_slabs.py)
     ("TRIPOLAR_REGULAR_WITH_LAND_AREA_WEIGHTED", (58, 16), 5, 5, "f8"),
     ("REGULAR_WITH_LAND", (58, 16), 5, 2, "f4"),
+    ("REGULAR_WITH_LAND", (58, 16), 5, 2, "f4b"),
     # f32 POP, n_steps 19 = launches of 7 + 7 + 5 levels on slabs of 14 rows with 14 ghost rows: the second launch of the top rank starts
     # exactly 2 S rows below the seam (k_fold_band's input rows; found by tools/fuzz_slabs.py -- the row-range check was one row too strict)
-    ("TRIPOLAR_POP_WITH_LAND", (28, 44), 16, 5, "f4", 19),
+    ("TRIPOLAR_POP_WITH_LAND", (28, 44), 16, 5, "f4b", 19),
     ("TRIPOLAR_POP_WITH_LAND", (40, 64), 16, 2, "f8", 24),
 ]
 
@@ -43,6 +45,7 @@ CASES_8 = [
     ("IRREGULAR_WITH_LAND", (144, 64), 8, 2, "f8"),
     ("TRIPOLAR_POP_WITH_LAND", (160, 64), 8, 2, "f8"),
     ("REGULAR_WITH_LAND", (131, 64), 5, 2, "f4"),
+    ("REGULAR_WITH_LAND", (131, 64), 5, 2, "f4b"),
     ("VECTOR_C_GRID", (128, 64), 4, 4, "f4"),
 ]
 
@@ -72,6 +75,11 @@ def _worker(rank, world, port, q, exchange="auto"):
             if rest and world != 2:
                 res[f"{grid}-{shape}-h{halo}-b{nbatch}-{dt}"] = (0.0, 0.0)   # (a two-rank geometry)
                 continue
+            name, back32 = f"{grid}-{shape}-h{halo}-b{nbatch}-{dt}", dt == "f4b"
+            dt = "f4" if back32 else dt
+            os.environ.pop("GCMF_CLENSHAW_F32", None)
+            if back32:
+                os.environ["GCMF_CLENSHAW_F32"] = "1"     # (read when a plan is created: the slab plans and the one-GPU plan below)
             vec = grid in T.VECTOR_GRIDS
             gv = T.vector_grid_vars(grid, shape) if vec else T.scalar_grid_vars(grid, shape)
             fields = [np.stack([T.random_field(shape, 7 + 10 * c + b) for b in range(nbatch)]) for c in range(2 if vec else 1)]
@@ -91,6 +99,8 @@ def _worker(rank, world, port, q, exchange="auto"):
             got = sf.gather_to_global(sf.apply_local(sf.scatter_from_global(fields)))
             sf.collect_kernel_times()
             assert not sf.p2p_timed_out(), grid
+            if dt == "f4" and not vec and not back32:
+                assert not sf.backward_cut, name      # f32 scalar fields: the forward recurrence unless asked otherwise
             if sf.backward_cut:   # flux kinds: the slabs evaluate backwards like the one-GPU path (k_ringc; k_ringcs = its early-exit form for slabs)
                 kern = sf.engine.plan.last_kernel()
                 assert "k_ringc<" in kern or "k_ringcs<" in kern, (grid, kern)
@@ -107,7 +117,8 @@ def _worker(rank, world, port, q, exchange="auto"):
                 nz = lambda a: np.nan_to_num(a, nan=0.0)
                 e_one = max(float(np.abs(nz(g) - nz(w)).max() / np.abs(nz(w)).max()) for g, w in zip(got, one))
                 e_ref = max(float(np.abs(nz(g) - nz(w)).max() / np.abs(nz(w)).max()) for g, w in zip(got, want))
-                res[f"{grid}-{shape}-h{halo}-b{nbatch}-{dt}"] = (e_one, e_ref)
+                res[name] = (e_one, e_ref)
+        os.environ.pop("GCMF_CLENSHAW_F32", None)
         if rank == 0:
             q.put(res)
     finally:
@@ -130,7 +141,7 @@ def test_slabs_on_one_gpu_match_single_domain(world, exchange):
     res = q.get()
     assert len(res) == len(CASES_8 if world == 8 else CASES)
     for name, (e_one, e_ref) in res.items():
-        f32 = name.endswith("f4")
+        f32 = name.endswith(("f4", "f4b"))
         assert e_one <= (1e-5 if f32 else 1e-13), (name, e_one)   # slab run == single-domain GPU run
         assert e_ref <= (1e-4 if f32 else 1e-11), (name, e_ref)   # and == the reference
 
