@@ -558,6 +558,7 @@ def run_host_path(dev, args):
         rec["row_block_pipeline_same_bits"] = bool(np.array_equal(out, want, equal_nan=True))
         out = want = None
         clear_plan_cache()                         # (a plan remembers its pipeline: the in-sequence figure needs a fresh one)
+        time.sleep(0.5)                            # (the block plans' memory is being scrubbed: see free_gpu)
         os.environ["GCMF_HOST_BLOCKS"] = "0"       # one plan: upload, recurrence, download in sequence (gcmf_apply with host pointers)
         flt.apply(f)
         rec["one_plan_in_sequence_ms"] = best(lambda: flt.apply(f), sync=False)
@@ -584,9 +585,17 @@ def free_gpu():
     import torch
 
     from gcm_filters_amd.kernels import clear_plan_cache
+    free0 = torch.cuda.mem_get_info()[0]
     clear_plan_cache()
     gc.collect()
     torch.cuda.empty_cache()
+    # The driver scrubs freed device memory in the background with the copy engines: for about a second after 20 GB have been
+    # freed an upload and a download take turns instead of sharing the link (host path: 2.8 instead of 1.7 ms per field) and
+    # resident kernels run ~5 % slower (experiments/scripts/host_batch_bisect3.py, profiles/r05/vram_scrub_after_free.txt).
+    # What is timed next must not overlap with the clean-up of what was timed before: wait it out (0.1 s per GB freed).
+    freed_gb = max(0, torch.cuda.mem_get_info()[0] - free0) / 2**30
+    if freed_gb > 0.5:
+        time.sleep(min(4.0, 0.1 * freed_gb))
 
 
 # ------------------------------------------------------------------------------------------------------------------
