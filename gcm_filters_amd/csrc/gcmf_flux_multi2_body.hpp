@@ -6,9 +6,8 @@
 
 namespace gcmf {
 
-template <typename T, typename FB, int S>
+template <typename T, typename FB, int S, int VEC = 16 / (int)sizeof(T)>   // (VEC: cells per lane = the caller's window geometry)
 __device__ __forceinline__ void flux_multi2_march(const MultiP<T, FB> &P, const int wid) {
-  constexpr int VEC = 16 / sizeof(T);
   constexpr int W = 64 * VEC;
   constexpr int M = (S + VEC - 1) / VEC * VEC;
   constexpr int WI = W - 2 * M;

@@ -158,6 +158,7 @@ struct gcmf_plan {
   int cgrid_tile = 0;     // 1: force the LDS-tile C-grid kernel instead of the streaming one (A/B testing)
   int cgrid_ring = 1;     // k_cgrid_ring (gcmf_cgrid_ring.hip) for batched f32 levels (0: k_cgrid_stream2c everywhere); env GCMF_CGRID_RING, gcmf_set_option
   int cgrid_ring_smax = 5;  // levels per launch of that kernel (4 / 5); env GCMF_CGRID_RING_SMAX
+  int ring_flux_f32 = 1;    // forward ring kernel for f32 flux-kind state (0: k_flux_multi2 as until round 4); gcmf_set_option
   int cgrid_ring_hmax = 0;  // tallest strip its launcher picks (0 = 96); gcmf_set_option
   // Land kept out of the state (scalar plans; slab-row layout): bit 0 of lbits[cell] = the cell exchanges with a neighbour.
   // A cell that does not (land under a wet mask; a flux-form cell whose four faces are closed) has L = 0 and evolves
@@ -233,6 +234,7 @@ int launch_vector_step(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 int launch_scalar_multi(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 bool flux_multi2_supported(const gcmf_plan *pl, int S);
 bool ring_supported(const gcmf_plan *pl, const MultiArgs &a);
+int launch_ring_flux_f32(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);   // gcmf_ring_flux_f32.hip
 // backward (Clenshaw) evaluation, gcmf_ringc_impl.hpp: one launch of S = 5..8 levels; a.fb_in = the constant input f, a.fb_out =
 // the result (last launch), a.pk[t] = the coefficient of level t + 1 of this launch
 int launch_ringc_reg(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);

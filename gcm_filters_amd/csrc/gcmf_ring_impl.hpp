@@ -59,9 +59,10 @@ template <typename X> __device__ __forceinline__ X *lane_ptr(X *rowp, unsigned b
   return reinterpret_cast<X *>(reinterpret_cast<char *>(rowp) + bytes);
 }
 
-template <typename T, typename FB, int KIND, int S, bool FIRST>
+// VEC: cells per lane -- 16 bytes' worth by default; the f32 flux kinds run with TWO (8-byte accesses): with four their rings need 510
+// registers (round 3: slower than k_flux_multi2), with two they need what the f64 kernel needs.
+template <typename T, typename FB, int KIND, int S, bool FIRST, int VEC = 16 / (int)sizeof(T)>
 __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
-  constexpr int VEC = 16 / sizeof(T);
   constexpr int W = 64 * VEC;
   constexpr int M = (S + VEC - 1) / VEC * VEC;
   constexpr int WI = W - 2 * M;
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
     if (dirty) {
       if (P.nfb && (threadIdx.x & 63) == 0) atomicAdd(P.nfb, 1u);  // instrumentation: gcmf_ring_fallbacks
       // the general march reads P.first itself; a first launch still has land in its input: K_MASK, not K_MASKZ
-      if constexpr (FLUX) flux_multi2_march<T, FB, S>(P, wid);   // the same strip: wid, not blockIdx (XCD order above)
+      if constexpr (FLUX) flux_multi2_march<T, FB, S, VEC>(P, wid);   // the same strip and window: wid, not blockIdx (XCD order above)
       else scalar_multi_march<T, FB, (FIRST ? K_MASK : KIND), S, 1>(P, wid);
       if constexpr (FIRST) {
         // the general march carries land through the recurrence; the launches that follow were promised states whose
@@ -400,9 +401,8 @@ __global__ __launch_bounds__(256, 1) void k_ring(const MultiP<T, FB> P) {
   }
 }
 
-template <typename T, typename FB, int KIND, int S, bool FIRST>
+template <typename T, typename FB, int KIND, int S, bool FIRST, int VEC = 16 / (int)sizeof(T)>
 static int launch_ring_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
-  constexpr int VEC = 16 / sizeof(T);
   constexpr int W = 64 * VEC;
   constexpr int M = (S + VEC - 1) / VEC * VEC;
   constexpr int WI = W - 2 * M;
@@ -455,24 +455,24 @@ static int launch_ring_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   dim3 block(256), grid((P.nwaves + 3) / 4, (unsigned)a.nbatch);
   P.xcd_per = pl->xcd_remap ? (int)(grid.x / 8) : 0;
   P.zigzag = 0;
-  hipLaunchKernelGGL((k_ring<T, FB, KIND, S, FIRST>), grid, block, 0, s, P);
+  hipLaunchKernelGGL((k_ring<T, FB, KIND, S, FIRST, VEC>), grid, block, 0, s, P);
   GCMF_HIP(hipGetLastError());
   note_kernel(pl, std::string("gcmf::k_ring<") + tyname<T>() + ", " + tyname<FB>() + ", " + std::to_string(KIND) + ", " +
-                      std::to_string(S) + ", " + (FIRST ? "true" : "false") + ">", S,
+                      std::to_string(S) + ", " + (FIRST ? "true" : "false") + (VEC == 16 / (int)sizeof(T) ? "" : ", " + std::to_string(VEC)) + ">", S,
               launch_geom(P.H, P.nstrips, P.nwx, P.xcd_per > 0, grid.x, grid.y, nrows));
   return GCMF_OK;
 }
 
-template <typename T, typename FB, int KIND, int S> static int launch_ring_s(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
-  return a.first ? launch_ring_sf<T, FB, KIND, S, true>(pl, a, s) : launch_ring_sf<T, FB, KIND, S, false>(pl, a, s);
+template <typename T, typename FB, int KIND, int S, int VEC> static int launch_ring_s(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
+  return a.first ? launch_ring_sf<T, FB, KIND, S, true, VEC>(pl, a, s) : launch_ring_sf<T, FB, KIND, S, false, VEC>(pl, a, s);
 }
 
-template <typename T, typename FB, int KIND> static int launch_ring_k(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
+template <typename T, typename FB, int KIND, int VEC = 16 / (int)sizeof(T)> static int launch_ring_k(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   switch (a.S) {
-    case 5: return launch_ring_s<T, FB, KIND, 5>(pl, a, s);
-    case 6: return launch_ring_s<T, FB, KIND, 6>(pl, a, s);
-    case 7: return launch_ring_s<T, FB, KIND, 7>(pl, a, s);
-    case 8: return launch_ring_s<T, FB, KIND, 8>(pl, a, s);
+    case 5: return launch_ring_s<T, FB, KIND, 5, VEC>(pl, a, s);
+    case 6: return launch_ring_s<T, FB, KIND, 6, VEC>(pl, a, s);
+    case 7: return launch_ring_s<T, FB, KIND, 7, VEC>(pl, a, s);
+    case 8: return launch_ring_s<T, FB, KIND, 8, VEC>(pl, a, s);
   }
   return GCMF_ERR_INVALID_ARG;
 }
@@ -481,10 +481,8 @@ template <typename T, typename FB, int KIND> static int launch_ring_k(gcmf_plan 
 template <int KIND> static int launch_ring_kind(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   if (pl->d.dtype == GCMF_F64) return launch_ring_k<double, double, KIND>(pl, a, s);
   if constexpr (KIND == K_FLUX) {
-    // f32 state (four cells per lane, f64 fbar): the rings need 510 registers and the AGPR traffic of the f64 fbar ring
-    // makes the kernel slower than k_flux_multi2 (IRREGULAR 2400x3600 f32: 405 against 485 G) -- not instantiated
-    set_error("k_ring: the flux kinds run in f64 only");
-    return GCMF_ERR_UNSUPPORTED;
+    // f32 state of the flux kinds: its own translation unit (gcmf_ring_flux_f32.hip, two cells per lane)
+    return launch_ring_flux_f32(pl, a, s);
   } else {
     if (a.fb_is_f32) return launch_ring_k<float, float, KIND>(pl, a, s);
     return launch_ring_k<float, double, KIND>(pl, a, s);

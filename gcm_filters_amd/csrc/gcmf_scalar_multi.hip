@@ -41,7 +41,7 @@ bool ring_supported(const gcmf_plan *pl, const MultiArgs &a) {
     return a.land_zero != 0;
   }
   if (pl->kind == K_MASK) return true;
-  if (pl->kind == K_FLUX) return pl->d.dtype == GCMF_F64;  // f32 flux: k_flux_multi2 is faster (see gcmf_ring_impl.hpp)
+  if (pl->kind == K_FLUX) return pl->d.dtype == GCMF_F64 || pl->ring_flux_f32;  // (f32: two cells per lane, gcmf_ring_flux_f32.hip)
   return pl->kind == K_REG;
 }
 

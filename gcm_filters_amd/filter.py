@@ -288,7 +288,7 @@ class Filter:
         (carried in float32 in Reinsch's form of the recurrence: 0.55-0.6 x the error of the reference's float32 path, e.g.
         1.8e-6 instead of 3.2e-6 at n_steps 44).  float32 scalar and VECTOR_B_GRID fields take the forward recurrence (round 5):
         summed backwards in float32 they are 15-45 x (B-grid 2-3 x) further from float64 arithmetic than the reference is.
-        ``"backward"``: backward evaluation for those too -- 1.1-1.8 x faster, all float32 (e.g. 9.5e-6 instead of 2.1e-7 on
+        ``"backward"``: backward evaluation for those too -- 1.1-1.5 x faster, all float32 (e.g. 9.5e-6 instead of 2.1e-7 on
         IRREGULAR_WITH_LAND at n_steps 98; inside SURVEY 8d's 1e-4 for float32).  The result is float64 in every case.
     plan_cache : {None, "protect", "verify", "off"}, keyword only (not a field of the reference class)
         The reference builds (and validates) a fresh Laplacian on every call (gcm_filters/filter.py:183); here the folded grid lives in

@@ -78,7 +78,7 @@ typedef enum gcmf_dtype { GCMF_F32 = 0, GCMF_F64 = 1 } gcmf_dtype;
 #define GCMF_NO_RESIDENT 0x8u /* gcmf_apply / gcmf_slab_apply_backward: never use the on-chip (resident) kernel,   */
                               /* csrc/gcmf_resident.hip -- the strip-marching launches of 5..8 levels instead (same bits) */
 #define GCMF_BACKWARD_F32 0x10u /* gcmf_apply, f32 scalar and B-grid plans: evaluate backwards (Clenshaw, all f32) like the f64 */
-                              /* plans.  Faster (1.1-1.8 x) and 2-45 x further from f64 arithmetic than the reference's own f32  */
+                              /* plans.  Faster (1.1-1.5 x) and 2-45 x further from f64 arithmetic than the reference's own f32  */
                               /* path (filter.py:192-206: f32 T_k, f64 running sum), which is the default for these plans.       */
 
 /* Chebyshev step modes for gcmf_cheb_step */

@@ -471,3 +471,50 @@ def test_bgrid_backward_evaluation_is_an_option(dt, nlev, n_steps):
     for g, w in ((gu, wu), (gw, wv)):
         assert np.array_equal(np.isnan(g), np.isnan(w))
         assert np.nanmax(np.abs(g - w)) <= tol * np.nanmax(np.abs(w))
+
+
+@pytest.mark.parametrize("grid", ["IRREGULAR_WITH_LAND", "MOM5T", "TRIPOLAR_POP_WITH_LAND"])
+@pytest.mark.parametrize("nb,n_steps,kw", [(1, 16, {}), (3, 29, dict(nanland=True)), (2, 21, dict(nanwet=True)), (1, 63, dict(f32out=True))])
+def test_f32_flux_forward_ring_kernel(grid, nb, n_steps, kw):
+    """Round 5: f32 scalar fields run the reference's forward scheme by default, and on the flux kinds that is now k_ring<float, double,
+    K_FLUX, S, FIRST, 2> (csrc/gcmf_ring_flux_f32.hip: two cells per lane; 509 -> 815 G on IRREGULAR 2400 x 3600).  Same bits as the general
+    kernel it replaces (k_flux_multi2, plan option ring_flux_f32 = 0), through NaN on land and NaN in a wet cell (the strip is redone by
+    the general march with the ring kernel's window geometry), and against the oracle's f32 path."""
+    import warnings
+    shape = (150, 512)
+    f, gv = T.scalar_case(grid, shape)
+    land = gv["wet_mask"] == 0
+    if nb > 1:
+        f = np.stack([f + 0.1 * i for i in range(nb)])
+    if kw.get("nanland"):
+        f = np.where(land, np.nan, f)
+    if kw.get("nanwet"):
+        f = f.copy()
+        j, i = np.argwhere(~land)[len(np.argwhere(~land)) // 3]
+        f[..., j, i] = np.nan
+    f4 = f.astype("f4")
+    gv4 = {k: v.astype("f4") for k, v in gv.items()}
+    dx = T.grid_dx_min(grid, gv4)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        flt = Filter(filter_scale=4.0 * dx, dx_min=dx, n_steps=n_steps, filter_shape=FilterShape.TAPER, grid_type=GridType[grid], grid_vars=gv4)
+    plan = ALL_KERNELS[GridType[grid]](**gv4)._plan(_lib.F32, shape)
+    lap = ALL_KERNELS[GridType[grid]](**gv4)
+    run = (lambda: lap._run([f4], spec=flt.filter_spec, out_f32=True)[0]) if kw.get("f32out") else (lambda: flt.apply(f4))
+    try:
+        plan.set_option("ring_flux_f32", 0)
+        want = run()
+        assert "k_ring<" not in plan.last_kernel()
+        plan.set_option("ring_flux_f32", 1)
+        got = run()
+        kern = plan.last_kernel()
+        assert re.search(r"k_ring<float, (double|float), 2, \d, (true|false), 2>", kern) or "k_fold_band" in kern or "k_land_fix" in kern, kern
+    finally:
+        plan.set_option("ring_flux_f32", 1)
+    assert got.dtype == (np.float32 if kw.get("f32out") else np.float64)
+    assert np.array_equal(got, want, equal_nan=True)
+    fs = flt.filter_spec
+    with np.errstate(all="ignore"):
+        ref = O.filter_func(O.FilterSpec(fs.n_steps, fs.s_max, np.asarray(fs.p), fs.dx_min_sq), grid, f4, gv4)    # the reference's own f32 path
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    assert np.nanmax(np.abs(got - ref)) <= (2e-5 if kw.get("f32out") else 2e-6) * np.nanmax(np.abs(ref))
