@@ -98,7 +98,8 @@ class SlabFilter:
     ``"p2p"``: peer stores into the neighbours' IPC-mapped mailboxes + flags, two small kernels on the compute stream per
     exchange and no RCCL at all (csrc/gcmf_p2p.hip; the ranks of ONE node; any backend carries the 64-byte handles once).
     ``self_ring`` (one rank, periodic grids): keep ghost rows and exchange with itself -- the whole slab choreography
-    incl. the native exchange on a single GPU.  ``evaluation``: as in ``Filter`` ("reference" = forward recurrence everywhere).
+    incl. the native exchange on a single GPU.  ``evaluation``: as in ``Filter`` ("reference" = forward recurrence everywhere,
+    "backward" = backward also for f32 scalar / B-grid state).
     """
 
     def __init__(self, grid_type, grid_vars: Dict[str, np.ndarray], filter_kwargs: dict, ny: int, nx: int, *,
@@ -215,10 +216,13 @@ class SlabFilter:
                     self.comm.close()
                 self.comm, self.exchange_kind = None, "torch"
         # the backward (Clenshaw) evaluation libgcmf uses on one GPU: every rank must take the same decision
-        if evaluation not in ("auto", "reference"):
-            raise ValueError(f"evaluation must be 'auto' or 'reference', not {evaluation!r}")
-        # evaluation="reference" (as in Filter): the forward recurrence with the reference's accumulation scheme on every rank
-        cut = self.engine.clenshaw_cut(self.n_steps) if (hasattr(self.engine, "clenshaw_cut") and evaluation == "auto") else []
+        if evaluation not in ("auto", "reference", "backward"):
+            raise ValueError(f"evaluation must be 'auto', 'reference' or 'backward', not {evaluation!r}")
+        # evaluation="reference" (as in Filter): the forward recurrence with the reference's accumulation scheme on every rank;
+        # "backward": the backward evaluation also for f32 scalar / B-grid state (the slab plan's clenshaw_f32 switch; all f32, faster)
+        if evaluation == "backward" and hasattr(getattr(self.engine, "plan", None), "set_option"):
+            self.engine.plan.set_option("clenshaw_f32", 1)
+        cut = self.engine.clenshaw_cut(self.n_steps) if (hasattr(self.engine, "clenshaw_cut") and evaluation != "reference") else []
         use = 1 if (cut and (not self.multi or self.halo >= max(cut))) else 0
         if self.world > 1 and dist.is_initialized():
             flag = torch.tensor([use], dtype=torch.int32,
@@ -487,7 +491,7 @@ class SlabFilter:
     def _vector_backward_ok(self, nbatch: int) -> bool:
         """Vector kinds (C-grid, B-grid) with a library-issued exchange: the backward application in ONE call into libgcmf
         (gcmf_slab_apply_backward_vec), like the scalar kinds -- if every rank's plan has the backward kernel for this batch size."""
-        if (self.ncomp != 2 or self.evaluation != "auto" or not self.native_driver or not isinstance(self.engine, HipSlabEngine)
+        if (self.ncomp != 2 or self.evaluation == "reference" or not self.native_driver or not isinstance(self.engine, HipSlabEngine)
                 or (self.multi and self.exchange_kind not in ("native", "p2p"))):
             return False
         ok = self._vec_backward.get(nbatch)

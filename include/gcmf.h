@@ -372,7 +372,8 @@ int gcmf_set_tuning(gcmf_plan *plan, int rows_per_wave, int xcd_remap, int multi
 /* Named per-plan switches (A/B testing, the parity tests): "cgrid_ring" 1 / 0 (the static-ring C-grid kernel of batched f32 levels,
  * gcmf_cgrid_ring.hip; 0 = k_cgrid_stream2c everywhere), "cgrid_ring_smax" 4 / 5 (levels per launch), "cgrid_ring_hmax" (tallest
  * strip, 0 = 96 rows), "ringc9" 1 / 0 (nine levels per k_ringc launch on whole f64 flux grids), "clenshaw_f32" 0 / 1 (GCMF_BACKWARD_F32
- * for every call of this plan, the slab drivers and gcmf_clenshaw_cut included).  Unknown names: GCMF_ERR_INVALID_ARG. */
+ * for every call of this plan, the slab drivers and gcmf_clenshaw_cut included), "ring_flux_f32" 1 / 0 (the forward ring kernel of the f32
+ * flux kinds, gcmf_ring_flux_f32.hip; 0 = k_flux_multi2, same bits).  Unknown names: GCMF_ERR_INVALID_ARG. */
 int gcmf_set_option(gcmf_plan *plan, const char *name, int value);
 
 /* Last error text of the calling thread (never NULL). */
