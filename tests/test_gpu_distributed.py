@@ -27,7 +27,7 @@ CASES = [
     ("VECTOR_B_GRID", (49, 64), 4, 2, "f4"),
     ("TRIPOLAR_POP_WITH_LAND", (120, 64), 4, 2, "f8"),   # NaN on land + land kept out of the state + overlapped exchange
     ("MOM5U", (64, 64), 8, 3, "f4"),            # f32 scalar fields: the reference's forward scheme by default (round 5) ...
-    ("MOM5U", (64, 64), 8, 3, "f4b"),           # ... "f4b": with GCMF_CLENSHAW_F32=1, the backward f32 slab kernels
+    ("MOM5U", (64, 64), 8, 3, "f4b"),           # ... "f4b": SlabFilter(evaluation="backward"), the backward f32 slab kernels
     # 58 rows over 3 ranks = 19 / 19 / 20: only the 20-row rank overlaps its exchange with the first launch and sends its
     # rows before zeroing their land; the receivers run the land-mask kernels in LAND_ZERO mode (found by tools/fuzz_slabs.py)
     ("TRIPOLAR_REGULAR_WITH_LAND_AREA_WEIGHTED", (58, 16), 5, 5, "f8"),
@@ -77,9 +77,7 @@ def _worker(rank, world, port, q, exchange="auto"):
                 continue
             name, back32 = f"{grid}-{shape}-h{halo}-b{nbatch}-{dt}", dt == "f4b"
             dt = "f4" if back32 else dt
-            os.environ.pop("GCMF_CLENSHAW_F32", None)
-            if back32:
-                os.environ["GCMF_CLENSHAW_F32"] = "1"     # (read when a plan is created: the slab plans and the one-GPU plan below)
+            ev = "backward" if back32 else "auto"     # (f32 scalar fields: backward only when asked for, round 5)
             vec = grid in T.VECTOR_GRIDS
             gv = T.vector_grid_vars(grid, shape) if vec else T.scalar_grid_vars(grid, shape)
             fields = [np.stack([T.random_field(shape, 7 + 10 * c + b) for b in range(nbatch)]) for c in range(2 if vec else 1)]
@@ -91,7 +89,7 @@ def _worker(rank, world, port, q, exchange="auto"):
                 fields = [f.astype(np.float32) for f in fields]
             dx = T.grid_dx_min(grid, gv) if O.DIMENSIONAL[grid] else 1.0
             fk = dict(filter_scale=5.0 * dx, dx_min=dx, filter_shape="GAUSSIAN", **({"n_steps": rest[0]} if rest else {}))
-            sf = SlabFilter(grid, gv, fk, shape[0], shape[1], halo=halo, dtype=np.dtype(dt), device=0, exchange=exchange)
+            sf = SlabFilter(grid, gv, fk, shape[0], shape[1], halo=halo, dtype=np.dtype(dt), device=0, exchange=exchange, evaluation=ev)
             if exchange == "p2p":   # peer stores into IPC-mapped mailboxes (csrc/gcmf_p2p.hip); rows that are not a multiple of 16 bytes fall back
                 assert sf.exchange_kind == ("p2p" if (shape[1] * np.dtype(dt).itemsize) % 16 == 0 else "torch")
             sf.overlap = True   # small test slabs: force the overlapped (edge strips first) exchange where it fits
@@ -107,7 +105,8 @@ def _worker(rank, world, port, q, exchange="auto"):
             if vec:   # the blocked vector kernels really ran on the slabs
                 assert sf.kernel_launches < sf.n_steps, (sf.kernel_launches, sf.n_steps)
             if rank == 0:
-                flt = Filter(filter_scale=fk["filter_scale"], dx_min=dx, grid_type=GridType[grid], grid_vars=gv, n_steps=fk.get("n_steps", 0))
+                flt = Filter(filter_scale=fk["filter_scale"], dx_min=dx, grid_type=GridType[grid], grid_vars=gv, n_steps=fk.get("n_steps", 0),
+                             evaluation=ev)
                 one = flt.apply_to_vector(*fields) if vec else (flt.apply(fields[0]),)
                 spec = O.make_spec(fk["filter_scale"], dx, "GAUSSIAN", n_steps=fk.get("n_steps", 0))
                 with np.errstate(all="ignore"):
@@ -118,7 +117,6 @@ def _worker(rank, world, port, q, exchange="auto"):
                 e_one = max(float(np.abs(nz(g) - nz(w)).max() / np.abs(nz(w)).max()) for g, w in zip(got, one))
                 e_ref = max(float(np.abs(nz(g) - nz(w)).max() / np.abs(nz(w)).max()) for g, w in zip(got, want))
                 res[name] = (e_one, e_ref)
-        os.environ.pop("GCMF_CLENSHAW_F32", None)
         if rank == 0:
             q.put(res)
     finally:
