@@ -18,6 +18,9 @@
 //   * +-inf (nan_to_num clamps it to +-FLT_MAX in the stencil, kernels.py:651-652) is only WATCHED on the delivered rows; a workgroup
 //     that meets one redoes its strip with the full nan_to_num at every level (SAN = true; same arithmetic);
 //   * scalar addressing: row pointers in SGPRs, one 32-bit lane offset (global_load ... saddr).
+//   * LDS-DIRECT LOADS (global_load_lds_dwordx4, gfx950): every operand row (u|v of b_{k+1}, of d_{k+1}, of f) and the wave's share of the
+//     coefficient rows go from memory straight into LDS, 16 bytes per lane, with explicit s_waitcnt vmcnt -- no registers in flight, which
+//     is what lets FIVE levels run at two waves per SIMD.
 //
 //   * the recurrence in REINSCH'S FORM (state planes (b_{k+1}, d_{k+1}), d_k = b_k + b_{k+1}: see gcmf_cgrid_stream2.hip): more accurate in
 //     f32 than the reference's own f32 path.  A level needs d of the level before (one more live row per level than b_{k+2} took), so
@@ -64,22 +67,21 @@ template <typename T> __device__ __forceinline__ T cr_san(T x) {  // numpy.nan_t
 
 constexpr int CR_U = 12;  // unroll factor of the row loop = common period of all rings
 
-// DMA = the operand rows come in through LDS-direct loads (global_load_lds_dwordx4, gfx950): 16 bytes per lane -- the access width the
-// memory pipeline likes (8-byte accesses of this pattern stream at ~4.4 TB/s, experiments/cgrid_probe) -- and no registers in flight.
-// WPB = waves (= levels of the batch) per workgroup: 4, or 8 in the LDS-direct form (one workgroup per CU, the 14 coefficient rows fetched once
-// per EIGHT levels: the coefficient rows were 40 % of the bytes the L2 was asked for)
-template <int S, int D, bool DMA, int WPB = 4> struct CRingGeom {
-  static constexpr int M = DMA ? (S <= 4 ? 4 : 8) : (S + 1) / 2 * 2;   // level j is stale j cells per side; DMA: windows start on a multiple of 4
+// The operand rows come in through LDS-direct loads (global_load_lds_dwordx4, gfx950): 16 bytes per lane -- the access width the memory
+// pipeline likes (8-byte accesses of this pattern stream at ~4.4 TB/s, experiments/cgrid_probe) -- and no registers in flight.  (Round 5
+// also built and measured a plain-load form and eight waves per workgroup; both lost and are gone: launch_cgrid_ring has the numbers.)
+constexpr int CR_WPB = 4;   // waves (= levels of the batch) per workgroup
+template <int S, int D> struct CRingGeom {
+  static constexpr int M = S <= 4 ? 4 : 8;   // level j is stale j cells per side; windows start on a multiple of 4 cells (16-byte loads)
   static constexpr int W = 128, WI = W - 2 * M;
-  // LDS slots of the coefficient ring.  Plain loads: S + 1 (the rows in flight are in registers), a divisor of the period.  DMA: the rows in
-  // flight occupy slots too: S + D, any number (the slot of a row is a scalar that travels with the row).
-  static constexpr int NS = DMA ? S + D : ((S <= 5) ? 6 : 12);
-  static constexpr unsigned SLOTB = (DMA ? 14u : 16u) * 512u;          // bytes per slot (f32: 128 cells x 4 bytes per plane)
-  static constexpr unsigned DUMMY_OFF = NS * SLOTB;                    // DMA: where the fourth wave's padding planes land
-  static constexpr unsigned STG_OFF = DUMMY_OFF + 1024u;               // DMA: the waves' staging slots: D per wave x (u0|v0, up|vp, fu|fv)
+  // LDS slots of the coefficient ring: the rows in flight occupy slots too: S + D (the slot of a row is a scalar that travels with the row)
+  static constexpr int NS = S + D;
+  static constexpr unsigned SLOTB = 14u * 512u;                        // bytes per slot (f32: 128 cells x 4 bytes per plane)
+  static constexpr unsigned DUMMY_OFF = NS * SLOTB;                    // where the fourth wave's padding planes land
+  static constexpr unsigned STG_OFF = DUMMY_OFF + 1024u;               // the waves' staging slots: D per wave x (u0|v0, up|vp, fu|fv)
   static constexpr unsigned STGB = 3072u;
-  static constexpr size_t lds_bytes() { return DMA ? (size_t)STG_OFF + (unsigned)WPB * D * STGB : (size_t)NS * SLOTB; }
-  static constexpr int NDC = 8 / WPB;   // DMA: coefficient loads per wave and row (two planes each; 16 plane slots over WPB waves)
+  static constexpr size_t lds_bytes() { return (size_t)STG_OFF + (unsigned)CR_WPB * D * STGB; }
+  static constexpr int NDC = 8 / CR_WPB;   // coefficient loads per wave and row (two planes each; 16 plane slots over the waves)
 };
 
 #pragma clang diagnostic ignored "-Winline-asm"   // (M0 on the clobber list: the compiler has no use of its own for it in these kernels)
@@ -126,95 +128,53 @@ struct CRingCursor {
 
 // A helper wave (a level that pads the last workgroup of a tile): fetches and publishes its share of the coefficient rows, keeps the
 // barriers, computes nothing.
-template <typename T, int S, int D, bool DMA, int WPB>
-__device__ __forceinline__ void cgring_helper(const CRingP<T> &P, unsigned char *s_raw, const int lane, const int wv, const unsigned colB,
-                                              const int pos0, const int r_begin, const int r_end, const int n_pad) {
-  typedef typename CgV2<T>::type v2;
-  typedef CRingGeom<S, D, DMA, WPB> G;
-  constexpr int NS = G::NS, RSH = D + 1;
-  typedef v2 Slot[16][64];
-  Slot *s_coef = reinterpret_cast<Slot *>(s_raw);
+template <typename T, int S, int D>
+__device__ __forceinline__ void cgring_helper(const CRingP<T> &P, unsigned char *s_raw, const int lane, const int wv, const int pos0,
+                                              const int r_begin, const int r_end, const int n_pad) {
+  typedef CRingGeom<S, D> G;
+  constexpr int NS = G::NS, NDC = G::NDC, PPW = 2 * NDC;   // PPW: planes per wave
   CRingCursor cur(P.nx, P.rows, P.wrap, r_begin, r_end, (unsigned)sizeof(T));
-  if constexpr (DMA) {
-    constexpr int NDC = G::NDC, PPW = 2 * NDC;   // planes per wave
-    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)s_raw);
-    const int half = lane >> 5;
-    int c4 = (pos0 + 4 * (lane & 31)) % P.nx;
-    if (c4 < 0) c4 += P.nx;
-    const char *q_c[NDC];
-    bool isa[NDC];
+  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)s_raw);
+  const int half = lane >> 5;
+  int c4 = (pos0 + 4 * (lane & 31)) % P.nx;
+  if (c4 < 0) c4 += P.nx;
+  const char *q_c[NDC];
+  bool isa[NDC];
 #pragma unroll
-    for (int h = 0; h < NDC; ++h) {
-      const int pa = PPW * wv + 2 * h + half;
-      q_c[h] = reinterpret_cast<const char *>(P.coef[pa < 14 ? pa : 0]) + (unsigned)c4 * 4u;
-      isa[h] = pa < 7 || pa >= 14;
-    }
-    unsigned nxt = 0;
-    auto issue = [&]() {
-      cur.advance();
-#pragma unroll
-      for (int h = 0; h < NDC; ++h)
-        cr_dma16(q_c[h] + (isa[h] ? cur.ro : cur.rc), (PPW * wv + 2 * h >= 14) ? lds0 + G::DUMMY_OFF : lds0 + nxt + (unsigned)(PPW * wv + 2 * h) * 512u);
-      nxt = (nxt + G::SLOTB == NS * G::SLOTB) ? 0u : nxt + G::SLOTB;
-    };
-#pragma unroll
-    for (int q = 0; q < D; ++q) issue();
-    for (int r = r_begin; r < r_begin + n_pad; ++r) {
-      cr_wait_vm<NDC * (D - 1)>();
-      __syncthreads();
-      issue();
-    }
-    cr_wait_vm<0>();
-  } else {
-  static_assert(DMA || WPB == 4, "plain loads: four waves per workgroup");
-  const T *cp[4];
-  bool isA[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int pidx = wv + 4 * q;
-    cp[q] = P.coef[pidx < 14 ? pidx : 0];
-    isA[q] = pidx < 7 || pidx >= 14;
+  for (int h = 0; h < NDC; ++h) {
+    const int pa = PPW * wv + 2 * h + half;
+    q_c[h] = reinterpret_cast<const char *>(P.coef[pa < 14 ? pa : 0]) + (unsigned)c4 * 4u;
+    isa[h] = pa < 7 || pa >= 14;
   }
-  v2 SH[RSH][4];
-  auto issue = [&](auto ph_c) {
-    constexpr int ph = decltype(ph_c)::value;
+  unsigned nxt = 0;
+  auto issue = [&]() {
     cur.advance();
-    const unsigned vo = colB + cur.ro, vc = colB + cur.rc;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      SH[ph % RSH][q] = *reinterpret_cast<const v2 *>(reinterpret_cast<const char *>(cp[q]) + (isA[q] ? vo : vc));
+    for (int h = 0; h < NDC; ++h)
+      cr_dma16(q_c[h] + (isa[h] ? cur.ro : cur.rc), (PPW * wv + 2 * h >= 14) ? lds0 + G::DUMMY_OFF : lds0 + nxt + (unsigned)(PPW * wv + 2 * h) * 512u);
+    nxt = (nxt + G::SLOTB == NS * G::SLOTB) ? 0u : nxt + G::SLOTB;
   };
-  auto phase = [&](auto ph_c) {
-    constexpr int ph = decltype(ph_c)::value;
-    issue(cic<(ph + D) % CR_U>{});
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s_coef[ph % NS][wv + 4 * q][lane] = SH[ph % RSH][q];
+  for (int q = 0; q < D; ++q) issue();
+  for (int r = r_begin; r < r_begin + n_pad; ++r) {
+    cr_wait_vm<NDC * (D - 1)>();
     __syncthreads();
-  };
-  issue(cic<0>{});
-  if constexpr (D >= 2) issue(cic<1>{});
-  if constexpr (D >= 3) issue(cic<2>{});
-  for (int r = r_begin; r < r_begin + n_pad; r += CR_U) {
-    phase(cic<0>{});  phase(cic<1>{});  phase(cic<2>{});  phase(cic<3>{});  phase(cic<4>{});  phase(cic<5>{});
-    phase(cic<6>{});  phase(cic<7>{});  phase(cic<8>{});  phase(cic<9>{});  phase(cic<10>{});  phase(cic<11>{});
+    issue();
   }
-  }
+  cr_wait_vm<0>();
 }
 
 // One march of a strip by one wave (one level of the batch).  Returns whether a +-inf was delivered (wave-uniform); SAN = the redo pass.
-template <typename T, int S, int D, bool FIRST, bool SAN, bool DMA, int WPB>
+template <typename T, int S, int D, bool FIRST, bool SAN>
 __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *s_raw, const int lane, const int wv, const long long boff,
                                              const unsigned colB, const int pos0, const bool keep, const int a, const int b, const int n_pad) {
   typedef typename CgV2<T>::type v2;
-  typedef CRingGeom<S, D, DMA, WPB> G;
+  typedef CRingGeom<S, D> G;
   constexpr int NS = G::NS;
-  constexpr int U = CR_U, RU = 6, RV = DMA ? 1 : D + 1, RF = 12, RSH = D + 1;
+  constexpr int U = CR_U, RU = 6, RF = 12;
   constexpr int NDC = G::NDC, PPW = 2 * NDC;
-  static_assert(DMA || WPB == 4, "plain loads: four waves per workgroup");
-  static_assert(D >= 1 && D <= 3 && S >= 2 && S + D <= RF && S < NS && (DMA || (U % NS == 0 && U % RV == 0)) && U % D == 0, "ring periods");
-  static_assert(!DMA || sizeof(T) == 4, "LDS-direct loads: f32 state");
-  typedef v2 Slot[16][64];
-  Slot *s_coef = reinterpret_cast<Slot *>(s_raw);
+  static_assert(D >= 1 && D <= 3 && S >= 2 && S + D <= RF && S < NS && U % D == 0, "ring periods");
+  static_assert(sizeof(T) == 4, "LDS-direct loads of 16 bytes = four cells: f32 state");
   const int nx = P.nx, rows = P.rows;
   const bool wrap = P.wrap, last = P.last;
   const T c = (T)P.c;
@@ -222,31 +182,19 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
   const T *pu0 = (FIRST ? P.fu : P.u0) + boff, *pv0 = (FIRST ? P.fv : P.v0) + boff;
   const T *pup = (FIRST ? P.fu : P.up) + boff, *pvp = (FIRST ? P.fv : P.vp) + boff;  // (first launch: never loaded)
   const T *pfu = P.fu + boff, *pfv = P.fv + boff;
-  const T *cp[4];
-  bool isA[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int pidx = wv + 4 * q;   // planes 0..6 travel with the delivered row, 7..13 with the row before; 14, 15: padding
-    cp[q] = P.coef[pidx < 14 ? pidx : 0];
-    isA[q] = pidx < 7 || pidx >= 14;
-  }
-  // (plane pointer in scalar registers) + (32-bit byte offset of the lane's cells in the row): the global_load saddr form
-  auto ld2 = [&](const T *plane, unsigned voff) { return *reinterpret_cast<const v2 *>(reinterpret_cast<const char *>(plane) + voff); };
   CRingCursor cur(nx, rows, wrap, r_begin, r_end, (unsigned)sizeof(T));
 
   const v2 Z = {T(0), T(0)};
   v2 G0u[RU], G0v[RU];         // delivered rows of b_{k+1} ("level 0"); slot = (row - r_begin) mod RU
-  v2 Vu[RV], Vv[RV];           // rows of b_{k+2}; slot = (iteration) mod RV
+  v2 Vu, Vv;                   // the delivered row of d_{k+1} (read out of the staging slot every iteration)
   v2 Fu[RF], Fv[RF];           // rows of f; slot = (iteration that delivered them) mod RF
-  v2 SH[RSH][4];               // this wave's share of the coefficient rows, in flight
   v2 Xu[S][3], Xv[S][3];       // X[m], m = 1 .. S - 1: rows of b of level m; slot = (iteration that produced them) mod 3 (two are live)
   v2 Du[S][2], Dv[S][2];       // D[m], m = 1 .. S - 1: the row of d level m produced; slot = (iteration) mod 2
   v2 Lvt[S + 1][2], Lvh[S + 1][2], Luh[S + 1][2], LP[S + 1][2], LQ[S + 1][2], LR[S + 1][2];  // per level: what the previous row hands on
   bool Ku0[U], Ku1[U], Kv0[U], Kv1[U];   // "not NaN" of the delivered rows; slot = (row - r_begin) mod U
 #pragma unroll
   for (int l = 0; l < RU; ++l) G0u[l] = G0v[l] = Z;
-#pragma unroll
-  for (int l = 0; l < RV; ++l) Vu[l] = Vv[l] = Z;
+  Vu = Vv = Z;
 #pragma unroll
   for (int l = 0; l < RF; ++l) Fu[l] = Fv[l] = Z;
 #pragma unroll
@@ -264,24 +212,8 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
   for (int l = 0; l < U; ++l) Ku0[l] = Ku1[l] = Kv0[l] = Kv1[l] = true;
   bool seen_inf = false;
 
-  auto issue = [&](auto ph_c) {  // the loads of the next iteration, into the slots of its phase
-    constexpr int ph = decltype(ph_c)::value;
-    cur.advance();   // (the padded iterations of the last period re-load the last row and store nothing)
-    const unsigned vo = colB + cur.ro, vc = colB + cur.rc;
-    G0u[ph % RU] = ld2(pu0, vo);
-    G0v[ph % RU] = ld2(pv0, vo);
-    if constexpr (!FIRST) {
-      Vu[ph % RV] = ld2(pup, vc);
-      Vv[ph % RV] = ld2(pvp, vc);
-    }
-    Fu[ph % RF] = ld2(pfu, vc);
-    Fv[ph % RF] = ld2(pfv, vc);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) SH[ph % RSH][q] = ld2(cp[q], isA[q] ? vo : vc);
-  };
-
-  // ---- DMA: per-lane global pointers (lanes 0..31 fetch the first plane of a pair, four cells each, lanes 32..63 the second) ----
-  unsigned slot_of[U];   // DMA: byte offset of the coefficient slot a row's planes went to; slot = (row - r_begin) mod U
+  // ---- per-lane global pointers (lanes 0..31 fetch the first plane of a pair, four cells each, lanes 32..63 the second) ----
+  unsigned slot_of[U];   // byte offset of the coefficient slot a row's planes went to; slot = (row - r_begin) mod U
 #pragma unroll
   for (int l = 0; l < U; ++l) slot_of[l] = 0u;
   unsigned nxt_slot = 0u;
@@ -297,7 +229,8 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
   bool isa[NDC];
 #pragma unroll
   for (int h = 0; h < NDC; ++h) {
-    const int pa = PPW * wv + 2 * h + half;   // this wave's share of the 14 coefficient planes (slots 14, 15: padding)
+    const int pa = PPW * wv + 2 * h + half;   // this wave's share of the 14 coefficient planes (planes 0..6 travel with the delivered row,
+    //                                           7..13 with the row before; slots 14, 15: padding)
     q_c[h] = reinterpret_cast<const char *>(P.coef[pa < 14 ? pa : 0]) + c4B;
     isa[h] = pa < 7 || pa >= 14;
   }
@@ -323,7 +256,6 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
   auto level = [&](auto jj, auto ph_c) {
     constexpr int j = decltype(jj)::value;
     constexpr int ph = decltype(ph_c)::value;
-    constexpr int sl = DMA ? 0 : cmod(ph - (j - 1), NS);      // the LDS slot published in iteration r - j + 1
     constexpr int kn = cmod(ph - (j - 1), U);       // NaN masks of row rho
     constexpr int n3 = ph % 3, o3 = cmod(ph - 1, 3);
     const v2 inu = (j == 1) ? G0u[ph % RU] : Xu[j >= 2 ? j - 1 : 1][n3];
@@ -331,8 +263,8 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
     const v2 xu = (j == 1) ? G0u[cmod(ph - 1, RU)] : Xu[j >= 2 ? j - 1 : 1][o3];   // row rho - 1 of level j - 1: the "-x" term
     const v2 xv = (j == 1) ? G0v[cmod(ph - 1, RU)] : Xv[j >= 2 ? j - 1 : 1][o3];
     // d_{k+1}, row rho - 1: what level j - 1 produced one iteration ago (level 1: the delivered row of d; first launch: d_n = b_n)
-    const v2 dpu = (j == 1) ? (FIRST ? xu : Vu[ph % RV]) : Du[j >= 2 ? j - 1 : 1][cmod(ph - 1, 2)];
-    const v2 dpv = (j == 1) ? (FIRST ? xv : Vv[ph % RV]) : Dv[j >= 2 ? j - 1 : 1][cmod(ph - 1, 2)];
+    const v2 dpu = (j == 1) ? (FIRST ? xu : Vu) : Du[j >= 2 ? j - 1 : 1][cmod(ph - 1, 2)];
+    const v2 dpv = (j == 1) ? (FIRST ? xv : Vv) : Dv[j >= 2 ? j - 1 : 1][cmod(ph - 1, 2)];
     const v2 fu = Fu[cmod(ph - j + 1, RF)], fv = Fv[cmod(ph - j + 1, RF)];        // row rho - 1 of f
     v2 su, sv;
     if constexpr (SAN) {
@@ -342,20 +274,12 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
       su.x = Ku0[kn] ? inu.x : T(0);  su.y = Ku1[kn] ? inu.y : T(0);
       sv.x = Kv0[kn] ? inv.x : T(0);  sv.y = Kv1[kn] ? inv.y : T(0);
     }
-    v2 A[7], B[7];
-    if constexpr (DMA) {
-      const v2 *cs = reinterpret_cast<const v2 *>(s_raw + slot_of[cmod(ph - (j - 1), U)]);
+    v2 A[7], B[7];   // the coefficient rows of iteration r - j + 1
+    const v2 *cs = reinterpret_cast<const v2 *>(s_raw + slot_of[cmod(ph - (j - 1), U)]);
 #pragma unroll
-      for (int q = 0; q < 7; ++q) {
-        A[q] = cs[q * 64 + lane];
-        B[q] = cs[(7 + q) * 64 + lane];
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 7; ++q) {
-        A[q] = s_coef[sl][q][lane];
-        B[q] = s_coef[sl][7 + q][lane];
-      }
+    for (int q = 0; q < 7; ++q) {
+      A[q] = cs[q * 64 + lane];
+      B[q] = cs[(7 + q) * 64 + lane];
     }
     constexpr int lo = cmod(ph - 1, 2), ln = ph % 2;
     // ---- what the previous row of this level hands on: the last level carries it, the others rebuild it (same operands, same bits) ----
@@ -370,14 +294,9 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
         pu.x = Ku0[kp] ? xu.x : T(0);  pu.y = Ku1[kp] ? xu.y : T(0);
         pv.x = Kv0[kp] ? xv.x : T(0);  pv.y = Kv1[kp] ? xv.y : T(0);
       }
-      v2 A1p, A2p, A3p;   // coefficient rows of the row before: the slot of iteration r - j
-      if constexpr (DMA) {
-        const v2 *cp_ = reinterpret_cast<const v2 *>(s_raw + slot_of[cmod(ph - j, U)]);
-        A1p = cp_[1 * 64 + lane];  A2p = cp_[2 * 64 + lane];  A3p = cp_[3 * 64 + lane];
-      } else {
-        constexpr int slp = cmod(ph - j, NS);
-        A1p = s_coef[slp][1][lane];  A2p = s_coef[slp][2][lane];  A3p = s_coef[slp][3][lane];
-      }
+      // coefficient rows of the row before: the slot of iteration r - j
+      const v2 *cp_ = reinterpret_cast<const v2 *>(s_raw + slot_of[cmod(ph - j, U)]);
+      const v2 A1p = cp_[1 * 64 + lane], A2p = cp_[2 * 64 + lane], A3p = cp_[3 * 64 + lane];
       uh_p = pu * A1p;  vt_p = pv * A2p;  vh_p = pv * A3p;
     } else {
       vt_p = Lvt[j][lo];  vh_p = Lvh[j][lo];  uh_p = Luh[j][lo];
@@ -424,7 +343,7 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
 
   auto phase = [&](auto ph_c, int r) {
     constexpr int ph = decltype(ph_c)::value;
-    if constexpr (DMA) {
+    {
       // this iteration's rows were asked for D iterations ago; the loads of the D - 1 iterations in between may still be in flight
       cr_wait_vm<((FIRST ? 2 : 3) + NDC) * (D - 1)>();
       __syncthreads();   // ... and the other waves' quarters of the coefficient slot are there too
@@ -432,18 +351,12 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
       G0u[ph % RU] = reinterpret_cast<const v2 *>(st)[lane];
       G0v[ph % RU] = reinterpret_cast<const v2 *>(st + 512)[lane];
       if constexpr (!FIRST) {
-        Vu[0] = reinterpret_cast<const v2 *>(st + 1024)[lane];
-        Vv[0] = reinterpret_cast<const v2 *>(st + 1536)[lane];
+        Vu = reinterpret_cast<const v2 *>(st + 1024)[lane];
+        Vv = reinterpret_cast<const v2 *>(st + 1536)[lane];
       }
       Fu[ph % RF] = reinterpret_cast<const v2 *>(st + 2048)[lane];
       Fv[ph % RF] = reinterpret_cast<const v2 *>(st + 2560)[lane];
       issue_dma(cic<(ph + D) % U>{});
-    } else {
-      issue(cic<(ph + D) % U>{});
-      // ---- hand this iteration's coefficient rows round ----
-#pragma unroll
-      for (int q = 0; q < 4; ++q) s_coef[ph % NS][wv + 4 * q][lane] = SH[ph % RSH][q];
-      __syncthreads();
     }
     // ---- the delivered row of b_{k+1}: b_n = p_n f in a first launch; its NaN cells; +-inf watched ----
     {
@@ -498,27 +411,22 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
     }
   };
 
-  if constexpr (DMA) {
-    issue_dma(cic<0>{});
-    if constexpr (D >= 2) issue_dma(cic<1>{});
-    if constexpr (D >= 3) issue_dma(cic<2>{});
-  } else {
-    issue(cic<0>{});
-    if constexpr (D >= 2) issue(cic<1>{});
-    if constexpr (D >= 3) issue(cic<2>{});
-  }
+  issue_dma(cic<0>{});
+  if constexpr (D >= 2) issue_dma(cic<1>{});
+  if constexpr (D >= 3) issue_dma(cic<2>{});
   for (int r = r_begin; r < r_begin + n_pad; r += U) {
     phase(cic<0>{}, r);  phase(cic<1>{}, r + 1);  phase(cic<2>{}, r + 2);  phase(cic<3>{}, r + 3);
     phase(cic<4>{}, r + 4);  phase(cic<5>{}, r + 5);  phase(cic<6>{}, r + 6);  phase(cic<7>{}, r + 7);
     phase(cic<8>{}, r + 8);  phase(cic<9>{}, r + 9);  phase(cic<10>{}, r + 10);  phase(cic<11>{}, r + 11);
   }
-  if constexpr (DMA) cr_wait_vm<0>();   // (nothing of this march may land in LDS after a redo pass -- or the next workgroup -- has taken it over)
+  cr_wait_vm<0>();   // (nothing of this march may land in LDS after a redo pass -- or the next workgroup -- has taken it over)
   return __any(seen_inf);
 }
 
-template <typename T, int S, int D, bool FIRST, int WPS, bool DMA, int WPB>
-__global__ __launch_bounds__(64 * WPB, WPS) void k_cgrid_ring(const CRingP<T> P) {
-  typedef CRingGeom<S, D, DMA, WPB> G;
+template <typename T, int S, int D, bool FIRST, int WPS>
+__global__ __launch_bounds__(64 * CR_WPB, WPS) void k_cgrid_ring(const CRingP<T> P) {
+  constexpr int WPB = CR_WPB;
+  typedef CRingGeom<S, D> G;
   constexpr int M = G::M, W = G::W, WI = G::WI;
   extern __shared__ __align__(16) unsigned char s_raw[];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -543,16 +451,16 @@ __global__ __launch_bounds__(64 * WPB, WPS) void k_cgrid_ring(const CRingP<T> P)
   const int pos = pos0 + lane * 2;
   int col = pos % nx;
   if (col < 0) col += nx;
-  const unsigned colB = (unsigned)col * (unsigned)sizeof(T);
+  const unsigned colB = (unsigned)col * (unsigned)sizeof(T);   // byte offset of the lane's two cells in a row (the stores)
   const bool keep = (lane * 2 >= M) && (lane * 2 < W - M) && (pos < nx);
   const int n_pad = ((b - a) + 2 * S + CR_U - 1) / CR_U * CR_U;   // the march is padded to whole ring periods
   bool bad = false;
-  if (shadow) cgring_helper<T, S, D, DMA, WPB>(P, s_raw, lane, wv, colB, pos0, a - S, b + S, n_pad);
-  else bad = cgring_march<T, S, D, FIRST, false, DMA, WPB>(P, s_raw, lane, wv, boff, colB, pos0, keep, a, b, n_pad);
+  if (shadow) cgring_helper<T, S, D>(P, s_raw, lane, wv, pos0, a - S, b + S, n_pad);
+  else bad = cgring_march<T, S, D, FIRST, false>(P, s_raw, lane, wv, boff, colB, pos0, keep, a, b, n_pad);
   if (__syncthreads_or(bad ? 1 : 0)) {   // a +-inf somewhere in the workgroup's rows: the strip again, nan_to_num in full at every level
     if (threadIdx.x == 0 && P.redo) atomicAdd(P.redo, 1u);
-    if (shadow) cgring_helper<T, S, D, DMA, WPB>(P, s_raw, lane, wv, colB, pos0, a - S, b + S, n_pad);
-    else cgring_march<T, S, D, FIRST, true, DMA, WPB>(P, s_raw, lane, wv, boff, colB, pos0, keep, a, b, n_pad);
+    if (shadow) cgring_helper<T, S, D>(P, s_raw, lane, wv, pos0, a - S, b + S, n_pad);
+    else cgring_march<T, S, D, FIRST, true>(P, s_raw, lane, wv, boff, colB, pos0, keep, a, b, n_pad);
   }
 }
 
@@ -569,8 +477,8 @@ bool cgrid_ring_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
   return true;
 }
 
-template <typename T, int S, int D, int WPS, bool DMA, int WPB = 4> static int launch_cr(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
-  constexpr int WI = CRingGeom<S, D, DMA, WPB>::WI;
+template <typename T, int S, int D, int WPS> static int launch_cr(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
+  constexpr int WI = CRingGeom<S, D>::WI, WPB = CR_WPB;
   const Geom &g = pl->g;
   CRingP<T> P;
   P.u0 = (const T *)a.u0[0];  P.v0 = (const T *)a.u0[1];
@@ -627,7 +535,7 @@ template <typename T, int S, int D, int WPS, bool DMA, int WPB = 4> static int l
   const long long groups_per_xcd = (P.ngroups + 7) / 8;
   const long long blocks_per_xcd = (groups_per_xcd * P.nlevp + WPB - 1) / WPB;
   dim3 block(64 * WPB), grid((unsigned)(blocks_per_xcd * 8));
-  const size_t lds = CRingGeom<S, D, DMA, WPB>::lds_bytes();
+  const size_t lds = CRingGeom<S, D>::lds_bytes();
   auto go = [&](auto kern, bool &attr_set) -> int {
     if (!attr_set && lds > 48 * 1024) {
       GCMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -637,10 +545,10 @@ template <typename T, int S, int D, int WPS, bool DMA, int WPB = 4> static int l
     return GCMF_OK;
   };
   static bool set_first = false, set_next = false;  // per instantiation
-  int rc = a.first ? go(&k_cgrid_ring<T, S, D, true, WPS, DMA, WPB>, set_first) : go(&k_cgrid_ring<T, S, D, false, WPS, DMA, WPB>, set_next);
+  int rc = a.first ? go(&k_cgrid_ring<T, S, D, true, WPS>, set_first) : go(&k_cgrid_ring<T, S, D, false, WPS>, set_next);
   if (rc) return rc;
   note_kernel(pl, std::string("gcmf::k_cgrid_ring<") + tyname<T>() + ", " + std::to_string(S) + ", " + std::to_string(D) + ", " +
-                      (a.first ? "true" : "false") + ", " + std::to_string(WPS) + ", " + (DMA ? "true" : "false") + ", " + std::to_string(WPB) + ">", S,
+                      (a.first ? "true" : "false") + ", " + std::to_string(WPS) + ">", S,
               launch_geom(P.H, (nrows + H - 1) / H, P.nwx, 1, grid.x, grid.y, nrows));
   GCMF_HIP(hipGetLastError());
   return GCMF_OK;
@@ -661,11 +569,11 @@ int launch_cgrid_ring(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
   // moves 1.5 x its algorithmic bytes and that only half of the re-reads of a group's 13 workgroups hit in the L2 -- they start up to a
   // fifth of a strip apart): the non-temporal hint on the state rows' loads, to leave the L2 to the coefficient rows: 388; a persistent
   // launch of teams (416 workgroups, the 13 of a group walking through their strips together, no waiting between them): 365 -- both
-  // the same bits, both slower (profiles/r05/cfg5_*.txt).  Only the LDS-direct form is built (the plain-load code paths of the templates
-  // above are what the A/B runs of round 5 used; they are no longer instantiated).
+  // the same bits, both slower (profiles/r05/cfg5_*.txt).  Only the LDS-direct form with four waves per workgroup is left in this file
+  // (profiles of round 5 taken before the clean-up name the kernel k_cgrid_ring<float, 5, 2, false, 2, true, 4>: the same code).
   switch (a.S) {   // (LDS-direct loads: windows start on multiples of four cells -- cgrid_ring_supported asked for nx % 4 == 0)
-    case 4: return launch_cr<float, 4, 2, 2, true>(pl, a, s);
-    case 5: return launch_cr<float, 5, 2, 2, true>(pl, a, s);
+    case 4: return launch_cr<float, 4, 2, 2>(pl, a, s);
+    case 5: return launch_cr<float, 5, 2, 2>(pl, a, s);
   }
   return GCMF_ERR_INVALID_ARG;
 }
