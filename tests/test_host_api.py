@@ -439,3 +439,18 @@ def test_build_is_serialised_and_a_fresh_binary_is_not_rebuilt(tmp_path):
     if _build.binary_build_id() == _build.source_build_id():
         before = os.path.getmtime(_build.LIB)
         assert _build.build_library() == _build.LIB and os.path.getmtime(_build.LIB) == before
+
+
+def test_evaluation_keyword_values():
+    """`evaluation` is a keyword-only extension of the reference's dataclass: "auto" (default), "reference" (the reference's forward
+    recurrence and accumulation scheme), "backward" (backward evaluation also for f32 scalar / B-grid fields); anything else raises at
+    construction, like the reference's own field validation (gcm_filters/filter.py:389-434)."""
+    from gcm_filters_amd.filter import EVALUATIONS
+    assert EVALUATIONS == ("auto", "reference", "backward")
+    for ev in EVALUATIONS:
+        flt = Filter(filter_scale=4.0, dx_min=1.0, grid_type=GridType.REGULAR, evaluation=ev)
+        assert flt.evaluation == ev and "evaluation" not in repr(flt)
+    with pytest.raises(ValueError, match="evaluation must be one of"):
+        Filter(filter_scale=4.0, dx_min=1.0, grid_type=GridType.REGULAR, evaluation="fast")
+    with pytest.raises(TypeError):
+        Filter(4.0, 1.0, FilterShape.GAUSSIAN, np.pi, 2, 0, GridType.REGULAR, {}, "reference")   # keyword only
