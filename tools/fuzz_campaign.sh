@@ -11,6 +11,9 @@ OUT=$PWD/gpurun_out/fuzz; mkdir -p "$OUT"; S=${1:-400}
   timeout 600 python tools/fuzz_gpu.py $((S+6)) 300 --tiny
   GCMF_RESIDENT=1 timeout 600 python tools/fuzz_gpu.py $((S+7)) 250
   GCMF_RESIDENT=0 timeout 600 python tools/fuzz_gpu.py $((S+8)) 150
+  timeout 600 python tools/fuzz_gpu.py $((S+30)) 200 --eval backward
+  timeout 600 python tools/fuzz_gpu.py $((S+31)) 200 --eval reference
+  timeout 600 python tools/fuzz_gpu.py $((S+32)) 80 --eval backward --bgrid
   timeout 600 python tools/fuzz_nsteps.py
   timeout 600 python tools/fuzz_inputs.py $((S+9))
   for w in 2 3; do for ex in auto p2p; do timeout 900 python tools/fuzz_slabs.py $((S+10+w)) 30 $w $ex; done; done

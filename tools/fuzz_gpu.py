@@ -6,6 +6,8 @@ from gcm_filters_amd import Filter, FilterShape, GridType, testing as T
 from gcm_filters_amd.kernels import clear_plan_cache
 from oracle import gcmf_oracle as O
 
+# --eval auto|reference|backward: the Filter's evaluation order (default auto; "backward" = the all-f32 backward kernels for f32 scalar / B-grid fields)
+EVAL = sys.argv[sys.argv.index("--eval") + 1] if "--eval" in sys.argv else "auto"
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 worst = {}
@@ -62,7 +64,8 @@ for it in range(ncase):
         import warnings
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            flt = Filter(filter_scale=scale, dx_min=dx, filter_shape=FilterShape[shp], n_steps=n_steps, grid_type=GridType[grid], grid_vars=gv)
+            flt = Filter(filter_scale=scale, dx_min=dx, filter_shape=FilterShape[shp], n_steps=n_steps, grid_type=GridType[grid], grid_vars=gv,
+                         evaluation=EVAL)
             if "--tune" in sys.argv:  # random blocking depth / strip height / prefetch depth of the plan this case uses
                 from gcm_filters_amd import _lib
                 from gcm_filters_amd.kernels import ALL_KERNELS
