@@ -381,9 +381,6 @@ def roofline_of(cfg, r, steps, default_tuning):
     achieved = minb / (avg_ms * 1e-3) / 1e9
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "traffic": rec.get("bytes_per_launch") if rec else None, "traffic_source": src,
-           "frac_basis": "algorithmic bytes of one launch (each operand plane of SURVEY 8d's count read once, each result plane "
-                         "written once: a blocked launch is ONE pass over HBM whatever its depth) / HIP-event launch time / 8 TB/s; "
-                         "hbm_frac = the same with the PMC-counted bytes (`traffic`)",
            "kernel": r["kernel"], "geometry": r.get("geometry"), "avg_launch_ms": avg_ms, "min_launch_ms": r["dom_min"], "max_launch_ms": r["dom_max"],
            "launches_of_it_per_application": r["dom_n"] / r["dom_reps"], "steps_per_launch": steps_per_launch,
            "recurrence_ms_per_application": r["kernel_ms"] / r["dom_reps"],
@@ -538,7 +535,7 @@ def run_host_path(dev, args):
     d = torch.from_numpy(f).to(dev)
     flt.apply(d)
     torch.cuda.synchronize()
-    rec = {"what": "config 3 on HOST buffers (numpy in / out), ms per 2400x3600 f64 field; PCIe-inclusive, never `value`", "field_MB": mb}
+    rec = {"field_MB": mb}   # config 3 on HOST buffers, ms per 2400x3600 f64 field; PCIe-inclusive, never `value`
     rec["recurrence_ms_field_resident"] = best(lambda: flt.apply(d))
     hbuf = torch.empty_like(d, device="cpu")
     rec["h2d_ms_pageable"] = best(lambda: d.copy_(torch.from_numpy(f)))
@@ -577,6 +574,75 @@ def run_host_path(dev, args):
                                              "row_block_pipeline": f.size * n / (rec["row_block_pipeline_ms"] * 1e-3),
                                              "batch_of_8": f.size * n / (rec["batch_of_8_ms_per_field"] * 1e-3)}
     return rec
+
+
+def run_midsize(dev):
+    """The reference's own tutorial size (1080 x 1440, /docs/examples/example_tripole_grid.ipynb: a 1/4-degree ocean) with the headline's
+    grid type and filter (IRREGULAR_WITH_LAND f64, Taper, filter_scale 16 dx_min, n_steps 63): too big for the on-chip kernel, small enough
+    that the strips of the marching launches are short.  Not a BASELINE config; reported in `summary`."""
+    import torch
+
+    from gcm_filters_amd import Filter, FilterShape, GridType, testing as T
+
+    shape = (1080, 1440)
+    f, gv = T.scalar_case("IRREGULAR_WITH_LAND", shape)
+    dx = T.grid_dx_min("IRREGULAR_WITH_LAND", gv)
+    flt = Filter(filter_scale=16 * dx, dx_min=dx, filter_shape=FilterShape.TAPER, grid_type=GridType.IRREGULAR_WITH_LAND, grid_vars=gv)
+    d = torch.from_numpy(f).to(dev)
+    for _ in range(5):
+        flt.apply(d)
+    torch.cuda.synchronize()
+    blocks = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for _ in range(50):
+            flt.apply(d)
+        torch.cuda.synchronize()
+        blocks.append((time.perf_counter() - t0) / 50)
+    t = sorted(blocks)[2]
+    n = int(flt.n_steps)
+    return {"config": f"extra: IRREGULAR_WITH_LAND 1080x1440 f64, Taper filter_scale=16 dx_min, n_steps={n} (the reference's tutorial size)",
+            "n_steps": n, "value": shape[0] * shape[1] * n / t, "unit": "cell-steps/s", "us_per_application": 1e6 * t, "dtype": "f64"}
+
+
+def build_summary(out):
+    """The whole round in <= 1.5 KB, printed LAST in the line (the driver's record keeps the tail): per workload
+    [G cell-steps/s, roofline frac (algorithmic bytes of one launch / launch time / 8 TB/s), counter traffic / algorithmic bytes, parity
+    rel_err vs the imported reference's probes] -- None where a figure does not exist -- plus the host path's three numbers."""
+    g = lambda v: None if v is None else round(v / 1e9, 1)
+    r3 = lambda v: None if v is None else round(v, 3)
+    e = lambda v: None if v is None else float(f"{v:.1e}")
+
+    def row(rec, parity=None):
+        rf = rec.get("roofline") or {}
+        par = parity if parity is not None else (rec.get("parity") or {})
+        err = par.get("rel_err", (par.get("reference_probes") or {}).get("rel_err"))
+        return [g(rec.get("value")), r3(rf.get("frac")), r3(rf.get("traffic_over_alg_bytes")), e(err)]
+    s = {"cols": ["G cell-steps/s", "frac", "traffic/alg", "parity rel_err"]}
+    main_cfg = out["config"]["workload"].split(":")[0].split()[-1]
+    s["cfg" + main_cfg] = row(out, out.get("parity"))
+    for rec in out.get("extra_configs") or []:
+        name = rec["config"]
+        if name.startswith("BASELINE config"):
+            key = "cfg" + name.split(":")[0].split()[-1]
+        elif "512x512" in name:
+            key = "onchip_512"
+        elif "1080x1440" in name:
+            key = "mid_1080x1440"
+        else:
+            key = name[:24]
+        s[key] = row(rec)
+        opt = rec.get("forward_reference_opt_in")
+        if opt:
+            s[key + "_ref_scheme"] = row(opt)
+    cb = out.get("cpu_baseline") or {}
+    if cb:
+        s["cpu_1core_M"] = round(cb["value"] / 1e6, 1)
+    hp = out.get("host_path")
+    if hp:
+        s["host_ms"] = {"h2d": r3(hp.get("h2d_ms_page_locked")), "d2h": r3(hp.get("d2h_ms_page_locked")),
+                        "pipeline": r3(hp.get("row_block_pipeline_ms")), "batch8_per_field": r3(hp.get("batch_of_8_ms_per_field"))}
+    return s
 
 
 def free_gpu():
@@ -799,7 +865,7 @@ def main_single(args):
                 free_gpu()
                 r2 = run_single(cfg, args, dev, steps=xs, warmup=xw, evaluation="reference")
                 osp = spread_of(r2)
-                opt = {"what": "Filter(evaluation=\"reference\"): forward recurrence, f32 T_k, f64 running sum -- the reference's own precision (NOT the default)",
+                opt = {"evaluation": "reference",   # forward recurrence, f32 T_k, f64 running sum: the reference's own scheme (NOT the default)
                        "kernel": r2["kernel"], "value": osp["value"], "value_min": osp["value_min"], "value_max": osp["value_max"], "unit": "cell-steps/s",
                        "ms_per_step": osp["ms_per_step"], "roofline": roofline_of(cfg, r2, xs, True)}
                 chk2 = golden_probe_check(cfg, 0.0, (args.ny, args.nx), r2["outs"])
@@ -817,7 +883,7 @@ def main_single(args):
                 free_gpu()
                 r2 = run_single(cfg, args, dev, steps=xs, warmup=xw, evaluation="reference")
                 osp = spread_of(r2)
-                opt = {"what": "Filter(evaluation=\"reference\"): forward recurrence, bit-exact with numpy (NOT the default)", "kernel": r2["kernel"],
+                opt = {"evaluation": "reference", "kernel": r2["kernel"],
                        "value": osp["value"], "value_min": osp["value_min"], "value_max": osp["value_max"], "unit": "cell-steps/s",
                        "ms_per_step": osp["ms_per_step"]}
                 chk2 = golden_probe_check(cfg, 0.0, (args.ny, args.nx), r2["outs"])
@@ -828,6 +894,7 @@ def main_single(args):
                 rec["forward_reference_opt_in"] = opt
             extras.append(rec)
         extras.append(small)
+        extras.append(run_midsize(dev))
         out["extra_configs"] = extras
         if args.config == 3 and (args.ny, args.nx) == (2400, 3600):
             r = None
@@ -835,6 +902,7 @@ def main_single(args):
             out["host_path"] = run_host_path(dev, args)
     if args.config == 5 and not args.no_cpu:
         out["cpu_baseline_pool"] = cpu_baseline_pool(5, args.ny, args.nx, nbatch_main, 4)
+    out["summary"] = build_summary(out)   # LAST key: the tail of the line carries every config's value / frac / traffic / parity
     print(json.dumps(out))
     if failed:
         print("bench.py: PARITY FAILURE -- " + "; ".join(failed), file=sys.stderr)

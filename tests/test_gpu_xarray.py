@@ -1,11 +1,13 @@
 """The xarray front door on the HIP path: ``Filter.apply(ds, dims)`` / ``apply_to_vector`` driven through
 ``xarray.apply_ufunc`` down to libgcmf, nothing monkeypatched but the xarray module itself (xarray is not installed in
 this image: tests/fake_xarray.py models the documented semantics Filter relies on, incl. dask="parallelized" calling
-filter_func concurrently from worker threads, block by block).  Mirrors upstream tests/test_filter.py:172-252."""
+filter_func concurrently from worker threads, block by block).  Every test also runs against the INSTALLED xarray (dask-backed inputs
+where dask imports) wherever there is one -- skipped here.  Mirrors upstream tests/test_filter.py:172-252."""
 import sys
 
 import numpy as np
 import pytest
+from conftest import XARRAY_KINDS, xarray_backend
 
 from gcm_filters_amd import Filter, FilterShape, GridType, testing as T
 from oracle import gcmf_oracle as O
@@ -13,11 +15,10 @@ from oracle import gcmf_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture
-def xr(monkeypatch):
-    import fake_xarray
-    monkeypatch.setitem(sys.modules, "xarray", fake_xarray)
-    return fake_xarray
+@pytest.fixture(params=XARRAY_KINDS)
+def xr(request, monkeypatch):
+    """The model of xarray (always) and the installed xarray (+ dask-backed inputs) wherever it imports."""
+    return xarray_backend(request.param, monkeypatch)
 
 
 def rel(a, b):
@@ -94,12 +95,12 @@ def test_dask_like_blocks_from_worker_threads(xr):
     whole = flt.apply(xr.DataArray(data, dims=["time", "y", "x"]), dims=["y", "x"])
     lazy = xr.chunked(xr.DataArray(data, dims=["time", "y", "x"]), "time", 5)
     blocks = flt.apply(lazy, dims=["y", "x"])
-    assert blocks.dims == ("time", "y", "x") and np.array_equal(blocks.data, whole.data)
+    assert blocks.dims == ("time", "y", "x") and np.array_equal(np.asarray(blocks.data), whole.data)
     want = O.filter_func(O.make_spec(8 * dx, dx), "IRREGULAR_WITH_LAND", data, gv)
-    assert rel(blocks.data, want) <= 1e-11
+    assert rel(np.asarray(blocks.data), want) <= 1e-11
     # transposed lazy input: every block arrives as a non-contiguous view with the core dims moved last
     lazy_t = xr.chunked(xr.DataArray(data.transpose(1, 0, 2).copy(), dims=["y", "time", "x"]), "time", 4)
-    assert np.array_equal(flt.apply(lazy_t, dims=["y", "x"]).data, whole.data)
+    assert np.array_equal(np.asarray(flt.apply(lazy_t, dims=["y", "x"]).data), whole.data)
     # vector filter, blocks over levels
     (u, v), gvv = T.vector_case("VECTOR_C_GRID", (64, 96))
     dxv = T.grid_dx_min("VECTOR_C_GRID", gvv)
@@ -110,7 +111,7 @@ def test_dask_like_blocks_from_worker_threads(xr):
     uo, vo = fv.apply_to_vector(xr.chunked(xr.DataArray(U, dims=["lev", "y", "x"]), "lev", 3),
                                 xr.DataArray(V, dims=["lev", "y", "x"]), dims=["y", "x"])
     wu, wv = O.filter_func_vec(O.make_spec(5 * dxv, dxv), "VECTOR_C_GRID", U, V, gvv)
-    assert rel(uo.data, wu) <= 1e-11 and rel(vo.data, wv) <= 1e-11
+    assert rel(np.asarray(uo.data), wu) <= 1e-11 and rel(np.asarray(vo.data), wv) <= 1e-11
 
 
 def test_depth_dependent_mask_through_xarray(xr):
