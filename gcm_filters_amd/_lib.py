@@ -33,7 +33,10 @@ EXPORTS = [
     "gcmf_comm_unique_id", "gcmf_comm_create", "gcmf_comm_destroy", "gcmf_halo_start", "gcmf_halo_finish", "gcmf_comm_info",
     "gcmf_build_id", "gcmf_last_kernel_geometry",
     "gcmf_slab_apply_backward", "gcmf_slab_backward_vec_supported", "gcmf_slab_apply_backward_vec", "gcmf_resident_supported", "gcmf_resident_levels", "gcmf_p2p_create", "gcmf_p2p_export", "gcmf_p2p_connect", "gcmf_p2p_start", "gcmf_p2p_finish", "gcmf_p2p_status", "gcmf_p2p_destroy", "gcmf_p2p_guard", "gcmf_p2p_seq", "gcmf_p2p_set_timeout_ms", "gcmf_p2p_debug_skip_post",
+    "gcmf_plan_last_path", "gcmf_resident_status",
 ]
+PATH_NAMES = {0: None, 1: "resident", 2: "strips", 3: "resident-lock-busy", 4: "resident-disabled"}
+RESIDENT_STATES = {0: "ok", 1: "lock-busy", 2: "disabled", 3: "off"}
 PLAN_SELF_RING, PLAN_SKIP_KAPPA_ONE = 0x1, 0x2
 
 
@@ -187,6 +190,10 @@ def load() -> C.CDLL:
         lib.gcmf_ring_fallbacks.restype = C.c_int
         lib.gcmf_last_kernel.argtypes = [vp, C.c_char_p, C.c_int]
         lib.gcmf_last_kernel.restype = C.c_int
+        lib.gcmf_plan_last_path.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+        lib.gcmf_plan_last_path.restype = C.c_int
+        lib.gcmf_resident_status.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
+        lib.gcmf_resident_status.restype = C.c_int
         lib.gcmf_last_kernel_geometry.argtypes = [vp, C.c_char_p, C.c_int]
         lib.gcmf_last_kernel_geometry.restype = C.c_int
         lib.gcmf_set_timing.argtypes = [vp, C.c_int]
@@ -230,6 +237,14 @@ def dtype_code(dt) -> int:
     if dt == np.float32:
         return F32
     raise TypeError(f"libgcmf computes in float32 or float64, not {dt}")
+
+
+def resident_status(device: int = 0) -> dict:
+    """This process's standing with the on-chip kernel on `device`: {"state": "ok" | "lock-busy" | "disabled" | "off", "failures": n}
+    (include/gcmf.h: gcmf_resident_status)."""
+    st, nf = C.c_int(), C.c_uint64()
+    check(load().gcmf_resident_status(int(device), C.byref(st), C.byref(nf)))
+    return {"state": RESIDENT_STATES.get(st.value, "off"), "failures": int(nf.value)}
 
 
 class Plan:
@@ -409,6 +424,20 @@ class Plan:
         n = C.c_int64()
         check(load().gcmf_ring_fallbacks(self._h, C.byref(n)))
         return n.value
+
+    def last_path(self):
+        """Which of the two bit-identical paths the last gcmf_apply of this plan took: "resident" (the whole polynomial on the chip),
+        "strips" (the strip-marching launches), "resident-lock-busy" (strips, because ANOTHER PROCESS holds this GPU's on-chip lock),
+        "resident-disabled" (strips, because an on-chip launch of this process timed out earlier); None before the first call."""
+        path = C.c_int()
+        check(load().gcmf_plan_last_path(self._h, C.byref(path), None))
+        return PATH_NAMES.get(path.value)
+
+    def path_counts(self) -> dict:
+        """How often each path was taken since the plan was made: {"resident": n, "strips": n, ...}."""
+        path, counts = C.c_int(), (C.c_int64 * 5)()
+        check(load().gcmf_plan_last_path(self._h, C.byref(path), counts))
+        return {PATH_NAMES[k]: int(counts[k]) for k in range(1, 5)}
 
     def last_kernel(self) -> str:
         buf = C.create_string_buffer(256)

@@ -523,6 +523,7 @@ int gcmf_set_option(gcmf_plan *pl, const char *name, int value) {
   if (n == "cgrid_ring") pl->cgrid_ring = value;
   else if (n == "cgrid_ring_smax") pl->cgrid_ring_smax = value;
   else if (n == "cgrid_ring_hmax") pl->cgrid_ring_hmax = value;
+  else if (n == "cgrid_ring_ncarry") pl->cgrid_ring_ncarry = value;
   else if (n == "ringc9") pl->ringc9 = value;
   else if (n == "clenshaw_f32") pl->clenshaw_f32 = value;
   else if (n == "ring_flux_f32") pl->ring_flux_f32 = value;
@@ -684,6 +685,24 @@ int gcmf_cheb_multi(gcmf_plan *pl, const void *u, const void *v, void *uo, void 
 // ---- the on-chip (resident) kernel, gcmf_resident.hip --------------------------------------------------------------------------
 // Whether L levels of the backward evaluation with output rows [row_lo, row_hi) of this plan can run in ONE resident launch (f64 scalar
 // plans whose rows [row_lo - L, row_hi + L) fit the register files + LDS of the chip, no tripole seam in that range, L <= 64).
+int gcmf_plan_last_path(const gcmf_plan *pl, int *path, int64_t *counts) {
+  if (!pl) return GCMF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(const_cast<gcmf_plan *>(pl)->mu);
+  if (path) *path = pl->last_path;
+  if (counts)
+    for (int k = 0; k < 5; ++k) counts[k] = pl->path_count[k];
+  return GCMF_OK;
+}
+
+int gcmf_resident_status(int device, int *state, uint64_t *failures) {
+  unsigned long long nf = 0;
+  int st = GCMF_RESIDENT_OFF;
+  resident_status(device, &st, &nf);
+  if (state) *state = st;
+  if (failures) *failures = (uint64_t)nf;
+  return GCMF_OK;
+}
+
 int gcmf_resident_supported(const gcmf_plan *pl, int64_t row_lo, int64_t row_hi, int L) {
   if (!pl) return 0;
   (void)hipSetDevice(pl->d.device);
@@ -730,7 +749,7 @@ int gcmf_cheb_multi_vec(gcmf_plan *pl, const void *const *u, const void *const *
     return gcmf_cheb_multi(pl, u[0], v ? v[0] : nullptr, uo ? uo[0] : nullptr, vo ? vo[0] : nullptr,
                            fbar_in ? fbar_in[0] : nullptr, fbar_out[0], pk, S, p0, c, mode, flags, nbatch, row_lo,
                            row_hi, stream);
-  if (!vec_multi_supported(pl, nbatch, S)) {
+  if (!vec_multi_supported(pl, nbatch, S, (mode & GCMF_STEP_CLENSHAW) != 0)) {
     set_error("gcmf_cheb_multi_vec: S=%d with %lld levels is not available for this plan", S, (long long)nbatch);
     return GCMF_ERR_UNSUPPORTED;
   }
@@ -940,6 +959,21 @@ land_and_guard:
 // cut exactly as gcmf_apply cuts them for this plan (at most four per launch), so a level filtered on a slab and in one piece see the same
 // arithmetic; a launch of S levels uses up S ghost rows, the ghost zone is refreshed (both states, both components: four planes in one
 // message per neighbour) when fewer are left than the next launch needs.  No edge / interior split.
+// Levels of the next launch of a backward VECTOR application with `left` levels to go and at most smax per launch: the fewest launches,
+// their depths evened out (44 levels at up to six per launch: 6 6 6 6 5 5 5 5 -- greedy sixes would leave a two-level launch of the
+// general kernel at the end), never a lone single level left behind; gcmf_apply and the slab driver cut alike.
+static bool ptr_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static int vec_backward_next_depth(const gcmf_plan *pl, int64_t nbatch, int left, int smax) {
+  if (smax >= 5) {
+    const int nl = (left + smax - 1) / smax, S = (left + nl - 1) / nl;
+    if (S >= 2 && S <= left && left - S != 1 && vec_multi_supported(pl, nbatch, S, true)) return S;
+  }
+  for (int cand = smax; cand >= 2; --cand)
+    if (cand <= left && left - cand != 1 && vec_multi_supported(pl, nbatch, cand, true)) return cand;
+  return left;
+}
+
 int gcmf_slab_backward_vec_supported(const gcmf_plan *pl, int64_t nbatch, int halo) {
   if (!pl || pl->ncomp != 2 || nbatch < 1) return 0;
   if (!((pl->kind == K_CGRID && pl->clenshaw >= 1) || (pl->kind == K_BGRID && pl->clenshaw >= 2 && (pl->d.dtype == GCMF_F64 || pl->clenshaw_f32))))
@@ -980,14 +1014,16 @@ int gcmf_slab_apply_backward_vec(gcmf_plan *pl, gcmf_comm *comm, gcmf_p2p *p2p, 
     if ((rc = exchange(st, 2))) return rc;
   }
   const void *u[2] = {X[0], X[1]}, *v[2] = {nullptr, nullptr};
-  const int smax = std::min(std::min(pl->multi_s, std::max(4, cgrid_ring_smax(pl, nbatch))), multi ? std::max(4, halo) : 8);   // (as gcmf_apply cuts them; never deeper than the ghost zone)
+  // (launches deeper than five levels exist only in k_cgrid_ring, whose 16-byte accesses need the caller's planes aligned)
+  bool al16 = true;
+  for (int q = 0; q < 2; ++q) al16 = al16 && ptr_al16(X[q]) && ptr_al16(out[q]);
+  for (int q = 0; q < 8; ++q) al16 = al16 && ptr_al16(pool[q]);
+  const int ring_smax = al16 ? cgrid_ring_smax(pl, nbatch) : std::min(5, cgrid_ring_smax(pl, nbatch));
+  const int smax = std::min(std::min(pl->multi_s, std::max(4, ring_smax)), multi ? std::max(4, halo) : 8);   // (as gcmf_apply cuts them; never deeper than the ghost zone)
   int valid = hs, lvl = 1;
   while (lvl <= n_steps) {
     const int left = n_steps - lvl + 1;
-    int S = 0;
-    for (int cand = smax; cand >= 2 && !S; --cand)
-      if (cand <= left && left - cand != 1 && vec_multi_supported(pl, nbatch, cand)) S = cand;
-    if (!S) S = left;
+    const int S = vec_backward_next_depth(pl, nbatch, left, smax);
     if (multi && valid < S) {   // (never before the first launch: valid = halo >= 4 there)
       void *st[4] = {const_cast<void *>(u[0]), const_cast<void *>(u[1]), const_cast<void *>(v[0]), const_cast<void *>(v[1])};
       if ((rc = exchange(st, 4))) return rc;
@@ -1130,15 +1166,30 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
     // Small fields: the whole polynomial on the chip in ONE launch (64 levels at a time; gcmf_resident.hip) -- the field, both states
     // and the coefficients live in registers / LDS, nothing but the result goes back to memory.  Same bits as the launches below.
     bool resident = false;
-    if (n_clen > 0 && nbatch == 1 && !(flags & GCMF_NO_RESIDENT)) {
-      if (resident_take_failure(pl->d.device)) {   // (told once; from here on this process runs the strip-marching launches: same bits)
-        set_error("k_resident: an earlier on-chip launch of this process timed out waiting for a neighbour tile and gave NaN (another "
-                  "process running resident kernels on this GPU outside the lock file's reach?); the strip-marching launches are used from now on");
+    int path = GCMF_PATH_STRIPS;
+    if (pl->res_lo) {   // the LAST call of this plan ran on the chip: did one of ITS launches time out?  (told once, to the plan whose
+      //                   output was poisoned -- never to an unrelated plan; the process runs the strip-marching launches from now on)
+      const unsigned lo = pl->res_lo, hi = pl->res_hi;
+      pl->res_lo = pl->res_hi = 0;
+      if (resident_take_failure(pl->d.device, lo, hi)) {
+        set_error("k_resident: the previous on-chip application of this plan timed out waiting for a neighbour tile and its result is NaN "
+                  "(another process running resident kernels on this GPU outside the lock file's reach?); the strip-marching launches are "
+                  "used from now on");
         return GCMF_ERR_HIP;
       }
-      resident = resident_supported(pl, 0, rows, std::min(n_steps, 64), n_steps);   // (small whole grids; GCMF_RESIDENT=1: whatever fits)
     }
+    if (n_clen > 0 && nbatch == 1 && !(flags & GCMF_NO_RESIDENT)) {
+      int why = GCMF_RESIDENT_OFF;
+      resident = resident_supported(pl, 0, rows, std::min(n_steps, 64), n_steps, &why);   // (small whole grids; GCMF_RESIDENT=1: whatever fits)
+      if (!resident && why == GCMF_RESIDENT_LOCK_BUSY) path = GCMF_PATH_STRIPS_LOCK_BUSY;
+      if (!resident && why == GCMF_RESIDENT_DISABLED) path = GCMF_PATH_STRIPS_DISABLED;
+    }
+    if (resident) path = GCMF_PATH_RESIDENT;
+    pl->last_path = path;
+    ++pl->path_count[path];
     if (resident) {
+      pl->res_lo = resident_next_serial(pl->d.device);
+      pl->res_hi = pl->res_lo;
       void *pool[4] = {A[0], B[0], Cb[0], Db[0]};
       const void *u = nullptr, *v = nullptr;
       double pkk[64];
@@ -1155,6 +1206,7 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
         for (int t = 0; t < L; ++t) pkk[t] = p[n_steps - (done + 1 + t)];
         m.p0 = p[n_steps]; m.c = c; m.nbatch = 1; m.row_lo = 0; m.row_hi = rows;
         if ((rc = dom_begin(pl, s))) return rc;
+        pl->res_hi = resident_next_serial(pl->d.device);   // (other plans of the process may have launched in between: a range, not a count)
         if ((rc = launch_resident(pl, m, pkk, L, s))) return rc;
         if ((rc = dom_end(pl, s))) return rc;
         ++launches;
@@ -1271,14 +1323,13 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
       // four levels per launch with two operand rows in flight: 353-357 G on config 5; five levels leave one row in flight and
       // spill (305-310 G); the forward kernel at its best (five levels) 280 G
       // (round 5: k_cgrid_ring, gcmf_cgrid_ring.hip, takes batched f32 levels four or five at a time)
-      const int smax = std::min(pl->multi_s, std::max(4, cgrid_ring_smax(pl, nbatch)));
+      // (launches deeper than five levels exist only in k_cgrid_ring, whose 16-byte accesses need the caller's planes aligned)
+      const bool al16 = ptr_al16(x0[0]) && ptr_al16(x0[1]) && ptr_al16(dout[0]) && ptr_al16(dout[1]);
+      const int smax = std::min(pl->multi_s, std::max(4, al16 ? cgrid_ring_smax(pl, nbatch) : std::min(5, cgrid_ring_smax(pl, nbatch))));
       int lvl = 1;
       while (lvl <= n_steps) {
         const int left = n_steps - lvl + 1;
-        int S = 0;
-        for (int cand = smax; cand >= 2 && !S; --cand)
-          if (cand <= left && left - cand != 1 && vec_multi_supported(pl, nbatch, cand)) S = cand;
-        if (!S) S = left;  // (left = 3 with smax 2 cannot happen: smax >= 4)
+        const int S = vec_backward_next_depth(pl, nbatch, left, smax);
         void *fr[2][2];
         int nf = 0;
         for (int q = 0; q < 4 && nf < 2; ++q)
@@ -1397,7 +1448,9 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
     for (int k = 0; k < nc; ++k)
       GCMF_HIP(hipMemcpyAsync(out[k], dout[k], ncell * fbs, hipMemcpyDeviceToHost, s));
     GCMF_HIP(hipStreamSynchronize(s));
-    if (resident_take_failure(pl->d.device)) {   // (the synchronising host path can tell for THIS call)
+    const unsigned rlo = pl->res_lo, rhi = pl->res_hi;
+    pl->res_lo = pl->res_hi = 0;   // (the stream is drained: nothing of this call is pending any more)
+    if (rlo && resident_take_failure(pl->d.device, rlo, rhi)) {   // (the synchronising host path can tell for THIS call)
       set_error("k_resident: the on-chip launch timed out waiting for a neighbour tile: the result is NaN (another process running "
                 "resident kernels on this GPU?); the strip-marching launches are used from now on");
       return GCMF_ERR_HIP;

@@ -32,6 +32,7 @@
 // still runs single-level fields, f64 plans and remainders below 4 levels) and the slab drivers give the same bits.
 #include "gcmf_multi_common.hpp"
 #include "gcmf_recurrence.hpp"
+#include <atomic>
 #include <cstdlib>
 
 namespace gcmf {
@@ -71,14 +72,16 @@ constexpr int CR_U = 12;  // unroll factor of the row loop = common period of al
 // pipeline likes (8-byte accesses of this pattern stream at ~4.4 TB/s, experiments/cgrid_probe) -- and no registers in flight.  (Round 5
 // also built and measured a plain-load form and eight waves per workgroup; both lost and are gone: launch_cgrid_ring has the numbers.)
 constexpr int CR_WPB = 4;   // waves (= levels of the batch) per workgroup
+
 template <int S, int D> struct CRingGeom {
   static constexpr int M = S <= 4 ? 4 : 8;   // level j is stale j cells per side; windows start on a multiple of 4 cells (16-byte loads)
   static constexpr int W = 128, WI = W - 2 * M;
   // LDS slots of the coefficient ring: the rows in flight occupy slots too: S + D (the slot of a row is a scalar that travels with the row)
   static constexpr int NS = S + D;
   static constexpr unsigned SLOTB = 14u * 512u;                        // bytes per slot (f32: 128 cells x 4 bytes per plane)
-  static constexpr unsigned DUMMY_OFF = NS * SLOTB;                    // where the fourth wave's padding planes land
-  static constexpr unsigned STG_OFF = DUMMY_OFF + 1024u;               // the waves' staging slots: D per wave x (u0|v0, up|vp, fu|fv)
+  static constexpr unsigned STG_OFF = NS * SLOTB;                      // the waves' staging slots: D per wave x (u0|v0, up|vp, fu|fv)
+  // (16 plane loads are dealt to the four waves, 14 planes exist: the fourth wave's last pair fetches planes 12 | 13 a second time, into
+  // their own place -- the same bytes to the same address -- instead of into a dummy kilobyte the six-level ring has no room for)
   static constexpr unsigned STGB = 3072u;
   static constexpr size_t lds_bytes() { return (size_t)STG_OFF + (unsigned)CR_WPB * D * STGB; }
   static constexpr int NDC = 8 / CR_WPB;   // coefficient loads per wave and row (two planes each; 16 plane slots over the waves)
@@ -140,18 +143,21 @@ __device__ __forceinline__ void cgring_helper(const CRingP<T> &P, unsigned char 
   if (c4 < 0) c4 += P.nx;
   const char *q_c[NDC];
   bool isa[NDC];
+  unsigned pair_off[NDC];
 #pragma unroll
   for (int h = 0; h < NDC; ++h) {
-    const int pa = PPW * wv + 2 * h + half;
-    q_c[h] = reinterpret_cast<const char *>(P.coef[pa < 14 ? pa : 0]) + (unsigned)c4 * 4u;
-    isa[h] = pa < 7 || pa >= 14;
+    const int pr = PPW * wv + 2 * h >= 14 ? 12 : PPW * wv + 2 * h;   // (the padding pair: planes 12 | 13 again)
+    const int pa = pr + half;
+    q_c[h] = reinterpret_cast<const char *>(P.coef[pa]) + (unsigned)c4 * 4u;
+    isa[h] = pa < 7;
+    pair_off[h] = (unsigned)pr * 512u;
   }
   unsigned nxt = 0;
   auto issue = [&]() {
     cur.advance();
 #pragma unroll
     for (int h = 0; h < NDC; ++h)
-      cr_dma16(q_c[h] + (isa[h] ? cur.ro : cur.rc), (PPW * wv + 2 * h >= 14) ? lds0 + G::DUMMY_OFF : lds0 + nxt + (unsigned)(PPW * wv + 2 * h) * 512u);
+      cr_dma16(q_c[h] + (isa[h] ? cur.ro : cur.rc), lds0 + nxt + pair_off[h]);
     nxt = (nxt + G::SLOTB == NS * G::SLOTB) ? 0u : nxt + G::SLOTB;
   };
 #pragma unroll
@@ -165,7 +171,7 @@ __device__ __forceinline__ void cgring_helper(const CRingP<T> &P, unsigned char 
 }
 
 // One march of a strip by one wave (one level of the batch).  Returns whether a +-inf was delivered (wave-uniform); SAN = the redo pass.
-template <typename T, int S, int D, bool FIRST, bool SAN>
+template <typename T, int S, int D, bool FIRST, bool SAN, int NCARRY>
 __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *s_raw, const int lane, const int wv, const long long boff,
                                              const unsigned colB, const int pos0, const bool keep, const int a, const int b, const int n_pad) {
   typedef typename CgV2<T>::type v2;
@@ -173,6 +179,9 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
   constexpr int NS = G::NS;
   constexpr int U = CR_U, RU = 6, RF = 12;
   constexpr int NDC = G::NDC, PPW = 2 * NDC;
+  // NCARRY: the top NCARRY levels keep their previous row's three scaled copies in registers, the others rebuild them (three more
+  // coefficient reads from LDS and a few packed multiplies per level)
+  static_assert(NCARRY >= 1 && NCARRY <= S, "levels that carry");
   static_assert(D >= 1 && D <= 3 && S >= 2 && S + D <= RF && S < NS && U % D == 0, "ring periods");
   static_assert(sizeof(T) == 4, "LDS-direct loads of 16 bytes = four cells: f32 state");
   const int nx = P.nx, rows = P.rows;
@@ -227,12 +236,14 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
   const char *q_ff = reinterpret_cast<const char *>(half ? pfv : pfu) + c4B;
   const char *q_c[NDC];
   bool isa[NDC];
+  unsigned pair_off[NDC];
 #pragma unroll
   for (int h = 0; h < NDC; ++h) {
-    const int pa = PPW * wv + 2 * h + half;   // this wave's share of the 14 coefficient planes (planes 0..6 travel with the delivered row,
-    //                                           7..13 with the row before; slots 14, 15: padding)
-    q_c[h] = reinterpret_cast<const char *>(P.coef[pa < 14 ? pa : 0]) + c4B;
-    isa[h] = pa < 7 || pa >= 14;
+    const int pr = PPW * wv + 2 * h >= 14 ? 12 : PPW * wv + 2 * h;   // (the padding pair: planes 12 | 13 again, see CRingGeom)
+    const int pa = pr + half;   // this wave's share of the 14 coefficient planes (planes 0..6 travel with the delivered row, 7..13 with the row before)
+    q_c[h] = reinterpret_cast<const char *>(P.coef[pa]) + c4B;
+    isa[h] = pa < 7;
+    pair_off[h] = (unsigned)pr * 512u;
   }
   const unsigned stg0 = G::STG_OFF + (unsigned)(wv * D) * G::STGB;   // this wave's staging slots
   auto issue_dma = [&](auto ph_c) {  // the LDS-direct loads of the next iteration: its coefficient slot, this wave's staging slot
@@ -242,7 +253,7 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
     slot_of[ph] = nxt_slot;
 #pragma unroll
     for (int h = 0; h < NDC; ++h)
-      cr_dma16(q_c[h] + (isa[h] ? cur.ro : cur.rc), (PPW * wv + 2 * h >= 14) ? lds0 + G::DUMMY_OFF : lds0 + nxt_slot + (unsigned)(PPW * wv + 2 * h) * 512u);
+      cr_dma16(q_c[h] + (isa[h] ? cur.ro : cur.rc), lds0 + nxt_slot + pair_off[h]);
     nxt_slot = (nxt_slot + G::SLOTB == NS * G::SLOTB) ? 0u : nxt_slot + G::SLOTB;
     const unsigned st = lds0 + stg0 + (unsigned)(ph % D) * G::STGB;
     cr_dma16(q_g0 + cur.ro, st);
@@ -284,7 +295,7 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
     constexpr int lo = cmod(ph - 1, 2), ln = ph % 2;
     // ---- what the previous row of this level hands on: the last level carries it, the others rebuild it (same operands, same bits) ----
     v2 vt_p, vh_p, uh_p;
-    if constexpr (j < S) {
+    if constexpr (j <= S - NCARRY) {
       v2 pu, pv;   // the previous row as the stencil saw it
       if constexpr (SAN) {
         pu.x = cr_san(xu.x);  pu.y = cr_san(xu.y);
@@ -316,7 +327,7 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
     v2 dsm;  dsm.x = from_lower_lane0(Sm.y) - Sm.x;  dsm.y = Sm.x - Sm.y;                 // W Sm - Sm
     const v2 lu = __builtin_elementwise_fma(B[3], dpp, B[4] * (LR[j][lo] - Rm));
     const v2 lv = __builtin_elementwise_fma(B[5], dsm, -(B[6] * (LQ[j][lo] - Qr)));
-    if constexpr (j == S) { Lvt[j][ln] = vt;  Lvh[j][ln] = vh;  Luh[j][ln] = uh; }
+    if constexpr (j > S - NCARRY) { Lvt[j][ln] = vt;  Lvh[j][ln] = vh;  Luh[j][ln] = uh; }
     LP[j][ln] = Pr;  LQ[j][ln] = Qr;  LR[j][ln] = Rm;
     // ---- Reinsch's form: d_k = p_k f - 2 c L(b_{k+1}) - d_{k+1},  b_k = d_k - b_{k+1};  the last level of the last launch is the result:
     //      p_0 f - c L(b_1) - d_1 ----
@@ -387,6 +398,18 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
     // ---- stores: row r - S of level S: b (or the result) ... ----
     const int ju = r - S;
     if (ju >= a && ju < b) {   // wave-uniform
+      if constexpr (!SAN) {   // (the watch: inside this block, next to the stores that need the row in registers anyway)
+        // Non-finite values that first appear INSIDE a launch (an f32 overflow in a stress, inf - inf; p_k f with f = +-inf where p_n f
+        // was NaN): whatever a non-finite stencil operand touches is non-finite, so they show in the last level's row of d as +-inf or as
+        // a NaN in a cell whose delivered row was not NaN -- the strip then takes the redo pass, where every level clamps like
+        // k_cgrid_stream2c's nan_to_num (advisor, round 5)
+        // (a NaN that was delivered sits in b's row too -- the level's own "-x" operand, still in its ring slot; d - d is NaN for +-inf as well)
+        const v2 xo_u = (S >= 2) ? Xu[S >= 2 ? S - 1 : 1][cmod(ph - 1, 3)] : G0u[cmod(ph - 1, RU)];
+        const v2 xo_v = (S >= 2) ? Xv[S >= 2 ? S - 1 : 1][cmod(ph - 1, 3)] : G0v[cmod(ph - 1, RU)];
+        const v2 tu = out_pu - out_pu, tv = out_pv - out_pv;
+        seen_inf = seen_inf | ((tu.x != tu.x) & (xo_u.x == xo_u.x)) | ((tu.y != tu.y) & (xo_u.y == xo_u.y)) |
+                   ((tv.x != tv.x) & (xo_v.x == xo_v.x)) | ((tv.y != tv.y) & (xo_v.y == xo_v.y));
+      }
       const unsigned vo = colB + (unsigned)(ju * nx) * (unsigned)sizeof(T);
       if (keep) {
         if (P.du) {   // (wave-uniform; last launch) f32 state, f64 result: NumPy >= 2 promotes p[k] * T
@@ -423,7 +446,7 @@ __device__ __forceinline__ bool cgring_march(const CRingP<T> &P, unsigned char *
   return __any(seen_inf);
 }
 
-template <typename T, int S, int D, bool FIRST, int WPS>
+template <typename T, int S, int D, bool FIRST, int WPS, int NCARRY>
 __global__ __launch_bounds__(64 * CR_WPB, WPS) void k_cgrid_ring(const CRingP<T> P) {
   constexpr int WPB = CR_WPB;
   typedef CRingGeom<S, D> G;
@@ -456,20 +479,40 @@ __global__ __launch_bounds__(64 * CR_WPB, WPS) void k_cgrid_ring(const CRingP<T>
   const int n_pad = ((b - a) + 2 * S + CR_U - 1) / CR_U * CR_U;   // the march is padded to whole ring periods
   bool bad = false;
   if (shadow) cgring_helper<T, S, D>(P, s_raw, lane, wv, pos0, a - S, b + S, n_pad);
-  else bad = cgring_march<T, S, D, FIRST, false>(P, s_raw, lane, wv, boff, colB, pos0, keep, a, b, n_pad);
-  if (__syncthreads_or(bad ? 1 : 0)) {   // a +-inf somewhere in the workgroup's rows: the strip again, nan_to_num in full at every level
+  else bad = cgring_march<T, S, D, FIRST, false, NCARRY>(P, s_raw, lane, wv, boff, colB, pos0, keep, a, b, n_pad);
+  // "did any wave meet a +-inf" without __syncthreads_or: that reserves 256 bytes of static LDS, and six levels need all 80 KB a
+  // workgroup can have at two per CU.  The marches are over (every LDS-direct load has landed): the first staging word is free.
+  unsigned *s_flag = reinterpret_cast<unsigned *>(s_raw + G::STG_OFF);
+  __syncthreads();
+  if (threadIdx.x == 0) *s_flag = 0u;
+  __syncthreads();
+  if (bad && lane == 0) *s_flag = 1u;
+  __syncthreads();
+  const bool redo = *s_flag != 0u;
+  __syncthreads();   // (before the redo pass's loads overwrite the word)
+  if (redo) {   // a +-inf somewhere in the workgroup's rows: the strip again, nan_to_num in full at every level
     if (threadIdx.x == 0 && P.redo) atomicAdd(P.redo, 1u);
     if (shadow) cgring_helper<T, S, D>(P, s_raw, lane, wv, pos0, a - S, b + S, n_pad);
-    else cgring_march<T, S, D, FIRST, true>(P, s_raw, lane, wv, boff, colB, pos0, keep, a, b, n_pad);
+    else cgring_march<T, S, D, FIRST, true, NCARRY>(P, s_raw, lane, wv, boff, colB, pos0, keep, a, b, n_pad);
   }
 }
 
 static bool cr_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// the state, input and result planes come straight from the caller (GCMF_DEVICE_PTRS, the slab drivers' pools): the 16-byte LDS-direct
+// loads and the 16-byte f64 stores need them aligned -- unaligned views take k_cgrid_stream2c (advisor, round 5)
+bool cgrid_ring_args_aligned(const VecMultiArgs &a) {
+  for (int k = 0; k < 2; ++k) {
+    if (!cr_al16(a.u0[k]) || !cr_al16(a.uprev[k]) || !cr_al16(a.fb_in[k]) || !cr_al16(a.u1o[k]) || !cr_al16(a.u2o[k]) || !cr_al16(a.fb_out[k]))
+      return false;
+  }
+  return true;
+}
+
 bool cgrid_ring_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
   if (pl->cgrid_ring <= 0 || pl->kind != K_CGRID || pl->cgrid_tile || pl->d.dtype != GCMF_F32) return false;
   if (nbatch < 2) return false;   // single-level fields: k_cgrid_stream2c's private-ring form
-  if (S < 4 || S > 5 || S > pl->cgrid_ring_smax) return false;
+  if (S < 4 || S > 6 || S > pl->cgrid_ring_smax) return false;
   if (pl->g.nx % 4 || pl->g.nx < 4 || pl->g.rows < S + 2) return false;
   if ((long long)pl->g.rows * pl->g.nx * 4 >= (1LL << 32)) return false;   // 32-bit byte offsets inside a level's plane
   for (int k = 0; k < MAX_COEF; ++k)
@@ -477,7 +520,7 @@ bool cgrid_ring_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
   return true;
 }
 
-template <typename T, int S, int D, int WPS> static int launch_cr(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
+template <typename T, int S, int D, int WPS, int NCARRY> static int launch_cr(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
   constexpr int WI = CRingGeom<S, D>::WI, WPB = CR_WPB;
   const Geom &g = pl->g;
   CRingP<T> P;
@@ -536,26 +579,29 @@ template <typename T, int S, int D, int WPS> static int launch_cr(gcmf_plan *pl,
   const long long blocks_per_xcd = (groups_per_xcd * P.nlevp + WPB - 1) / WPB;
   dim3 block(64 * WPB), grid((unsigned)(blocks_per_xcd * 8));
   const size_t lds = CRingGeom<S, D>::lds_bytes();
-  auto go = [&](auto kern, bool &attr_set) -> int {
-    if (!attr_set && lds > 48 * 1024) {
+  // (the attribute belongs to the function ON A DEVICE: one bit per device ordinal and instantiation -- a process that drives plans on
+  // several GPUs must set it on each; advisor, round 5)
+  auto go = [&](auto kern, std::atomic<unsigned long long> &attr_set) -> int {
+    const unsigned long long bit = 1ULL << (pl->d.device & 63);
+    if (lds > 48 * 1024 && (pl->d.device >= 64 || !(attr_set.load(std::memory_order_relaxed) & bit))) {
       GCMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
+      attr_set.fetch_or(bit, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL(kern, grid, block, lds, s, P);
     return GCMF_OK;
   };
-  static bool set_first = false, set_next = false;  // per instantiation
-  int rc = a.first ? go(&k_cgrid_ring<T, S, D, true, WPS>, set_first) : go(&k_cgrid_ring<T, S, D, false, WPS>, set_next);
+  static std::atomic<unsigned long long> set_first{0}, set_next{0};  // per instantiation
+  int rc = a.first ? go(&k_cgrid_ring<T, S, D, true, WPS, NCARRY>, set_first) : go(&k_cgrid_ring<T, S, D, false, WPS, NCARRY>, set_next);
   if (rc) return rc;
   note_kernel(pl, std::string("gcmf::k_cgrid_ring<") + tyname<T>() + ", " + std::to_string(S) + ", " + std::to_string(D) + ", " +
-                      (a.first ? "true" : "false") + ", " + std::to_string(WPS) + ">", S,
+                      (a.first ? "true" : "false") + ", " + std::to_string(WPS) + ", " + std::to_string(NCARRY) + ">", S,
               launch_geom(P.H, (nrows + H - 1) / H, P.nwx, 1, grid.x, grid.y, nrows));
   GCMF_HIP(hipGetLastError());
   return GCMF_OK;
 }
 
 int cgrid_ring_smax(const gcmf_plan *pl, int64_t nbatch) {
-  for (int S = 5; S >= 4; --S)
+  for (int S = 6; S >= 4; --S)
     if (cgrid_ring_supported(pl, nbatch, S)) return S;
   return 0;
 }
@@ -571,9 +617,17 @@ int launch_cgrid_ring(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
   // launch of teams (416 workgroups, the 13 of a group walking through their strips together, no waiting between them): 365 -- both
   // the same bits, both slower (profiles/r05/cfg5_*.txt).  Only the LDS-direct form with four waves per workgroup is left in this file
   // (profiles of round 5 taken before the clean-up name the kernel k_cgrid_ring<float, 5, 2, false, 2, true, 4>: the same code).
+  // Round 6 (same box, alternating, config 5; G cells.steps/s): every level carrying its previous row's scaled copies in registers instead
+  // of rebuilding them from LDS (the compiler, nudged by where the +-inf watch sits, now needs 225 instead of 255 registers for five
+  // levels): 479 against 475 (three coefficient reads and ~8 VALU instructions fewer per level: neither the LDS nor the VALU paces this
+  // kernel); SIX levels per launch at two workgroups per CU -- 80 KB of LDS each: the dummy kilobyte of the coefficient ring and the 256
+  // static bytes of __syncthreads_or had to go -- 44 levels = 6 6 6 6 5 5 5 5: 508-513 (5.0 ms per six-level launch against 4.5 per
+  // five); with one workgroup per CU (81 KB) the same kernel ran 6.5 ms.  Six levels with all of them carrying spill; two carry.
+  const bool r5 = pl->cgrid_ring_ncarry == 1;   // (option "cgrid_ring_ncarry" = 1: round 5's form, only the last level carries)
   switch (a.S) {   // (LDS-direct loads: windows start on multiples of four cells -- cgrid_ring_supported asked for nx % 4 == 0)
-    case 4: return launch_cr<float, 4, 2, 2>(pl, a, s);
-    case 5: return launch_cr<float, 5, 2, 2>(pl, a, s);
+    case 4: return r5 ? launch_cr<float, 4, 2, 2, 1>(pl, a, s) : launch_cr<float, 4, 2, 2, 4>(pl, a, s);
+    case 5: return r5 ? launch_cr<float, 5, 2, 2, 1>(pl, a, s) : launch_cr<float, 5, 2, 2, 5>(pl, a, s);
+    case 6: return r5 ? launch_cr<float, 6, 2, 2, 1>(pl, a, s) : launch_cr<float, 6, 2, 2, 2>(pl, a, s);
   }
   return GCMF_ERR_INVALID_ARG;
 }

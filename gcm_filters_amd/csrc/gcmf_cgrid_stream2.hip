@@ -422,14 +422,15 @@ __global__ __launch_bounds__((PRIV ? 64 : 256), (sizeof(T) * VEC == 16 && (PRIV 
 
 static bool c2al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-bool cgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
+bool cgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S, bool backward) {
   if (pl->kind != K_CGRID || pl->cgrid_tile) return false;
   // f64: more than two levels spill registers.  f32: S = 6 / 8 fit only one wave per SIMD and measured slower than
   // S = 4 at two (234-252 G against 268-274 G cell.steps/s on config 5)
   // f32: S = 5 holds 238 VGPRs at two waves per SIMD and measured 282 G against 250 G for S = 4 on the same box
   // (config 5); S = 6 spills (229 G).  f64: S <= 4 (one wave per SIMD from S = 3 on)
   // single-level fields (wave-private LDS rings): S = 5 leaves five waves per CU and measured 90 G against 133 G at S = 4
-  if (S < 2 || (S > ((pl->d.dtype == GCMF_F64 || nbatch == 1) ? 4 : 5) && !cgrid_ring_supported(pl, nbatch, S))) return false;
+  // (six levels: only k_cgrid_ring, i.e. the backward evaluation of batched f32 levels)
+  if (S < 2 || (S > ((pl->d.dtype == GCMF_F64 || nbatch == 1) ? 4 : 5) && !(backward && cgrid_ring_supported(pl, nbatch, S)))) return false;
   const int vec = pl->d.dtype == GCMF_F64 ? 2 : 4;
   if (pl->g.nx % vec || pl->g.nx < vec || pl->g.rows < S + 2) return false;
   // any batch size: the lock-step workgroups of 4 levels are padded with shadow waves that repeat the last level
@@ -540,7 +541,7 @@ template <typename T, typename FB, int S> static int launch_c2_sel(gcmf_plan *pl
 }
 
 int launch_cgrid_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
-  if (a.clen && cgrid_ring_supported(pl, a.nbatch, a.S)) return launch_cgrid_ring(pl, a, s);   // batched f32 levels, deep launches
+  if (a.clen && cgrid_ring_supported(pl, a.nbatch, a.S) && cgrid_ring_args_aligned(a)) return launch_cgrid_ring(pl, a, s);   // batched f32 levels, deep launches
   if (a.clen) {  // backward evaluation: the conveyor has the state's type; single-level fields: private coefficient rings as above
     static const bool priv_ok = !(getenv("GCMF_VEC_PRIV") && atoi(getenv("GCMF_VEC_PRIV")) == 0);
     const bool priv = a.nbatch == 1 && priv_ok;

@@ -157,9 +157,10 @@ struct gcmf_plan {
   int prefetch_rows = 0;  // rows of operands in flight per wave (0 = default per S)
   int cgrid_tile = 0;     // 1: force the LDS-tile C-grid kernel instead of the streaming one (A/B testing)
   int cgrid_ring = 1;     // k_cgrid_ring (gcmf_cgrid_ring.hip) for batched f32 levels (0: k_cgrid_stream2c everywhere); env GCMF_CGRID_RING, gcmf_set_option
-  int cgrid_ring_smax = 5;  // levels per launch of that kernel (4 / 5); env GCMF_CGRID_RING_SMAX
+  int cgrid_ring_smax = 6;  // levels per launch of that kernel (4 / 5 / 6; six since round 6); env GCMF_CGRID_RING_SMAX
   int ring_flux_f32 = 1;    // forward ring kernel for f32 flux-kind state (0: k_flux_multi2 as until round 4); gcmf_set_option
   int cgrid_ring_hmax = 0;  // tallest strip its launcher picks (0 = 96); gcmf_set_option
+  int cgrid_ring_ncarry = 0;  // 0: the levels carry their previous row's scaled copies in registers (round 6; six levels: the top two), 1: only the last one (round 5); gcmf_set_option
   // Land kept out of the state (scalar plans; slab-row layout): bit 0 of lbits[cell] = the cell exchanges with a neighbour.
   // A cell that does not (land under a wet mask; a flux-form cell whose four faces are closed) has L = 0 and evolves
   // on its own: gcmf_apply zeroes such cells in the two states the first blocked launch wrote -- NaN on land then never
@@ -180,6 +181,9 @@ struct gcmf_plan {
                           // B-grid kinds; the f32 C-grid stays backward: in Reinsch's form it is MORE accurate than the reference's).
                           // GCMF_CLENSHAW_F32=1, gcmf_set_option("clenshaw_f32"), or per call GCMF_BACKWARD_F32.
   void *resident = nullptr;  // state of the on-chip (resident) kernel: exchange planes, tile flags (gcmf_resident.hip)
+  unsigned res_lo = 0, res_hi = 0;   // serial numbers of the resident launches of the last gcmf_apply that took that path (0: none pending)
+  int last_path = 0;                 // GCMF_PATH_* of the last gcmf_apply
+  long long path_count[5] = {0, 0, 0, 0, 0};
   double *dev_p = nullptr;   // p[0..n_steps] of the last filter, for k_land_fix
   size_t dev_p_n = 0;
   std::vector<double> host_p;
@@ -246,26 +250,29 @@ int launch_ringc_flux_slab_f32(gcmf_plan *pl, const MultiArgs &a, hipStream_t s)
 int launch_flux_multi2(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 // the on-chip kernel (gcmf_resident.hip): L <= 64 levels of the backward evaluation in ONE launch on a field that fits the register
 // files + LDS of the chip (short slabs, small grids); pk = the L coefficients (a.S / a.pk are ignored)
-bool resident_supported(const gcmf_plan *pl, int row_lo, int row_hi, int L, int n_total);   // fits AND the policy says so (n_total: levels of the whole filter)
+bool resident_supported(const gcmf_plan *pl, int row_lo, int row_hi, int L, int n_total, int *why = nullptr);   // fits AND the policy says so (n_total: levels of the whole filter; why: GCMF_RESIDENT_* when not)
 bool resident_fits(const gcmf_plan *pl, int row_lo, int row_hi, int L);
 int launch_resident(gcmf_plan *pl, const MultiArgs &a, const double *pk, int L, hipStream_t s);
 void resident_free(gcmf_plan *pl);
-bool resident_take_failure(int dev);   // a resident launch of this process on `dev` timed out since the last call (reported once)
+bool resident_take_failure(int dev, unsigned lo, unsigned hi);   // did one of the resident launches with serials [lo, hi] time out?  (reported once)
+unsigned resident_next_serial(int dev);
+void resident_status(int dev, int *state, unsigned long long *failures);
 int launch_cgrid_stream(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 bool cgrid_stream_supported(const gcmf_plan *pl, const StepArgs &a);
 int launch_bgrid_stream(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 bool bgrid_stream_supported(const gcmf_plan *pl, const StepArgs &a);
 bool multi_supported(const gcmf_plan *pl, int S);
-bool cgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S);
+bool cgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S, bool backward = false);   // (backward: k_cgrid_ring's deeper launches count)
 int launch_cgrid_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s);
 // the static-ring form of the backward C-grid kernel (gcmf_cgrid_ring.hip): batched f32 levels, S = 4 .. 8
 bool cgrid_ring_supported(const gcmf_plan *pl, int64_t nbatch, int S);
+bool cgrid_ring_args_aligned(const VecMultiArgs &a);   // the caller's state / input / result planes on 16-byte boundaries
 int cgrid_ring_smax(const gcmf_plan *pl, int64_t nbatch);   // deepest launch it offers this plan / batch (0: none)
 int launch_cgrid_ring(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s);
 bool bgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S);
 int launch_bgrid_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s);
-inline bool vec_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S) {
-  return pl->kind == K_CGRID ? cgrid_multi_supported(pl, nbatch, S) : bgrid_multi_supported(pl, nbatch, S);
+inline bool vec_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S, bool backward = false) {
+  return pl->kind == K_CGRID ? cgrid_multi_supported(pl, nbatch, S, backward) : bgrid_multi_supported(pl, nbatch, S);
 }
 inline int launch_vec_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
   return pl->kind == K_CGRID ? launch_cgrid_multi(pl, a, s) : launch_bgrid_multi(pl, a, s);

@@ -40,11 +40,15 @@
 #include "gcmf_multi_common.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <cerrno>
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 
 #include <fcntl.h>
 #include <sys/file.h>
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_resident(const ResP P) {
             // round trip, and 2048 lanes polling it cost 30 us per exchange in the first version)
             if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > P.spin_limit) {
               __hip_atomic_store(P.dfail, P.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (before any later band of this tile)
-              __hip_atomic_store(P.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              __hip_atomic_store(P.fail, P.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (which launch: the host tells the plan that issued it)
               s_fail = 1;
               break;
             }
@@ -583,7 +587,10 @@ struct ResArena {
   std::chrono::steady_clock::time_point last_try{};
   bool tried = false;
   bool disabled = false;           // a launch of this process timed out all the same (a process outside the lock's reach): strips from now on
-  bool failure_reported = true;    // the time-out has been handed to a caller as an error
+  unsigned failed_serial = 0;      // serial number of that launch (0: none): handed ONCE to the plan that issued it (resident_take_failure)
+  unsigned long long failures = 0; // time-outs seen on this device by this process (gcmf_resident_status)
+  bool lock_busy = false;          // the last attempt at the lock found another process holding it
+  std::chrono::steady_clock::time_point last_use{};   // last resident launch (the idle watchdog releases the lock some seconds later)
 };
 
 }  // namespace gcmf
@@ -598,27 +605,109 @@ void resident_free(gcmf_plan *pl) { pl->resident = nullptr; }   // (nothing per 
 // of them interleaved on the chip would each hold CUs the other's missing workgroups need.  A process-wide chain of events does it
 // without touching the host: every resident launch waits for the previous one's end.  (Two PROCESSES on one GPU cannot be chained; see
 // the header of this file.)  The same lock guards the arena.
-static std::mutex g_chain_mu;
-static std::map<int, ResArena> g_arena;   // by device ordinal (a node in CPX mode shows 64 devices)
+// (both live for ever: the idle watchdog below may still look at them while the process's static destructors run)
+static std::mutex &g_chain_mu = *new std::mutex;
+static std::map<int, ResArena> &g_arena = *new std::map<int, ResArena>;   // by device ordinal (a node in CPX mode shows 64 devices)
 
-// (g_chain_mu held)  May this process run resident kernels on `dev` now?
-static bool res_process_allowed(int dev) {
-  ResArena &st = g_arena[dev];
-  if (st.fail_host && __atomic_load_n(st.fail_host, __ATOMIC_ACQUIRE)) {   // a launch timed out since the last look
-    __atomic_store_n(st.fail_host, 0u, __ATOMIC_RELEASE);
-    st.disabled = true;
-    st.failure_reported = false;
+// ---- the lock file ------------------------------------------------------------------------------------------------------------
+// /dev/shm is shared by every user of the machine -- it has to be: the lock keeps OTHER users' processes on this GPU off the on-chip
+// kernel too -- so the name is predictable and anybody may have put something there first (advisor, round 5).  The file is therefore
+// never followed through a symbolic link (O_NOFOLLOW), has its mode set only by the process that CREATED it (O_CREAT | O_EXCL), is opened
+// read-only otherwise (flock needs no write access), and is refused unless it is a regular file with a single link.
+static int res_open_lock(const std::string &path) {
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0 && errno == ENOENT) {
+      fd = open(path.c_str(), O_RDWR | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0666);
+      if (fd < 0 && errno == EEXIST) continue;          // somebody created it between the two calls: open theirs
+      if (fd >= 0) (void)fchmod(fd, 0666);              // ours: other users' processes share the GPU too (umask)
+    }
+    if (fd < 0) return -1;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_nlink != 1) { close(fd); return -1; }
+    return fd;
   }
-  if (st.disabled) return false;
+  return -1;
+}
+
+// ---- the idle watchdog: a process that ran an on-chip kernel once must not keep every other process of the GPU off that path until
+// it exits (an idle notebook).  GCMF_RESIDENT_LOCK_IDLE_S seconds (default 5; 0 = keep it until exit) after the last
+// resident launch of this process has FINISHED the lock is given back; the next small grid asks for it again.
+static std::mutex &g_wd_mu = *new std::mutex;
+static std::condition_variable &g_wd_cv = *new std::condition_variable;
+static bool g_wd_stop = false, g_wd_started = false;
+static std::thread *g_wd_thread = nullptr;
+
+static double res_idle_seconds() {
+  static const double v = getenv("GCMF_RESIDENT_LOCK_IDLE_S") ? atof(getenv("GCMF_RESIDENT_LOCK_IDLE_S")) : 5.0;
+  return v;
+}
+
+static void res_watchdog() {
+  const auto idle = std::chrono::duration<double>(res_idle_seconds());
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lk(g_wd_mu);
+      if (g_wd_cv.wait_for(lk, std::chrono::milliseconds(500), [] { return g_wd_stop; })) return;
+    }
+    std::lock_guard<std::mutex> chain(g_chain_mu);
+    const auto now = std::chrono::steady_clock::now();
+    for (auto &kv : g_arena) {
+      ResArena &st = kv.second;
+      if (!st.have_lock || st.lock_fd < 0 || now - st.last_use < idle) continue;
+      if (st.chain_set && hipEventQuery(st.chain_ev) != hipSuccess) { (void)hipGetLastError(); continue; }   // (still running / queued)
+      if (flock(st.lock_fd, LOCK_UN) == 0) {
+        st.have_lock = false;
+        st.tried = false;
+      }
+    }
+  }
+}
+
+static void res_watchdog_stop() {   // atexit: registered after HIP's own handlers, so it runs before the runtime is torn down
+  {
+    std::lock_guard<std::mutex> lk(g_wd_mu);
+    g_wd_stop = true;
+  }
+  g_wd_cv.notify_all();
+  if (g_wd_thread && g_wd_thread->joinable()) g_wd_thread->join();
+}
+
+static void res_watchdog_start() {   // (g_chain_mu held)
+  if (g_wd_started || res_idle_seconds() <= 0.0) return;
+  g_wd_started = true;
+  g_wd_thread = new std::thread(res_watchdog);
+  atexit(res_watchdog_stop);
+}
+
+// (g_chain_mu held)  a time-out since the last look?  -> strips from now on, the serial remembered for the plan that issued it
+static void res_note_failure(ResArena &st) {
+  if (!st.fail_host) return;
+  const unsigned f = __atomic_load_n(st.fail_host, __ATOMIC_ACQUIRE);
+  if (!f) return;
+  __atomic_store_n(st.fail_host, 0u, __ATOMIC_RELEASE);
+  st.disabled = true;
+  st.failed_serial = f;
+  ++st.failures;
+}
+
+// (g_chain_mu held)  May this process run resident kernels on `dev` now?  why (optional): GCMF_RESIDENT_* reason when not.
+static bool res_process_allowed(int dev, int *why = nullptr) {
+  ResArena &st = g_arena[dev];
+  res_note_failure(st);
+  if (st.disabled) { if (why) *why = GCMF_RESIDENT_DISABLED; return false; }
   // A CU mask (HSA_CU_MASK, ROC_GLOBAL_CU_MASK) takes compute units away while hipDeviceAttributeMultiprocessorCount still reports all
   // of them: "one workgroup per CU, all resident" no longer holds (advisor, round 4).  Such a process takes the strip-marching launches.
   static const bool cu_masked = (getenv("HSA_CU_MASK") && *getenv("HSA_CU_MASK")) || (getenv("ROC_GLOBAL_CU_MASK") && *getenv("ROC_GLOBAL_CU_MASK"));
-  if (cu_masked) return false;
+  if (cu_masked) { if (why) *why = GCMF_RESIDENT_OFF; return false; }
   if (st.have_lock) return true;
   static const bool lock_on = !(getenv("GCMF_RESIDENT_LOCK") && atoi(getenv("GCMF_RESIDENT_LOCK")) == 0);
   if (!lock_on) { st.have_lock = true; return true; }
   const auto now = std::chrono::steady_clock::now();
-  if (st.tried && now - st.last_try < std::chrono::seconds(1)) return false;   // (asked a moment ago)
+  if (st.tried && now - st.last_try < std::chrono::seconds(1)) {   // (asked a moment ago)
+    if (why) *why = st.lock_busy ? GCMF_RESIDENT_LOCK_BUSY : GCMF_RESIDENT_OFF;
+    return false;
+  }
   st.tried = true;
   st.last_try = now;
   if (st.lock_fd < 0) {
@@ -627,14 +716,18 @@ static bool res_process_allowed(int dev) {
     for (char *c = bus; *c; ++c) if (*c == ':' || *c == '/') *c = '_';
     const char *own = getenv("GCMF_RESIDENT_LOCK_DIR");   // (tests: a lock namespace of their own)
     const char *dirs[2] = {own && *own ? own : "/dev/shm", "/tmp"};
-    for (int q = 0; q < 2 && st.lock_fd < 0; ++q) {
-      const std::string path = std::string(dirs[q]) + "/gcmf_resident_" + bus + ".lock";
-      st.lock_fd = open(path.c_str(), O_RDWR | O_CREAT | O_CLOEXEC, 0666);
-      if (st.lock_fd >= 0) (void)fchmod(st.lock_fd, 0666);   // (other users' processes share the GPU too)
-    }
+    for (int q = 0; q < 2 && st.lock_fd < 0; ++q) st.lock_fd = res_open_lock(std::string(dirs[q]) + "/gcmf_resident_" + bus + ".lock");
     if (st.lock_fd < 0) { st.have_lock = true; return true; }   // nowhere to put a lock file: as before (bounded waits, loud failure)
   }
-  if (flock(st.lock_fd, LOCK_EX | LOCK_NB) == 0) st.have_lock = true;
+  if (flock(st.lock_fd, LOCK_EX | LOCK_NB) == 0) {
+    st.have_lock = true;
+    st.lock_busy = false;
+    st.last_use = now;
+    res_watchdog_start();
+  } else {
+    st.lock_busy = true;
+    if (why) *why = GCMF_RESIDENT_LOCK_BUSY;
+  }
   return st.have_lock;
 }
 
@@ -731,7 +824,8 @@ namespace gcmf {
 //   * row slabs of a multi-GPU run: no -- on the 8-way slab of 2400 x 3600 a tile exchange costs ~9.5 us against ~1 us per level and
 //     registers + LDS only hold a K = 4 halo: 0.336 against 0.307 ms per application.
 // env GCMF_RESIDENT=1 forces it wherever it fits, =0 forbids it; the building block (gcmf_resident_levels) is always available.
-bool resident_supported(const gcmf_plan *pl, int row_lo, int row_hi, int L, int n_total) {
+bool resident_supported(const gcmf_plan *pl, int row_lo, int row_hi, int L, int n_total, int *why) {
+  if (why) *why = GCMF_RESIDENT_OFF;
   const char *e = getenv("GCMF_RESIDENT");
   const int mode = e ? atoi(e) : -1;
   if (mode == 0) return false;
@@ -750,23 +844,44 @@ bool resident_supported(const gcmf_plan *pl, int row_lo, int row_hi, int L, int 
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
   std::lock_guard<std::mutex> chain(g_chain_mu);
-  return res_process_allowed(dev);   // (another process of this GPU runs resident kernels: the strip-marching launches, same bits)
+  return res_process_allowed(dev, why);   // (another process of this GPU runs resident kernels: the strip-marching launches, same bits)
 }
 
-// A resident launch of this process on `dev` timed out since the last call (its result is NaN): reported once, to whoever asks first.
-bool resident_take_failure(int dev) {
+// Did one of the resident launches with serial numbers [lo, hi] (a plan's own, wrap-around safe) time out?  Reported ONCE, to the plan
+// that issued the launch -- whose output it poisoned with NaN -- never to an unrelated call (advisor, round 5): a time-out nobody claims
+// stays visible in gcmf_resident_status and switches the process to the strip-marching launches all the same.
+bool resident_take_failure(int dev, unsigned lo, unsigned hi) {
   std::lock_guard<std::mutex> chain(g_chain_mu);
   auto it = g_arena.find(dev);
   if (it == g_arena.end()) return false;
   ResArena &st = it->second;
-  if (st.fail_host && __atomic_load_n(st.fail_host, __ATOMIC_ACQUIRE)) {
-    __atomic_store_n(st.fail_host, 0u, __ATOMIC_RELEASE);
-    st.disabled = true;
-    st.failure_reported = false;
-  }
-  if (st.failure_reported) return false;
-  st.failure_reported = true;
+  res_note_failure(st);
+  if (!st.failed_serial || !lo) return false;
+  if ((unsigned)(st.failed_serial - lo) > (unsigned)(hi - lo)) return false;   // somebody else's launch
+  st.failed_serial = 0;
   return true;
+}
+
+// serial number the NEXT resident launch on `dev` will carry (the plan brackets its launches with it)
+unsigned resident_next_serial(int dev) {
+  std::lock_guard<std::mutex> chain(g_chain_mu);
+  const unsigned s = g_arena[dev].serial + 1;
+  return s ? s : 1;
+}
+
+void resident_status(int dev, int *state, unsigned long long *failures) {
+  std::lock_guard<std::mutex> chain(g_chain_mu);
+  auto it = g_arena.find(dev);
+  int st_ = GCMF_RESIDENT_OFF;
+  unsigned long long nf = 0;
+  if (it != g_arena.end()) {
+    ResArena &st = it->second;
+    res_note_failure(st);
+    nf = st.failures;
+    st_ = st.disabled ? GCMF_RESIDENT_DISABLED : st.have_lock ? GCMF_RESIDENT_OK : st.lock_busy ? GCMF_RESIDENT_LOCK_BUSY : GCMF_RESIDENT_OFF;
+  }
+  if (state) *state = st_;
+  if (failures) *failures = nf;
 }
 
 bool resident_fits(const gcmf_plan *pl, int row_lo, int row_hi, int L) { return res_supported(pl, row_lo, row_hi, L, nullptr, nullptr, nullptr, nullptr); }
@@ -830,6 +945,7 @@ int launch_resident(gcmf_plan *pl, const MultiArgs &a, const double *pk, int L, 
   P.flags = st->flags;
   P.fail = st->fail_dev;
   P.dfail = st->flags + 1000;
+  st->last_use = std::chrono::steady_clock::now();
   if (++st->serial == 0) st->serial = 1;
   P.serial = st->serial;
   P.epoch0 = st->epoch;

@@ -15,6 +15,7 @@ from typing import Iterable, NamedTuple, Optional
 import numpy as np
 
 from .kernels import PLAN_CACHE_MODES, plan_cache_mode, kernels_cache_enabled
+from .kernels import last_path as kernels_last_path
 from .kernels import (
     ALL_KERNELS,
     AreaWeightedMixin,
@@ -179,8 +180,11 @@ def _create_filter_func(filter_spec: FilterSpec, Laplacian, evaluation: str = "a
         assert len(args) == len(Laplacian.required_grid_args())
         with plan_cache_mode(plan_cache):
             laplacian = memo.get(args)  # device plan: cached while the grid arrays are unchanged
-            return laplacian._run([field], spec=filter_spec, forward=forward, backward_f32=backward)[0]
+            out = laplacian._run([field], spec=filter_spec, forward=forward, backward_f32=backward)[0]
+        filter_func.last_path = kernels_last_path()
+        return out
 
+    filter_func.last_path = None
     return filter_func
 
 
@@ -195,8 +199,10 @@ def _create_filter_func_vec(filter_spec: FilterSpec, Laplacian, evaluation: str 
         with plan_cache_mode(plan_cache):
             laplacian = memo.get(args)
             u, v = laplacian._run([ufield, vfield], spec=filter_spec, forward=forward, backward_f32=backward)
+        filter_func_vec.last_path = kernels_last_path()
         return (u, v)
 
+    filter_func_vec.last_path = None
     return filter_func_vec
 
 
@@ -428,6 +434,16 @@ class Filter:
             hit = (key, make(self.filter_spec, self.Laplacian, self.evaluation, **extra))
             self.__dict__["_op"] = hit
         return hit[1]
+
+    @property
+    def last_path(self):
+        """Which of the library's bit-identical paths this Filter's last application took (not in the reference, which has one numpy
+        path): ``"resident"`` -- the whole polynomial in one on-chip launch (small grids); ``"strips"`` -- the strip-marching launches;
+        ``"resident-lock-busy"`` -- strips, because another process holds this GPU's on-chip lock (a ``RuntimeWarning`` says so once per
+        process); ``"resident-disabled"`` -- strips, because an on-chip launch of this process timed out earlier;
+        ``"host-row-blocks"`` -- a large host array streamed through row blocks; ``None`` before the first call."""
+        hit = self.__dict__.get("_op")
+        return None if hit is None else getattr(hit[1], "last_path", None)
 
     def apply(self, ds, dims=None):
         """Filter an ``xarray.DataArray`` / ``xarray.Dataset`` with a scalar Laplacian across ``dims``

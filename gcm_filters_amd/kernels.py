@@ -13,6 +13,7 @@ import contextlib
 import contextvars
 import os
 import threading
+import warnings
 import weakref
 from collections import OrderedDict
 from typing import Any, Dict, Optional, Sequence, Tuple
@@ -598,6 +599,7 @@ class _DeviceLaplacian:
                                bool(out_f32 and dtype == _lib.F32))
                 except _lib.GcmfError as e:
                     raise _translate(e) from None
+                _PATH.last = "host-row-blocks"
                 return outs
         if nbatch:
             self._call(plan, spec, [a.ctypes.data for a in ins], [a.ctypes.data for a in outs], nbatch, False,
@@ -643,8 +645,33 @@ class _DeviceLaplacian:
                 c = 2 / spec.s_max if self.is_dimensional else 2 / (spec.s_max * spec.dx_min_sq)
                 plan.apply(np.asarray(spec.p, dtype=np.float64), c, ins, outs, nbatch, device_ptrs=device_ptrs,
                            out_f32=out_f32, stream=stream, forward=forward, backward_f32=backward_f32)
+                _note_path(plan.last_path(), plan.device)
         except _lib.GcmfError as e:
             raise _translate(e) from None
+
+
+# ---- which path ran ------------------------------------------------------------------------------------------
+_PATH = threading.local()
+_PATH_WARNED = set()
+
+
+def _note_path(path, device):
+    """Remember, per thread, which of the two bit-identical paths the last filter application took (Filter.last_path), and say ONCE
+    per process when a grid that qualifies for the on-chip kernel is kept off it by another process's lock -- same bits, about half the
+    speed for a small grid, and otherwise silent."""
+    _PATH.last = path
+    if path in ("resident-lock-busy", "resident-disabled") and path not in _PATH_WARNED:
+        _PATH_WARNED.add(path)
+        why = ("another process holds the on-chip (resident) lock of GPU %s" % device if path == "resident-lock-busy" else
+               "an on-chip launch of this process timed out earlier on GPU %s (gcm_filters_amd._lib.resident_status)" % device)
+        warnings.warn(f"gcm_filters_amd: {why}: small grids run the strip-marching launches instead -- the same bits, slower "
+                      f"(Filter.last_path tells which path a call took).", RuntimeWarning, stacklevel=4)
+
+
+def last_path():
+    """The path the calling thread's last filter application took: "resident", "strips", "resident-lock-busy", "resident-disabled",
+    "host-row-blocks" (a large host array streamed through row blocks), or None."""
+    return getattr(_PATH, "last", None)
 
 
 class BaseScalarLaplacian(_DeviceLaplacian):

@@ -362,6 +362,31 @@ int gcmf_resident_supported(const gcmf_plan *plan, int64_t row_lo, int64_t row_h
 int gcmf_resident_levels(gcmf_plan *plan, const void *u, const void *v, void *uo, void *vo, const void *f, void *out, const double *pk,
                          int L, double p0, double c, uint32_t mode, int64_t row_lo, int64_t row_hi, void *stream);
 
+/* Which of the two bit-identical paths the last gcmf_apply of a plan took, and how often each was taken since the plan was made
+ * ("make the path taken observable").  The reference has no counterpart (one numpy path, filter.py:177-212).
+ *   GCMF_PATH_RESIDENT            the whole polynomial in on-chip launches (k_resident)
+ *   GCMF_PATH_STRIPS              the strip-marching launches (BASELINE-size grids, batches, f32, vector kinds, GCMF_RESIDENT=0 ...)
+ *   GCMF_PATH_STRIPS_LOCK_BUSY    the grid qualified for the on-chip kernel, but ANOTHER PROCESS holds this GPU's resident lock
+ *   GCMF_PATH_STRIPS_DISABLED     the grid qualified, but an on-chip launch of this process timed out earlier (see gcmf_resident_status)
+ * counts (optional): int64[5], indexed by the path codes. */
+#define GCMF_PATH_NONE 0
+#define GCMF_PATH_RESIDENT 1
+#define GCMF_PATH_STRIPS 2
+#define GCMF_PATH_STRIPS_LOCK_BUSY 3
+#define GCMF_PATH_STRIPS_DISABLED 4
+int gcmf_plan_last_path(const gcmf_plan *plan, int *path, int64_t *counts);
+/* This process's standing with the on-chip kernel on `device`: GCMF_RESIDENT_OK (it holds the per-GPU lock file -- given back
+ * GCMF_RESIDENT_LOCK_IDLE_S seconds, default 5, after its last on-chip launch finished; 0 = kept until exit), GCMF_RESIDENT_LOCK_BUSY
+ * (another process holds it), GCMF_RESIDENT_DISABLED (an on-chip launch of this process timed out: NaN result, strip-marching launches
+ * from then on), GCMF_RESIDENT_OFF (never asked / GCMF_RESIDENT=0 / a CU mask).  failures: time-outs seen so far.  A time-out is
+ * returned as GCMF_ERR_HIP ONCE, by the next gcmf_apply of the plan that issued the launch (the same call on the synchronising host
+ * path); calls on other plans are never failed for it. */
+#define GCMF_RESIDENT_OK 0
+#define GCMF_RESIDENT_LOCK_BUSY 1
+#define GCMF_RESIDENT_DISABLED 2
+#define GCMF_RESIDENT_OFF 3
+int gcmf_resident_status(int device, int *state, uint64_t *failures);
+
 
 /* Tunables: rows marched per wave of the single-step kernel (0 keeps the default); XCD-aware tile order
  * (bit 0: 1 on, 0 off; bits 1-2: neighbouring strips of the backward flux kernels march in opposite directions -- 1 off, 2 on, 0 keep;
@@ -370,8 +395,8 @@ int gcmf_resident_levels(gcmf_plan *plan, const void *u, const void *v, void *uo
  * backward evaluation (1 off, 2 flux kinds, 3 all scalar kinds; 0 keep); 0 keeps the default. */
 int gcmf_set_tuning(gcmf_plan *plan, int rows_per_wave, int xcd_remap, int multi);
 /* Named per-plan switches (A/B testing, the parity tests): "cgrid_ring" 1 / 0 (the static-ring C-grid kernel of batched f32 levels,
- * gcmf_cgrid_ring.hip; 0 = k_cgrid_stream2c everywhere), "cgrid_ring_smax" 4 / 5 (levels per launch), "cgrid_ring_hmax" (tallest
- * strip, 0 = 96 rows), "ringc9" 1 / 0 (nine levels per k_ringc launch on whole f64 flux grids), "clenshaw_f32" 0 / 1 (GCMF_BACKWARD_F32
+ * gcmf_cgrid_ring.hip; 0 = k_cgrid_stream2c everywhere), "cgrid_ring_smax" 4 / 5 / 6 (levels per launch), "cgrid_ring_ncarry" 0 / 1 (1 = round 5's form: only
+ * the last level keeps its previous row's scaled copies in registers; same bits), "cgrid_ring_hmax" (tallest strip, 0 = 96 rows), "ringc9" 1 / 0 (nine levels per k_ringc launch on whole f64 flux grids), "clenshaw_f32" 0 / 1 (GCMF_BACKWARD_F32
  * for every call of this plan, the slab drivers and gcmf_clenshaw_cut included), "ring_flux_f32" 1 / 0 (the forward ring kernel of the f32
  * flux kinds, gcmf_ring_flux_f32.hip; 0 = k_flux_multi2, same bits).  Unknown names: GCMF_ERR_INVALID_ARG. */
 int gcmf_set_option(gcmf_plan *plan, const char *name, int value);

@@ -27,7 +27,7 @@ def _case(shape, nlev, n_steps, scale=10.0, seed=0):
     return flt, plan, u, v, gv
 
 
-def _both(flt, plan, u, v, smax=4, strip_rows=0):
+def _both(flt, plan, u, v, smax=4, strip_rows=0, ncarry=0):
     try:
         plan.set_option("cgrid_ring", 0)
         plan.last_kernel()
@@ -35,13 +35,15 @@ def _both(flt, plan, u, v, smax=4, strip_rows=0):
         assert "k_cgrid_stream2c<" in plan.last_kernel()
         plan.set_option("cgrid_ring", 1)
         plan.set_option("cgrid_ring_smax", smax)
+        plan.set_option("cgrid_ring_ncarry", ncarry)
         if strip_rows:
             plan.set_tuning(multi_s=8, strip_rows=strip_rows)
         got = flt.apply_to_vector(u, v)
         assert "k_cgrid_ring<" in plan.last_kernel(), plan.last_kernel()
     finally:
         plan.set_option("cgrid_ring", 1)
-        plan.set_option("cgrid_ring_smax", 5)
+        plan.set_option("cgrid_ring_smax", 6)
+        plan.set_option("cgrid_ring_ncarry", 0)
         plan.set_tuning(multi_s=8, strip_rows=0)
     return ref, got
 
@@ -49,7 +51,7 @@ def _both(flt, plan, u, v, smax=4, strip_rows=0):
 @pytest.mark.parametrize("shape,nlev", [((96, 160), 8), ((64, 256), 12), ((33, 132), 2), ((120, 124), 5), ((48, 64), 50), ((25, 520), 4),
                                         ((7, 8), 3)])
 @pytest.mark.parametrize("n_steps", [8, 13, 44])
-@pytest.mark.parametrize("smax", [4, 5])
+@pytest.mark.parametrize("smax", [4, 5, 6])
 def test_same_bits_as_stream2c(shape, nlev, n_steps, smax):
     flt, plan, u, v, gv = _case(shape, nlev, n_steps)
     u[nlev // 2, 5 % shape[0], 7 % shape[1]] = np.nan     # NaN in wet cells: the stencil sees 0, the cell keeps its NaN
@@ -64,8 +66,21 @@ def test_same_bits_as_stream2c(shape, nlev, n_steps, smax):
     assert np.isnan(got[0][nlev // 2, 5 % shape[0], 7 % shape[1]])
 
 
+@pytest.mark.parametrize("smax", [4, 5, 6])
+def test_round5_form_only_the_last_level_carries(smax):
+    """"cgrid_ring_ncarry" = 1: the levels below the last REBUILD their previous row's three scaled copies from the raw row, its NaN
+    masks and the coefficient slot of the row before (round 5's register budget); the default since round 6 carries them.  Same operands,
+    same bits."""
+    flt, plan, u, v, gv = _case((96, 160), 8, 23)
+    u[3, 11, 17] = np.nan
+    ref, got = _both(flt, plan, u, v, smax, ncarry=1)
+    for r, g in zip(ref, got):
+        assert np.array_equal(r, g, equal_nan=True)
+
+
+@pytest.mark.parametrize("smax", [5, 6])
 @pytest.mark.parametrize("shape,nlev,n_steps", [((96, 160), 8, 13), ((40, 300), 5, 9)])
-def test_inf_takes_the_redo_pass(shape, nlev, n_steps):
+def test_inf_takes_the_redo_pass(shape, nlev, n_steps, smax):
     """+-inf in a wet cell: nan_to_num clamps it to +-FLT_MAX in the stencil (kernels.py:651-652); the workgroups that meet one redo
     their strip with the full nan_to_num at every level and give what k_cgrid_stream2c gives."""
     flt, plan, u, v, gv = _case(shape, nlev, n_steps)
@@ -73,7 +88,19 @@ def test_inf_takes_the_redo_pass(shape, nlev, n_steps):
     v[nlev - 1, 3, 150 % shape[1]] = -np.inf
     u[0, 9, 9] = np.nan
     with np.errstate(all="ignore"):
-        ref, got = _both(flt, plan, u, v, 5)
+        ref, got = _both(flt, plan, u, v, smax)
+    for r, g in zip(ref, got):
+        assert np.array_equal(r, g, equal_nan=True)
+
+
+def test_inf_that_appears_inside_a_launch_takes_the_redo_pass_too():
+    """A field near FLT_MAX overflows to +-inf INSIDE a launch (nothing non-finite is delivered): the watch on the last level's row sends
+    the strip to the redo pass, where every level clamps like k_cgrid_stream2c's nan_to_num (advisor, round 5)."""
+    flt, plan, u, v, gv = _case((96, 160), 8, 13)
+    u[2, 40:44, 60:64] = 3.0e38
+    v[5, 10, 100] = -3.2e38
+    with np.errstate(all="ignore"):
+        ref, got = _both(flt, plan, u, v, 6)
     for r, g in zip(ref, got):
         assert np.array_equal(r, g, equal_nan=True)
 
@@ -81,7 +108,7 @@ def test_inf_takes_the_redo_pass(shape, nlev, n_steps):
 @pytest.mark.parametrize("strip_rows", [16, 20, 31])
 def test_same_bits_however_the_strips_are_cut(strip_rows):
     flt, plan, u, v, gv = _case((150, 260), 6, 21)
-    ref, got = _both(flt, plan, u, v, 5, strip_rows)
+    ref, got = _both(flt, plan, u, v, 6, strip_rows)
     for r, g in zip(ref, got):
         assert np.array_equal(r, g, equal_nan=True)
 

@@ -210,7 +210,7 @@ def test_config5_cgrid_50_levels_fullsize(fullsize):
     try:
         plan.set_tuning(multi_s=8, clenshaw=2)    # the default: backward evaluation, four levels per launch
         cu_, cw_ = flt.apply_to_vector(u, v)
-        assert "k_cgrid_ring<float, 5, 2" in plan.last_kernel(), plan.last_kernel()   # five levels per launch, LDS-direct loads (round 5)
+        assert "k_cgrid_ring<float, 6, 2" in plan.last_kernel(), plan.last_kernel()   # six levels per launch (round 6: 44 = 6 6 6 6 5 5 5 5), LDS-direct loads (round 5)
         cu0, cw0 = cu_[0].cpu().numpy(), cw_[0].cpu().numpy()
         assert cu0.dtype == np.float64
         # levels 24 and 49 of the batch against the reference's own outputs for those levels (round 4: the fixture used to pin level 0 only)

@@ -51,6 +51,8 @@ def main():
             # optional suffixes: x0 = groups dealt round-robin to the XCDs instead of contiguous ranges, hNNN = tallest strip
             import re
             plan.set_option("cgrid_ring_hmax", int(re.search(r"h(\d+)", name).group(1)) if re.search(r"h(\d+)", name) else 0)
+            # cN: how many levels carry their previous row's scaled copies in registers (c1: round 5's form; default: all; m6: c1 unless c6)
+            plan.set_option("cgrid_ring_ncarry", int(re.search(r"c(\d+)", name).group(1)) if re.search(r"c(\d+)", name) else 0)
         plan.set_tuning(multi_s=8, strip_rows=a.strip, xcd_remap=0 if "x0" in name else 1)
 
     ref = None
