@@ -368,7 +368,7 @@ def roofline_of(cfg, r, steps, default_tuning):
     # recurrence steps one launch of that kernel advances: its last (vector kernels: fourth) template argument
     targs = r["kernel"][r["kernel"].index("<") + 1: r["kernel"].rindex(">")].split(", ")
     backward = any(k in r["kernel"] for k in ("k_ringc<", "k_ringcs<", "k_cgrid_stream2c<", "k_cgrid_ring<"))
-    steps_per_launch = float(targs[1] if ("k_ringcs<" in r["kernel"] or "k_cgrid_ring<" in r["kernel"]) else   # (<T, S, ...>: the early-exit form of short strips, the static-ring C-grid kernel)
+    steps_per_launch = float(targs[1] if any(k in r["kernel"] for k in ("k_ringcs<", "k_cgrid_ring<", "k_cgrid_ringf<")) else   # (<T, S, ...>: the early-exit form of short strips, the static-ring C-grid kernel)
                              targs[2] if backward else
                              targs[3] if any(k in r["kernel"] for k in ("stream2", "k_scalar_multi", "k_ring")) else
                              (targs[-1] if "k_flux_multi2" in r["kernel"] else 1))
@@ -749,6 +749,9 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (and the oracle parity check)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs measurements (configs 2, 4, 5)")
     ap.add_argument("--no-replan", action="store_true", help="keep ONE plan for all timed blocks (profiling runs: one placement)")
+    ap.add_argument("--kinds", action="store_true", help="instead of the BASELINE line: one roofline record per Laplacian kind that is not a "
+                    "BASELINE config (B-grid, MOM5U/T, the area-weighted and tripolar regular kinds) at --ny x --nx (tools/bench_kinds.py)")
+    ap.add_argument("--kinds-only", default="", help="--kinds: comma-separated subset of the kind names")
     ap.add_argument("--cpu-steps", type=int, default=64, help="Laplacian steps of the CPU sample")
     ap.add_argument("--rows-per-wave", type=int, default=0)
     ap.add_argument("--xcd-remap", type=int, default=-1)
@@ -1188,6 +1191,10 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
+    if args.kinds:
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import bench_kinds
+        return bench_kinds.main(args)
     if world == 1:
         return main_single(args)
     return main_multi(args, world, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")))

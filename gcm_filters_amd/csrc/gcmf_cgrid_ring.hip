@@ -30,19 +30,9 @@
 //
 // Arithmetic per level = CgLevel::feed<true> of gcmf_cgrid_stream2.hip operation for operation, so this kernel, k_cgrid_stream2c (which
 // still runs single-level fields, f64 plans and remainders below 4 levels) and the slab drivers give the same bits.
-#include "gcmf_multi_common.hpp"
-#include "gcmf_recurrence.hpp"
-#include <atomic>
-#include <cstdlib>
+#include "gcmf_cgrid_ring_common.hpp"
 
 namespace gcmf {
-
-template <typename T> struct CgV2;
-template <> struct CgV2<float> { typedef float type __attribute__((ext_vector_type(2))); };
-template <> struct CgV2<double> { typedef double type __attribute__((ext_vector_type(2))); };
-
-template <int N> using cic = std::integral_constant<int, N>;
-constexpr int cmod(int a, int m) { return ((a % m) + m) % m; }
 
 template <typename T> struct CRingP {
   const T *u0, *v0;    // b_{k+1} (first launch: the input f, scaled by p_n as it is loaded)
@@ -59,19 +49,9 @@ template <typename T> struct CRingP {
   double pn, pk[8], c;
 };
 
-template <typename T> __device__ __forceinline__ T cr_san(T x) {  // numpy.nan_to_num, as c2san of gcmf_cgrid_stream2.hip
-  const bool isn = (x != x);
-  const bool big = (mabs(x) > MLim<T>::big());
-  const T clamped = big ? (x > T(0) ? MLim<T>::big() : -MLim<T>::big()) : x;
-  return isn ? T(0) : clamped;
-}
-
-constexpr int CR_U = 12;  // unroll factor of the row loop = common period of all rings
-
 // The operand rows come in through LDS-direct loads (global_load_lds_dwordx4, gfx950): 16 bytes per lane -- the access width the memory
 // pipeline likes (8-byte accesses of this pattern stream at ~4.4 TB/s, experiments/cgrid_probe) -- and no registers in flight.  (Round 5
 // also built and measured a plain-load form and eight waves per workgroup; both lost and are gone: launch_cgrid_ring has the numbers.)
-constexpr int CR_WPB = 4;   // waves (= levels of the batch) per workgroup
 
 template <int S, int D> struct CRingGeom {
   static constexpr int M = S <= 4 ? 4 : 8;   // level j is stale j cells per side; windows start on a multiple of 4 cells (16-byte loads)
@@ -85,48 +65,6 @@ template <int S, int D> struct CRingGeom {
   static constexpr unsigned STGB = 3072u;
   static constexpr size_t lds_bytes() { return (size_t)STG_OFF + (unsigned)CR_WPB * D * STGB; }
   static constexpr int NDC = 8 / CR_WPB;   // coefficient loads per wave and row (two planes each; 16 plane slots over the waves)
-};
-
-#pragma clang diagnostic ignored "-Winline-asm"   // (M0 on the clobber list: the compiler has no use of its own for it in these kernels)
-// one LDS-direct load: every lane fetches 16 bytes from its global address, lane l's land at (LDS address in M0) + 16 l
-__device__ __forceinline__ void cr_dma16(const void *gptr, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_addr) : "memory", "m0");
-}
-template <int N> __device__ __forceinline__ void cr_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// The row cursor of a march (scalar registers): issue after issue it walks the rows r_begin, r_begin + 1, ... of the strip (periodic or
-// clamped at the slab's edges), stops at the last delivered row (the padded iterations of the last ring period re-load it), and gives
-// the byte offsets of the row it is on (ro) and of the row before it (rc) inside a level's plane (< 4 GB).
-struct CRingCursor {
-  int nx, rows, r_end, ri, cj;
-  bool wrap;
-  unsigned ro, rc, es;
-  __device__ __forceinline__ CRingCursor(int nx_, int rows_, bool wrap_, int r_begin, int r_end_, unsigned es_)
-      : nx(nx_), rows(rows_), r_end(r_end_), ri(r_begin), wrap(wrap_), es(es_) {
-    int r = r_begin - 1;
-    if (wrap) {
-      r = r < 0 ? r + rows : (r >= rows ? r - rows : r);
-      r = r < 0 ? r + rows : (r >= rows ? r - rows : r);  // |overshoot| <= S + 1 may exceed one period on tiny grids
-    } else {
-      r = r < 0 ? 0 : (r >= rows ? rows - 1 : r);
-    }
-    cj = r;
-    ro = rc = (unsigned)(cj * nx) * es;
-  }
-  __device__ __forceinline__ void advance() {
-    const bool adv = ri < r_end;
-    int nj;
-    if (wrap) {
-      nj = cj + 1;
-      nj = nj >= rows ? nj - rows : nj;
-    } else {
-      nj = ri < 0 ? 0 : (ri >= rows ? rows - 1 : ri);
-    }
-    rc = adv ? ro : rc;
-    cj = adv ? nj : cj;
-    ro = (unsigned)(cj * nx) * es;
-    ri += adv ? 1 : 0;
-  }
 };
 
 // A helper wave (a level that pads the last workgroup of a tile): fetches and publishes its share of the coefficient rows, keeps the

@@ -542,6 +542,7 @@ template <typename T, typename FB, int S> static int launch_c2_sel(gcmf_plan *pl
 
 int launch_cgrid_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s) {
   if (a.clen && cgrid_ring_supported(pl, a.nbatch, a.S) && cgrid_ring_args_aligned(a)) return launch_cgrid_ring(pl, a, s);   // batched f32 levels, deep launches
+  if (!a.clen && cgrid_ringf_supported(pl, a)) return launch_cgrid_ringf(pl, a, s);   // ... of the forward recurrence with an f64 running sum (round 6)
   if (a.clen) {  // backward evaluation: the conveyor has the state's type; single-level fields: private coefficient rings as above
     static const bool priv_ok = !(getenv("GCMF_VEC_PRIV") && atoi(getenv("GCMF_VEC_PRIV")) == 0);
     const bool priv = a.nbatch == 1 && priv_ok;

@@ -269,6 +269,9 @@ bool cgrid_ring_supported(const gcmf_plan *pl, int64_t nbatch, int S);
 bool cgrid_ring_args_aligned(const VecMultiArgs &a);   // the caller's state / input / result planes on 16-byte boundaries
 int cgrid_ring_smax(const gcmf_plan *pl, int64_t nbatch);   // deepest launch it offers this plan / batch (0: none)
 int launch_cgrid_ring(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s);
+// ... and of the forward recurrence with an f64 running sum (gcmf_cgrid_ringf.hip: Filter(evaluation="reference") on batched f32 levels)
+bool cgrid_ringf_supported(const gcmf_plan *pl, const VecMultiArgs &a);
+int launch_cgrid_ringf(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s);
 bool bgrid_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S);
 int launch_bgrid_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s);
 inline bool vec_multi_supported(const gcmf_plan *pl, int64_t nbatch, int S, bool backward = false) {

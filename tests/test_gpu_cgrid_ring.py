@@ -127,3 +127,73 @@ def test_against_the_oracle():
     for g, w in ((gu, wu), (gw, wv)):
         assert np.array_equal(np.isnan(g), np.isnan(w))
         assert np.nanmax(np.abs(g - w)) <= 1e-5 * np.nanmax(np.abs(w))   # (f32 state: SURVEY 8d's gate is 1e-4)
+
+
+# ---- k_cgrid_ringf (csrc/gcmf_cgrid_ringf.hip): the same structure for the reference's forward recurrence with an f64 running sum --------
+def _both_forward(u, v, gv, n_steps, scale=10.0, smax=5, strip_rows=0):
+    shape = u.shape[-2:]
+    dx = T.grid_dx_min("VECTOR_C_GRID", gv)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        flt = Filter(filter_scale=scale * dx, dx_min=dx, n_steps=n_steps, grid_type=GridType.VECTOR_C_GRID, grid_vars=gv, evaluation="reference")
+    plan = ALL_KERNELS[GridType.VECTOR_C_GRID](**gv)._plan(_lib.F32, shape)
+    try:
+        plan.set_option("cgrid_ring", 0)
+        plan.set_tuning(multi_s=smax, strip_rows=strip_rows)
+        plan.last_kernel()
+        ref = flt.apply_to_vector(u, v)
+        assert "k_cgrid_stream2<float, double" in plan.last_kernel(), plan.last_kernel()
+        plan.set_option("cgrid_ring", 1)
+        got = flt.apply_to_vector(u, v)
+        assert "k_cgrid_ringf<" in plan.last_kernel(), plan.last_kernel()
+    finally:
+        plan.set_option("cgrid_ring", 1)
+        plan.set_tuning(multi_s=8, strip_rows=0)
+    return ref, got
+
+
+@pytest.mark.parametrize("shape,nlev", [((96, 160), 8), ((64, 256), 12), ((33, 132), 2), ((120, 124), 5), ((48, 64), 50), ((25, 520), 4), ((7, 8), 3)])
+@pytest.mark.parametrize("n_steps", [9, 13, 44])
+@pytest.mark.parametrize("smax", [4, 5])
+def test_forward_ring_same_bits_as_stream2(shape, nlev, n_steps, smax):
+    """Filter(evaluation="reference") on batched f32 levels: k_cgrid_ringf against k_cgrid_stream2<float, double> (which the other tests
+    pin to single steps and to the reference's vectors), NaN in wet cells included."""
+    if shape[0] < smax + 2:
+        pytest.skip("fewer rows than a launch is deep")
+    flt, plan, u, v, gv = _case(shape, nlev, n_steps)
+    u[nlev // 2, 5 % shape[0], 7 % shape[1]] = np.nan
+    v[0, shape[0] - 1, shape[1] - 1] = np.nan
+    ref, got = _both_forward(u, v, gv, n_steps, smax=smax)
+    for r, g in zip(ref, got):
+        assert g.dtype == np.float64 and np.array_equal(r, g, equal_nan=True), (shape, nlev, n_steps, np.nanmax(np.abs(r - g)))
+    assert np.isnan(got[0][nlev // 2, 5 % shape[0], 7 % shape[1]])
+
+
+@pytest.mark.parametrize("strip_rows", [0, 16, 31])
+def test_forward_ring_redo_pass_with_the_running_sum_updated_in_place(strip_rows):
+    """+-inf delivered, and values near FLT_MAX that overflow INSIDE a launch: the fast pass stops storing where it sees the first
+    non-finite value and the redo pass (full nan_to_num) stores from there on -- gcmf_apply updates the running sum in place, so rows the
+    fast pass has already accumulated must not be accumulated again."""
+    flt, plan, u, v, gv = _case((150, 260), 6, 21)
+    u[1, 20, 33] = np.inf
+    v[5, 100, 150] = -np.inf
+    u[2, 70:74, 60:64] = 3.0e38
+    u[0, 9, 9] = np.nan
+    with np.errstate(all="ignore"):
+        ref, got = _both_forward(u, v, gv, 21, strip_rows=strip_rows)
+    for r, g in zip(ref, got):
+        assert np.array_equal(r, g, equal_nan=True)
+
+
+def test_forward_ring_against_the_oracle():
+    shape, nlev, n_steps = (96, 160), 9, 44
+    flt, plan, u, v, gv = _case(shape, nlev, n_steps)
+    u[3, 50, 70] = np.nan
+    ref, got = _both_forward(u, v, gv, n_steps)
+    fs = flt.filter_spec
+    with np.errstate(all="ignore"):
+        wu, wv = O.filter_func_vec(O.FilterSpec(fs.n_steps, fs.s_max, np.asarray(fs.p), fs.dx_min_sq), "VECTOR_C_GRID",
+                                   u.astype("f8"), v.astype("f8"), {k: x.astype("f8") for k, x in gv.items()})
+    for g, w in zip(got, (wu, wv)):
+        assert np.array_equal(np.isnan(g), np.isnan(w))
+        assert np.nanmax(np.abs(g - w)) <= 1e-5 * np.nanmax(np.abs(w))

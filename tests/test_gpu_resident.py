@@ -218,15 +218,15 @@ def test_reference_zarr_goldens_under_the_default_policy(grid, golden_zarr, monk
         assert "k_resident<" in plan.last_kernel(), plan.last_kernel()
 
 
-def _run_two_workers(tmp_path, seconds, extra_env, nproc=2):
+def _run_two_workers(tmp_path, seconds, extra_env, nproc=2, extra_args=None):
     import json
     import subprocess
     import sys
     env = dict(os.environ, GCMF_RESIDENT_LOCK_DIR=str(tmp_path), **extra_env)
     env.pop("GCMF_RESIDENT", None)
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "resident_worker.py")
-    procs = [subprocess.Popen([sys.executable, worker, str(seconds), str(k)], env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE,
-                              stderr=subprocess.PIPE, text=True) for k in range(nproc)]
+    procs = [subprocess.Popen([sys.executable, worker, str(seconds), str(k)] + [str(x) for x in (extra_args[k] if extra_args else [])], env=env,
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k in range(nproc)]
     try:
         for p in procs:
             assert p.stdout.readline().strip() == "READY", p.stderr.read()[-2000:]
@@ -255,6 +255,46 @@ def test_two_processes_share_a_gpu_without_clashing(tmp_path):
         assert o["n"] > 20 and o["wrong"] == 0 and o["nan_results"] == 0 and o["errors"] == [], outs
     assert any("gcmf::k_resident" in o["kernels"] for o in outs), outs          # somebody did run on the chip ...
     assert any(k.startswith("gcmf::k_ringc") for o in outs for k in o["kernels"]), outs   # ... and somebody stepped aside
+    # ... and says so: Filter.last_path names the path, one RuntimeWarning per process names the reason
+    stepped = [o for o in outs if "resident-lock-busy" in o["paths"]]
+    assert stepped and all(len(o["lock_warnings"]) == 1 and "another process holds" in o["lock_warnings"][0] for o in stepped), outs
+    assert all(o["path_counts"]["resident-lock-busy"] > 0 for o in stepped), outs
+    assert any(o["paths"] == ["resident"] and o["lock_warnings"] == [] and o["status"]["state"] == "ok" for o in outs), outs
+
+
+def test_an_idle_process_gives_the_lock_back(tmp_path):
+    """a process that once filtered a small grid and then sits idle (a notebook) must not keep every other process of
+    the GPU off the on-chip path until it exits: GCMF_RESIDENT_LOCK_IDLE_S seconds (default 5; 1 here) after its last on-chip launch has
+    finished the lock is given back.  Process 0 filters for a second and then idles for six; process 1 starts three seconds in and must find
+    the on-chip path free."""
+    outs = _run_two_workers(tmp_path, 1.0, {"GCMF_RESIDENT_LOCK_IDLE_S": "1"}, extra_args=[[0.0, 6.0], [3.0, 0.0]])
+    assert outs[0]["paths"] == ["resident"] and outs[1]["paths"] == ["resident"], outs
+    assert outs[0]["status"]["state"] == "off" and outs[1]["status"]["state"] == "ok", outs     # (0 gave it back; 1 holds it)
+    for o in outs:
+        assert o["wrong"] == 0 and o["nan_results"] == 0 and o["errors"] == [] and o["lock_warnings"] == [], outs
+
+
+def test_last_path_and_counters(monkeypatch):
+    """Filter.last_path / Plan.path_counts (include/gcmf.h: gcmf_plan_last_path): which of the two bit-identical paths ran."""
+    shape = (256, 256)
+    f, gv = T.scalar_case("IRREGULAR_WITH_LAND", shape)
+    dx = T.grid_dx_min("IRREGULAR_WITH_LAND", gv)
+    flt = Filter(filter_scale=8.0 * dx, dx_min=dx, grid_type=GridType.IRREGULAR_WITH_LAND, grid_vars=gv)
+    assert flt.last_path is None
+    monkeypatch.delenv("GCMF_RESIDENT", raising=False)
+    a = flt.apply(f)
+    assert flt.last_path == "resident"
+    monkeypatch.setenv("GCMF_RESIDENT", "0")
+    b = flt.apply(f)
+    assert flt.last_path == "strips" and np.array_equal(a, b, equal_nan=True)
+    plan = ALL_KERNELS[GridType.IRREGULAR_WITH_LAND](**gv)._plan(_lib.F64, shape)
+    counts = plan.path_counts()
+    assert counts["resident"] >= 1 and counts["strips"] >= 1 and counts["resident-lock-busy"] == 0
+    assert _lib.resident_status(0)["state"] in ("ok", "off") and _lib.resident_status(0)["failures"] == 0
+    big = Filter(filter_scale=4.0, dx_min=1.0, grid_type=GridType.REGULAR)      # too few levels for the on-chip policy: strips
+    monkeypatch.delenv("GCMF_RESIDENT", raising=False)
+    big.apply(T.random_field((64, 64), 3))
+    assert big.last_path == "strips"
 
 
 def test_a_clash_outside_the_lock_is_loud_and_then_falls_back(tmp_path):
@@ -264,7 +304,10 @@ def test_a_clash_outside_the_lock_is_loud_and_then_falls_back(tmp_path):
     outs = _run_two_workers(tmp_path, 4.0, {"GCMF_RESIDENT_LOCK": "0", "GCMF_RESIDENT_TIMEOUT_MS": "100"})
     for o in outs:
         assert o["wrong"] == 0, outs                       # right or NaN, nothing in between
-        assert len(o["errors"]) <= 1, outs                 # told once
+        assert len(o["errors"]) <= 1, outs                 # told once -- to the plan whose application it poisoned
+        assert (o["status"]["failures"] > 0) == (o["status"]["state"] == "disabled"), outs
+        if o["errors"]:
+            assert o["status"]["state"] == "disabled" and "resident-disabled" in o["paths"], outs
         assert o["n"] > 10, outs                           # and the work went on
         if o["errors"] or o["nan_results"]:
             assert any(k.startswith("gcmf::k_ringc") for k in o["kernels"]), outs

@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--halo", type=int, default=0, help="ghost rows per side of the slab (0 = SlabFilter's default: as deep as the filter, <= 64)")
+    ap.add_argument("--overlap", type=int, default=-1, help="1: split every launch that is followed by an exchange into edge strips + interior and "
+                    "run the exchange beside the interior; 0: never; -1: SlabFilter's own choice")
     a = ap.parse_args()
     ny, nx = 2400, 3600
     wl = T.baseline_workload(a.config, (ny, nx))
@@ -70,6 +72,8 @@ def main():
             for ex in ("none", "p2p", "native"):
                 sf = SlabFilter(wr["grid"], wr["grid_vars"], dict(wr["fk"]), rows, nx, device=0, rank=0, world=1, self_ring=True,
                                 exchange="p2p" if ex == "none" else ex, halo=a.halo or None)
+                if a.overlap >= 0:
+                    sf.overlap = bool(a.overlap)
                 if ex == "none":
                     sf.native_driver = False
                     sf._exchange_start = lambda tensors: None
@@ -80,6 +84,8 @@ def main():
         else:
             rank = a.world - 1
             sf = SlabFilter(wl["grid"], wl["grid_vars"], fk, ny, nx, rank=rank, world=a.world, device=0, exchange="torch", halo=a.halo or None)
+            if a.overlap >= 0:
+                sf.overlap = bool(a.overlap)
             sf.native_driver = False
             sf._exchange_start = lambda tensors: None
             sf._exchange_finish = lambda ticket: None
@@ -91,6 +97,8 @@ def main():
             for ex in ("none", "p2p", "native"):
                 s3 = SlabFilter(w3["grid"], w3["grid_vars"], dict(w3["fk"]), rows, nx, device=0, rank=0, world=1, self_ring=True,
                                 exchange="p2p" if ex == "none" else ex, halo=a.halo or None)
+                if a.overlap >= 0:
+                    s3.overlap = bool(a.overlap)
                 if ex == "none":
                     s3.native_driver = False
                     s3._exchange_start = lambda tensors: None
