@@ -14,6 +14,7 @@ OUT=$PWD/gpurun_out/fuzz; mkdir -p "$OUT"; S=${1:-400}
   timeout 600 python tools/fuzz_gpu.py $((S+30)) 200 --eval backward
   timeout 600 python tools/fuzz_gpu.py $((S+31)) 200 --eval reference
   timeout 600 python tools/fuzz_gpu.py $((S+32)) 80 --eval backward --bgrid
+  timeout 600 python tools/fuzz_gpu.py $((S+33)) 120 --eval reference --cgrid
   timeout 600 python tools/fuzz_nsteps.py
   timeout 600 python tools/fuzz_inputs.py $((S+9))
   for w in 2 3; do for ex in auto p2p; do timeout 900 python tools/fuzz_slabs.py $((S+10+w)) 30 $w $ex; done; done
