@@ -349,6 +349,7 @@ int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int 
   if (const char *e = getenv("GCMF_RINGC_XE_ROWS")) pl->ringc_xe_rows = atoi(e);
   if (const char *e = getenv("GCMF_CLENSHAW")) pl->clenshaw = atoi(e);
   if (const char *e = getenv("GCMF_RINGC9")) pl->ringc9 = atoi(e);
+  if (const char *e = getenv("GCMF_PACK_BATCH")) pl->pack_batch = atoi(e);
   if (const char *e = getenv("GCMF_CLENSHAW_F32")) pl->clenshaw_f32 = atoi(e);
   PLAN_HIP(hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking));
   PLAN_HIP(hipEventCreate(&pl->ev0));

@@ -172,6 +172,7 @@ struct gcmf_plan {
   int ring = 1;           // env GCMF_RING=0: deep launches stay with k_flux_multi2 / k_scalar_multi
   unsigned *ring_nfb = nullptr;    // device counter behind gcmf_ring_fallbacks (lives behind zero_row)
   const void *zero_row = nullptr;  // nx zeros: what rows beyond a closed boundary read as coefficients / mask bits (k_ring)
+  int pack_batch = 1;     // k_ringc / k_ringcs: the fields of a batch as one column per window (ringc_walk, round 6); gcmf_set_option "pack_batch"
   int ringc9 = 1;         // whole f64 flux-form grids without a tripole seam: up to NINE levels per k_ringc launch (env GCMF_RINGC9, gcmf_set_option "ringc9")
   int clenshaw = 2;       // backward (Clenshaw) evaluation: 0 off, 1 the flux kinds + C-grid, 2 (default since round 4) every kind that has a
                           // backward kernel (f64 REGULAR / land-mask kinds, B-grid too); env GCMF_CLENSHAW.  Per call: GCMF_FORWARD_RECURRENCE

@@ -111,6 +111,8 @@ template <typename T, typename FB> struct MultiP {
   int wrap, first, last, area_weighted;
   int xcd_per;       // k_ring: workgroups per XCD for the XCD-contiguous order (0 = launch order)
   int zigzag;        // k_ringc, flux kinds: odd strips march upwards (gcmf_ringc_impl.hpp)
+  int npack;         // k_ringc / k_ringcs, batches (round 6): > 0 = the npack fields of the batch are ONE column of npack * (out_hi - out_lo) rows
+                     // per window, cut into runs of H rows -- a wave walks its run, at most two (field, row range) segments (0: gridDim.y = batch)
   long long bstride;
   double pk[MAX_PK];  // coefficient of level t (1-based) at pk[t-1]
   double p0;         // first only

@@ -39,8 +39,9 @@ template <int VEC> __device__ __forceinline__ unsigned cell_bytes(const uint8_t 
 // XE: early exits also for the flux kinds (k_ringcs: slabs that do not own a tripole seam, see below)
 // XE6: ONE early exit, in the middle of the ring period (whole f64 flux grids at nine levels, round 6: a strip marches a multiple of six
 // rows instead of twelve)
+// (wx: the wave's window; [a, b): the rows it owns; boff: its field's offset in the planes; odd: odd strips of the flux kinds march upwards)
 template <typename T, int KIND, int S, bool FIRST, bool SANI, bool XE = false, bool XE6 = false>
-__device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid) {
+__device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wx, const int a, const int b, const long long boff, const bool odd) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int W = 64 * VEC;
   constexpr int M = (S + VEC - 1) / VEC * VEC;
@@ -52,11 +53,7 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
   constexpr bool FUSED = true;   // nothing here is bit-identical with numpy anyway: every multiply-add pair is one fma
 
   const int lane = threadIdx.x & 63;
-  const int wx = wid % P.nwx, st = wid / P.nwx;
   const int nx = P.nx, rows = P.rows;
-  const int a = P.out_lo + st * P.H;
-  const int b = min(a + P.H, P.out_hi);
-  const long long boff = (long long)blockIdx.y * P.bstride;
   const int pos = wx * WI - M + lane * VEC;
   int col_s = pos % nx;
   if (col_s < 0) col_s += nx;
@@ -110,7 +107,7 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
   // marches read them a whole march apart).  The arithmetic is the same instruction stream: "north" in march order is the grid's
   // south, the row of cN that travels with a centre row j is that of row j - 1, the carried flux is minus the grid's north flux, and
   // (fe - fw) + (fn - fs) is bit-for-bit symmetric under that exchange.
-  const bool up = FLUX && P.zigzag && (st & 1);
+  const bool up = FLUX && P.zigzag && odd;
   const int mir = a + b - 1;
   int cj, cj_prev;
   bool cout_, cout_prev;
@@ -386,18 +383,61 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wid
   return false;
 }
 
+// What wave `wid` of a launch marches.  gridDim.y = the batch (P.npack == 0): the strip st = wid / nwx of field blockIdx.y.  Packed batches
+// (P.npack > 0, round 6): the fields of the batch are ONE column of npack * nrows rows per window, cut into runs of P.H rows; a wave walks
+// its run, which crosses at most one field boundary (H <= nrows): up to two (field, row range) segments, each a march of its own with its
+// 2 S warm-up rows.  16 fields x 33 windows of a 300-row slab tile 1024 wave slots at ~70 % as whole strips (a strip cannot cross from one
+// field into the next) and at ~95 % this way.
+template <typename T, int KIND, int S, bool FIRST, bool XE, bool XE6, bool PACK>
+__device__ __forceinline__ void ringc_walk(const MultiP<T, T> &P, const int wid) {
+  const int wx = wid % P.nwx, st = wid / P.nwx;
+  if constexpr (!PACK) {   // one strip of one field (the instruction stream of rounds 2-5: the walk below costs the land-mask kernel 5 %)
+    const int a = P.out_lo + st * P.H;
+    const int b = min(a + P.H, P.out_hi);
+    const long long boff = (long long)blockIdx.y * P.bstride;
+    if (ringc_march<T, KIND, S, FIRST, false, XE, XE6>(P, wx, a, b, boff, (st & 1) != 0)) {
+      if constexpr (KIND != K_REG) {
+        if (P.nfb && (threadIdx.x & 63) == 0) atomicAdd(P.nfb, 1u);                      // instrumentation: gcmf_ring_fallbacks
+        ringc_march<T, KIND, S, FIRST, true, XE, XE6>(P, wx, a, b, boff, (st & 1) != 0);   // the same strip again, operands through nan_to_num
+      }
+    }
+    return;
+  }
+  const int nrows = P.out_hi - P.out_lo;
+  int v0 = st * P.H;   // (rows of the batch's column: the launcher keeps batch x rows below 2^30)
+  const int v1 = min(v0 + P.H, P.npack * nrows);
+  while (v0 < v1) {   // (wave-uniform: scalar registers)
+    const int fld = v0 / nrows, r = v0 - fld * nrows;
+    const int len = min(v1 - v0, nrows - r);
+    const int a = P.out_lo + r, b = a + len;
+    const long long boff = (long long)fld * P.bstride;
+    if (ringc_march<T, KIND, S, FIRST, false, XE, XE6>(P, wx, a, b, boff, (st & 1) != 0)) {
+      if constexpr (KIND != K_REG) {
+        if (P.nfb && (threadIdx.x & 63) == 0) atomicAdd(P.nfb, 1u);
+        ringc_march<T, KIND, S, FIRST, true, XE, XE6>(P, wx, a, b, boff, (st & 1) != 0);
+      }
+    }
+    v0 += len;
+  }
+}
+
 template <typename T, int KIND, int S, bool FIRST>
 __global__ __launch_bounds__(256, 1) void k_ringc(const MultiP<T, T> P) {
   int bx = blockIdx.x;
   if (P.xcd_per > 0 && bx < 8 * P.xcd_per) bx = (bx & 7) * P.xcd_per + (bx >> 3);
   const int wid = bx * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wid >= P.nwaves) return;
-  if (ringc_march<T, KIND, S, FIRST, false>(P, wid)) {
-    if constexpr (KIND != K_REG) {
-      if (P.nfb && (threadIdx.x & 63) == 0) atomicAdd(P.nfb, 1u);  // instrumentation: gcmf_ring_fallbacks
-      ringc_march<T, KIND, S, FIRST, true>(P, wid);                 // the same strip again, operands through nan_to_num
-    }
-  }
+  ringc_walk<T, KIND, S, FIRST, false, false, false>(P, wid);
+}
+
+// ... and for packed batches (ringc_walk<PACK>): XE = the early-exit form of the flux kinds (k_ringcs)
+template <typename T, int KIND, int S, bool FIRST, bool XE>
+__global__ __launch_bounds__(256, 1) void k_ringcp(const MultiP<T, T> P) {
+  int bx = blockIdx.x;
+  if (P.xcd_per > 0 && bx < 8 * P.xcd_per) bx = (bx & 7) * P.xcd_per + (bx >> 3);
+  const int wid = bx * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wid >= P.nwaves) return;
+  ringc_walk<T, KIND, S, FIRST, XE, false, true>(P, wid);
 }
 
 // The flux kinds with early exits: for ROW SLABS that own no tripole seam (the ranks of a multi-GPU run, the row blocks of the host
@@ -409,10 +449,7 @@ __global__ __launch_bounds__(256, 1) void k_ringcs(const MultiP<T, T> P) {
   if (P.xcd_per > 0 && bx < 8 * P.xcd_per) bx = (bx & 7) * P.xcd_per + (bx >> 3);
   const int wid = bx * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wid >= P.nwaves) return;
-  if (ringc_march<T, K_FLUX, S, FIRST, false, true>(P, wid)) {
-    if (P.nfb && (threadIdx.x & 63) == 0) atomicAdd(P.nfb, 1u);
-    ringc_march<T, K_FLUX, S, FIRST, true, true>(P, wid);
-  }
+  ringc_walk<T, K_FLUX, S, FIRST, true, false, false>(P, wid);
 }
 
 // k_ringc with the one mid-period exit (see ringc_march)
@@ -422,10 +459,7 @@ __global__ __launch_bounds__(256, 1) void k_ringc6(const MultiP<T, T> P) {
   if (P.xcd_per > 0 && bx < 8 * P.xcd_per) bx = (bx & 7) * P.xcd_per + (bx >> 3);
   const int wid = bx * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wid >= P.nwaves) return;
-  if (ringc_march<T, KIND, S, FIRST, false, false, true>(P, wid)) {
-    if (P.nfb && (threadIdx.x & 63) == 0) atomicAdd(P.nfb, 1u);
-    ringc_march<T, KIND, S, FIRST, true, false, true>(P, wid);
-  }
+  ringc_walk<T, KIND, S, FIRST, false, true, false>(P, wid);
 }
 
 template <typename T, int KIND, int S, bool FIRST, bool XE = false, bool XE6 = false>
@@ -474,6 +508,34 @@ static int launch_ringc_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   if (H > nrows) H = nrows;
   P.H = H;
   P.nstrips = (nrows + H - 1) / H;
+  P.npack = 0;
+  if (!XE6 && a.nbatch > 1 && pl->strip_rows <= 0 && pl->pack_batch && (long long)a.nbatch * nrows < (1LL << 30)) {
+    // Packed batch (see ringc_walk): as many runs per window as fill whole rounds of the 1024 wave slots, never longer than a field.
+    // Taken when its rounds x (run + warm-up rows, one field boundary in most runs) beat the whole strips chosen above -- short grids
+    // (the 300-row slab of one of 8 ranks, 16 fields: 626-651 -> 708-710 G; tools/measure_batched_scaling.py).
+    constexpr int EXITP = (KIND == K_FLUX && !XE) ? (XE6 ? R / 2 : R) : 4;
+    auto padded = [&](long long m) { return (m + EXITP - 1) / EXITP * EXITP; };
+    const long long total = (long long)a.nbatch * nrows, slots = std::max(1LL, 1024LL / P.nwx);
+    const long long rounds_u = ((long long)P.nwx * a.nbatch * P.nstrips + 1023) / 1024;
+    const double cost_u = (double)(rounds_u * padded(H + 2 * S)) * (1.0 + 0.04 * (rounds_u - 1));
+    double best = cost_u;
+    long long best_q = 0, best_w = 0;
+    for (long long k = 1; k <= 16; ++k) {
+      const long long w = std::min(total, slots * k);                 // runs per window
+      const long long q = (total + w - 1) / w;                       // rows per run
+      if (q > nrows || q > 320) continue;   // (tall runs lose: 2400 x 3600 x 8 fields as 30 runs of 640 rows per window 768 G against 805 G as whole strips)
+      const long long rounds = (w * P.nwx + 1023) / 1024;
+      const bool crosses = (nrows % q) != 0;                          // (runs aligned with the fields cross nothing)
+      const double cost = (double)(rounds * (padded(q + 2 * S) + (crosses ? padded(2 * S + EXITP / 2) : 0))) * (1.0 + 0.04 * (rounds - 1));
+      if (cost < 0.97 * best) { best = cost; best_q = q; best_w = (total + q - 1) / q; }
+      if (w >= total) break;
+    }
+    if (best_q > 0) {
+      P.H = (int)best_q;
+      P.nstrips = (int)best_w;
+      P.npack = (int)a.nbatch;
+    }
+  }
   P.nwaves = P.nwx * P.nstrips;
   P.wrap = g.south_wrap && g.north_wrap;
   P.first = FIRST ? 1 : 0;
@@ -483,9 +545,19 @@ static int launch_ringc_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   for (int t = 0; t < MAX_PK; ++t) P.pk[t] = t < S ? a.pk[t] : 0.0;
   P.p0 = a.p0;
   P.c = a.c;
-  dim3 block(256), grid((P.nwaves + 3) / 4, (unsigned)a.nbatch);
+  dim3 block(256), grid((P.nwaves + 3) / 4, P.npack > 0 ? 1u : (unsigned)a.nbatch);
   P.xcd_per = pl->xcd_remap ? (int)(grid.x / 8) : 0;
   P.zigzag = pl->zigzag;
+  if constexpr (!XE6) {
+    if (P.npack > 0) {
+      hipLaunchKernelGGL((k_ringcp<T, KIND, S, FIRST, XE>), grid, block, 0, s, P);
+      GCMF_HIP(hipGetLastError());
+      note_kernel(pl, std::string("gcmf::k_ringcp<") + tyname<T>() + ", " + std::to_string(KIND) + ", " + std::to_string(S) + ", " +
+                          (FIRST ? "true" : "false") + ", " + (XE ? "true" : "false") + ">", S,
+                  launch_geom(P.H, P.nstrips, P.nwx, P.xcd_per > 0, grid.x, grid.y, nrows));
+      return GCMF_OK;
+    }
+  }
   if constexpr (XE) {
     hipLaunchKernelGGL((k_ringcs<T, S, FIRST>), grid, block, 0, s, P);
     GCMF_HIP(hipGetLastError());

@@ -149,6 +149,50 @@ def test_opposite_marches_give_the_same_bits(grid, dt, kwargs):
     assert np.abs(outs[0][ok] - want[ok]).max() <= (1e-12 if dt == "f8" else 1e-4) * np.abs(want[ok]).max()
 
 
+@pytest.mark.parametrize("grid", ["IRREGULAR_WITH_LAND", "MOM5U", "TRIPOLAR_POP_WITH_LAND", "REGULAR_WITH_LAND", "REGULAR", "TRIPOLAR_REGULAR_WITH_LAND_AREA_WEIGHTED"])
+@pytest.mark.parametrize("shape,nb", [((300, 520), 16), ((260, 520), 5), ((96, 1100), 7), ((1200, 260), 3), ((64, 300), 41)])
+def test_packed_batches_give_the_same_bits(grid, shape, nb):
+    """Round 6 (csrc/gcmf_ringc_impl.hpp: ringc_walk): the fields of a batch are cut as ONE column of nb x rows rows per window, a wave
+    walks a run that may cross from one field into the next -- two marches with their own warm-up rows.  The same rows, the same
+    arithmetic: bit-identical with whole strips per field (option "pack_batch" 0), with NaN on land, NaN / inf in wet cells of some fields
+    (the redo of one segment), on periodic, closed and tripolar grids, and at forced strip heights that put the cuts everywhere."""
+    flt, plan, f, want = _case(grid, shape, 21, nanland=True, nb=nb)
+    f = f.copy()
+    land = np.isnan(f[0])
+    wet = np.argwhere(~land)
+    j, i = wet[len(wet) // 3]
+    f[1, j, i] = np.nan
+    j, i = wet[(2 * len(wet)) // 3]
+    f[nb - 1, j, i] = np.inf
+    outs, kernels = [], []
+    try:
+        for pack in (0, 1):
+            plan.set_option("pack_batch", pack)
+            plan.last_kernel()
+            with np.errstate(all="ignore"):
+                outs.append(flt.apply(f))
+            kernels.append((plan.last_kernel(), plan.last_kernel_geometry()))
+    finally:
+        plan.set_option("pack_batch", 1)
+    assert "k_ringc" in kernels[0][0] and "k_ringc" in kernels[1][0], kernels
+    assert kernels[0][1]["grid"].endswith(f"x{nb}"), kernels                        # one grid row per field ...
+    assert np.array_equal(outs[0], outs[1], equal_nan=True), kernels
+    clean = [k for k in range(nb) if k not in (1, nb - 1)]
+    ok = ~np.isnan(want[clean])
+    assert np.array_equal(np.isnan(outs[1][clean]), np.isnan(want[clean]))
+    assert np.abs(outs[1][clean][ok] - want[clean][ok]).max() <= 1e-12 * np.abs(want[clean][ok]).max()
+
+
+def test_packed_batches_are_what_a_slab_batch_runs():
+    """... and the packed form is what the launcher picks where whole strips tile the wave slots badly: 16 fields on a 300-row grid."""
+    flt, plan, f, want = _case("IRREGULAR_WITH_LAND", (300, 3600), 24, nb=16)
+    plan.last_kernel()
+    got = flt.apply(f)
+    geom = plan.last_kernel_geometry()
+    assert "k_ringc" in plan.last_kernel() and geom["grid"].endswith("x1"), (plan.last_kernel(), geom)   # ... or ONE for the packed column
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+
+
 def test_default_is_backward_for_flux_kinds_and_forward_for_the_rest():
     """(The name is round 3's.)  Round 4: the default evaluates EVERY f64 scalar kind backwards -- the land-mask / REGULAR kinds gain
     12-20 % from the fused arithmetic and stay within 1e-14 of numpy; Filter(evaluation="reference") is the bit-exact escape."""
