@@ -328,9 +328,19 @@ int gcmf_slab_apply_backward(gcmf_plan *pl, gcmf_comm *comm, gcmf_p2p *p2p, int 
     return p2p ? gcmf_p2p_finish(p2p, stream) : gcmf_halo_finish(comm, stream);
   };
   int rc;
-  {  // f's ghost rows: the first launch forms b_n = p_n f on them, the later ones read f on the rows they compute
+  // f's ghost rows: the first launch forms b_n = p_n f on them, the later ones read f on the rows they compute.  Batches (round 6): the
+  // rows of the first launch whose S-level cone stays inside the owned rows need none of them, so that exchange -- the only one of an
+  // application when the ghost zone is as deep as the filter -- runs BESIDE them, and the two edge pieces follow (one launch cut in
+  // three).  MEASURED, round 6 (tools/measure_batched_scaling.py, 300-row slab of 2400 x 3600, same box, off / on): 16 fields RCCL 1.922 /
+  // 1.974 ms, mailboxes 1.969 / 2.076; 8 fields RCCL 1.185 / 1.134, mailboxes 1.158 / 1.214; config 4, 16 fields 1.672 / 1.742 -- the two
+  // edge pieces cost what the hidden exchange saves.  OFF unless GCMF_SLAB_OVERLAP_FIRST=1.
+  static const bool first_beside = getenv("GCMF_SLAB_OVERLAP_FIRST") && atoi(getenv("GCMF_SLAB_OVERLAP_FIRST")) != 0;
+  bool first_pending = false;
+  {
     void *st[1] = {X};
-    if ((rc = exchange_start(st, 1)) || (rc = exchange_finish())) return rc;
+    if ((rc = exchange_start(st, 1))) return rc;
+    first_pending = multi && first_beside && nbatch >= 2 && nbatch * ro >= 2000 && ro >= 4 * (int64_t)cut[0];
+    if (!first_pending && (rc = exchange_finish())) return rc;
   }
   const bool fb32 = (dtype == GCMF_F32) && (flags & GCMF_OUT_F32);
   void *u = nullptr, *v = nullptr;
@@ -405,7 +415,18 @@ int gcmf_slab_apply_backward(gcmf_plan *pl, gcmf_comm *comm, gcmf_p2p *p2p, int 
       mm.row_lo = r0; mm.row_hi = r1;
       return advance_multi(pl, mm, s, nullptr, true);
     };
-    if (ovl) {
+    if (first_pending && ovl) {   // (both at once is not worth a fourth piece: the input's ghost rows first, then as below)
+      if ((rc = exchange_finish())) return rc;
+      first_pending = false;
+    }
+    if (first_pending) {
+      const int ilo = gs ? (int)(fo + S) : lo, ihi = gn ? (int)(fo + ro - S) : hi;
+      if ((rc = launch(ilo, ihi))) return rc;
+      if ((rc = exchange_finish())) return rc;
+      first_pending = false;
+      if (gs && (rc = launch(lo, ilo))) return rc;
+      if (gn && (rc = launch(ihi, hi))) return rc;
+    } else if (ovl) {
       // the next launch needs fresh ghost rows: advance the rows the neighbours need first, post the exchange of the NEW state, and
       // let the interior rows run while the messages are in flight (the edge launches reach to the inner end of what is sent)
       const int ilo = gs ? (int)(fo + hs) : lo, ihi = gn ? (int)(fo + ro - hs) : hi;
