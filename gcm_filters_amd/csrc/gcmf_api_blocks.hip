@@ -313,6 +313,18 @@ int gcmf_slab_apply_backward(gcmf_plan *pl, gcmf_comm *comm, gcmf_p2p *p2p, int 
     return GCMF_ERR_INVALID_ARG;
   }
   hipStream_t s = (hipStream_t)stream;
+  {   // an on-chip launch of this plan's PREVIOUS application timed out (its result is NaN): told once, here (as gcmf_apply does)
+    std::lock_guard<std::mutex> lk(pl->mu);
+    if (pl->res_lo) {
+      const unsigned rlo = pl->res_lo, rhi = pl->res_hi;
+      pl->res_lo = pl->res_hi = 0;
+      if (resident_take_failure(pl->d.device, rlo, rhi)) {
+        set_error("k_resident: the previous on-chip application of this slab plan timed out waiting for a neighbour tile and its result is NaN; "
+                  "the strip-marching launches are used from now on");
+        return GCMF_ERR_HIP;
+      }
+    }
+  }
   const int64_t fo = pl->first_owned, ro = pl->rows_owned, ra = pl->rows_alloc;
   const bool gs = fo > 0, gn = ra - fo - ro > 0;
   const int hs = multi ? halo : 0;
@@ -379,6 +391,9 @@ int gcmf_slab_apply_backward(gcmf_plan *pl, gcmf_comm *comm, gcmf_p2p *p2p, int 
         {
           std::lock_guard<std::mutex> lk(pl->mu);
           GCMF_HIP(hipSetDevice(pl->d.device));
+          const unsigned serial = resident_next_serial(pl->d.device);   // (whose launch it is, should it time out: gcmf_resident.hip)
+          if (!pl->res_lo) pl->res_lo = serial;
+          pl->res_hi = serial;
           if ((rc = launch_resident(pl, m, pk.data(), L, s))) return rc;
         }
         u = fr[0]; v = fr[1];
