@@ -158,6 +158,49 @@ def run_midsize(dev):
             "n_steps": n, "value": shape[0] * shape[1] * n / t, "unit": "cell-steps/s", "us_per_application": 1e6 * t, "dtype": "f64"}
 
 
+def run_single_launch(dev, args):
+    """The north star's literal form on the headline workload: BASELINE config 3 with the whole n_steps polynomial in ONE persistent launch
+    (csrc/gcmf_ringc_one.hip; opt-in: plan option "single_launch" / GCMF_SINGLE_LAUNCH=1) next to the default (seven back-to-back
+    launches of nine levels), same process, alternating; same bits required."""
+    import torch
+
+    from gcm_filters_amd import Filter, FilterShape, GridType, _lib, testing as T
+    from gcm_filters_amd.kernels import ALL_KERNELS
+
+    wl = T.baseline_workload(3, (args.ny, args.nx))
+    fk = wl["fk"]
+    flt = Filter(grid_type=GridType[wl["grid"]], grid_vars=wl["grid_vars"], filter_scale=fk["filter_scale"], dx_min=fk["dx_min"],
+                 filter_shape=FilterShape[fk["filter_shape"]])
+    cls = ALL_KERNELS[GridType[wl["grid"]]]
+    plan = cls(*[wl["grid_vars"][k] for k in cls.required_grid_args()])._plan(_lib.F64, (args.ny, args.nx), dev.index)
+    d = torch.from_numpy(wl["fields"][0]).to(dev)
+    res, outs, kern = {0: [], 1: []}, {}, {}
+    try:
+        for rnd in range(3):
+            for opt in (0, 1):
+                plan.set_option("single_launch", opt)
+                for _ in range(5):
+                    flt.apply(d)
+                torch.cuda.synchronize()
+                plan.last_kernel()
+                t0 = time.perf_counter()
+                for _ in range(40):
+                    outs[opt] = flt.apply(d)
+                torch.cuda.synchronize()
+                res[opt].append((time.perf_counter() - t0) / 40)
+                kern[opt] = plan.last_kernel()
+    finally:
+        plan.set_option("single_launch", 0)
+    n = int(flt.n_steps)
+    cells = args.ny * args.nx
+    t0, t1 = sorted(res[0])[1], sorted(res[1])[1]
+    return {"config": f"extra: BASELINE config 3 with the whole polynomial in ONE persistent launch (opt-in; n_steps={n})",
+            "n_steps": n, "value": cells * n / t1, "unit": "cell-steps/s", "us_per_application": 1e6 * t1, "kernel": kern[1],
+            "launches_per_application": 1, "dtype": "f64",
+            "back_to_back_launches": {"value": cells * n / t0, "us_per_application": 1e6 * t0, "kernel": kern[0]},
+            "same_bits": bool(torch.equal(outs[0].nan_to_num(), outs[1].nan_to_num()))}
+
+
 def build_summary(out):
     """The whole round in <= 1.5 KB, printed LAST in the line (the driver's record keeps the tail): per workload
     [G cell-steps/s, roofline frac (algorithmic bytes of one launch / launch time / 8 TB/s), counter traffic / algorithmic bytes, parity
@@ -182,6 +225,8 @@ def build_summary(out):
             key = "onchip_512"
         elif "1080x1440" in name:
             key = "mid_1080x1440"
+        elif "ONE persistent launch" in name:
+            key = "cfg3_one_launch"
         else:
             key = name[:24]
         s[key] = row(rec)
@@ -366,6 +411,11 @@ def main_single(args):
             extras.append(rec)
         extras.append(small)
         extras.append(run_midsize(dev))
+        if args.config == 3 and (args.ny, args.nx) == (2400, 3600):
+            one = run_single_launch(dev, args)
+            if not one["same_bits"] or "k_ringc_one" not in one["kernel"]:
+                failed.append(f"single launch: same bits {one['same_bits']}, kernel {one['kernel']}")
+            extras.append(one)
         out["extra_configs"] = extras
         if args.config == 3 and (args.ny, args.nx) == (2400, 3600):
             r = None

@@ -350,6 +350,7 @@ int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int 
   if (const char *e = getenv("GCMF_CLENSHAW")) pl->clenshaw = atoi(e);
   if (const char *e = getenv("GCMF_RINGC9")) pl->ringc9 = atoi(e);
   if (const char *e = getenv("GCMF_PACK_BATCH")) pl->pack_batch = atoi(e);
+  if (const char *e = getenv("GCMF_SINGLE_LAUNCH")) pl->single_launch = atoi(e);
   if (const char *e = getenv("GCMF_CLENSHAW_F32")) pl->clenshaw_f32 = atoi(e);
   PLAN_HIP(hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking));
   PLAN_HIP(hipEventCreate(&pl->ev0));
@@ -515,9 +516,9 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
       const unsigned lo = pl->res_lo, hi = pl->res_hi;
       pl->res_lo = pl->res_hi = 0;
       if (resident_take_failure(pl->d.device, lo, hi)) {
-        set_error("k_resident: the previous on-chip application of this plan timed out waiting for a neighbour tile and its result is NaN "
-                  "(another process running resident kernels on this GPU outside the lock file's reach?); the strip-marching launches are "
-                  "used from now on");
+        set_error("the previous on-chip / single-launch application of this plan (k_resident, k_ringc_one) timed out waiting for another "
+                  "workgroup and its result is NaN (another process running persistent kernels on this GPU outside the lock file's reach?); "
+                  "the back-to-back strip-marching launches are used from now on");
         return GCMF_ERR_HIP;
       }
     }
@@ -556,6 +557,20 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
         u = fr[0]; v = fr[1];
         done += L;
       }
+      if (pl->n_land > 0) {
+        if ((rc = ensure_dev_p(pl, p, n_steps, s))) return rc;
+        if ((rc = launch_land_fix(pl, din[0], dout[0], pl->dev_p, n_steps, c, fb32 ? 1 : 0, nbatch, s))) return rc;
+      }
+    } else if (n_clen > 0 && !(flags & GCMF_NO_RESIDENT) && ringc_one_depth(pl, n_steps, nbatch) > 0 &&
+               [&]() -> bool {   // OPT-IN ("single_launch"): the whole polynomial in ONE persistent launch (gcmf_ringc_one.hip); taken when
+                 //               the process may run persistent kernels now, else the back-to-back launches below (same bits)
+                 void *pool[4] = {A[0], B[0], Cb[0], Db[0]};
+                 if (dom_begin(pl, s)) return false;
+                 const int r1 = launch_ringc_one(pl, ringc_one_depth(pl, n_steps, nbatch), p, n_steps, c, din[0], dout[0], pool, s);
+                 if (dom_end(pl, s)) return false;
+                 if (r1 == GCMF_OK) ++launches;
+                 return r1 == GCMF_OK;
+               }()) {
       if (pl->n_land > 0) {
         if ((rc = ensure_dev_p(pl, p, n_steps, s))) return rc;
         if ((rc = launch_land_fix(pl, din[0], dout[0], pl->dev_p, n_steps, c, fb32 ? 1 : 0, nbatch, s))) return rc;

@@ -131,6 +131,7 @@ int gcmf_set_option(gcmf_plan *pl, const char *name, int value) {
   else if (n == "cgrid_ring_hmax") pl->cgrid_ring_hmax = value;
   else if (n == "cgrid_ring_ncarry") pl->cgrid_ring_ncarry = value;
   else if (n == "pack_batch") pl->pack_batch = value;
+  else if (n == "single_launch") pl->single_launch = value;
   else if (n == "ringc9") pl->ringc9 = value;
   else if (n == "clenshaw_f32") pl->clenshaw_f32 = value;
   else if (n == "ring_flux_f32") pl->ring_flux_f32 = value;

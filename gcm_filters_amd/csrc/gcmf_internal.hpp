@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -172,6 +173,7 @@ struct gcmf_plan {
   int ring = 1;           // env GCMF_RING=0: deep launches stay with k_flux_multi2 / k_scalar_multi
   unsigned *ring_nfb = nullptr;    // device counter behind gcmf_ring_fallbacks (lives behind zero_row)
   const void *zero_row = nullptr;  // nx zeros: what rows beyond a closed boundary read as coefficients / mask bits (k_ring)
+  int single_launch = 0;  // whole f64 flux grids: the whole polynomial in ONE persistent launch (k_ringc_one; measured slower); gcmf_set_option / GCMF_SINGLE_LAUNCH
   int pack_batch = 1;     // k_ringc / k_ringcs: the fields of a batch as one column per window (ringc_walk, round 6); gcmf_set_option "pack_batch"
   int ringc9 = 1;         // whole f64 flux-form grids without a tripole seam: up to NINE levels per k_ringc launch (env GCMF_RINGC9, gcmf_set_option "ringc9")
   int clenshaw = 2;       // backward (Clenshaw) evaluation: 0 off, 1 the flux kinds + C-grid, 2 (default since round 4) every kind that has a
@@ -258,6 +260,12 @@ void resident_free(gcmf_plan *pl);
 bool resident_take_failure(int dev, unsigned lo, unsigned hi);   // did one of the resident launches with serials [lo, hi] time out?  (reported once)
 unsigned resident_next_serial(int dev);
 void resident_status(int dev, int *state, unsigned long long *failures);
+// another persistent kernel of this process (k_ringc_one): under the on-chip lock, chained behind the process's other persistent launches;
+// launch(flags, fail word (device address of mapped host memory), serial, first value of the arrival counter flags[1001]); nbar = arrivals it adds
+int resident_persistent_launch(int dev, hipStream_t s, unsigned nbar, const std::function<int(unsigned *, unsigned *, unsigned, unsigned)> &launch);
+// the whole polynomial of a whole f64 flux grid in ONE launch (gcmf_ringc_one.hip; opt-in): levels per pass (0: not this application)
+int ringc_one_depth(const gcmf_plan *pl, int n_steps, int64_t nbatch);
+int launch_ringc_one(gcmf_plan *pl, int S, const double *p, int n_steps, double c, const void *f, void *out, void *const *pool, hipStream_t s);
 int launch_cgrid_stream(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 bool cgrid_stream_supported(const gcmf_plan *pl, const StepArgs &a);
 int launch_bgrid_stream(gcmf_plan *pl, const StepArgs &a, hipStream_t s);

@@ -577,6 +577,7 @@ struct ResArena {
   unsigned *fail_host = nullptr, *fail_dev = nullptr;
   unsigned epoch = 0;
   unsigned serial = 0;
+  unsigned bar_count = 0;          // arrivals the persistent strip-marching launches (k_ringc_one) have added to flags[1001] so far
   hipEvent_t chain_ev = nullptr;   // end of the last resident launch of this process on the device
   bool chain_set = false;
   // Two PROCESSES must not run resident kernels on one GPU at the same time (each would hold CUs the other's missing workgroups wait
@@ -886,6 +887,39 @@ void resident_status(int dev, int *state, unsigned long long *failures) {
 
 bool resident_fits(const gcmf_plan *pl, int row_lo, int row_hi, int L) { return res_supported(pl, row_lo, row_hi, L, nullptr, nullptr, nullptr, nullptr); }
 
+// (g_chain_mu held)  the chain event, the flag words and the failure word of a device's arena
+static int res_arena_ready(ResArena *st) {
+  if (!st->chain_ev) GCMF_HIP(hipEventCreateWithFlags(&st->chain_ev, hipEventDisableTiming));
+  if (!st->flags) {
+    GCMF_HIP(hipExtMallocWithFlags((void **)&st->flags, 1024 * sizeof(unsigned), hipDeviceMallocUncached));
+    GCMF_HIP(hipMemset(st->flags, 0, 1024 * sizeof(unsigned)));
+    GCMF_HIP(hipHostMalloc((void **)&st->fail_host, 64, hipHostMallocMapped));
+    *st->fail_host = 0u;
+    GCMF_HIP(hipHostGetDevicePointer((void **)&st->fail_dev, st->fail_host, 0));
+  }
+  return GCMF_OK;
+}
+
+int resident_persistent_launch(int dev, hipStream_t s, unsigned nbar, const std::function<int(unsigned *, unsigned *, unsigned, unsigned)> &launch) {
+  std::lock_guard<std::mutex> chain(g_chain_mu);
+  if (!res_process_allowed(dev)) {
+    set_error("persistent launch: another process runs persistent kernels on this GPU (or an earlier one of this process timed out)");
+    return GCMF_ERR_UNSUPPORTED;
+  }
+  ResArena *st = &g_arena[dev];
+  { const int rc_ = res_arena_ready(st); if (rc_) return rc_; }
+  if (st->chain_set) GCMF_HIP(hipStreamWaitEvent(s, st->chain_ev, 0));
+  struct Mark {
+    hipEvent_t e; hipStream_t s; bool *set;
+    ~Mark() { if (hipEventRecord(e, s) == hipSuccess) *set = true; }
+  } mark{st->chain_ev, s, &st->chain_set};
+  st->last_use = std::chrono::steady_clock::now();
+  if (++st->serial == 0) st->serial = 1;
+  const unsigned bar0 = st->bar_count;
+  st->bar_count += nbar;
+  return launch(st->flags, st->fail_dev, st->serial, bar0);
+}
+
 // L levels (a.S is ignored: pk = the L coefficients) of the backward evaluation on rows [a.row_lo, a.row_hi), one launch.
 // The plan's mutex is held and its device is current.
 int launch_resident(gcmf_plan *pl, const MultiArgs &a, const double *pk, int L, hipStream_t s) {
@@ -910,14 +944,7 @@ int launch_resident(gcmf_plan *pl, const MultiArgs &a, const double *pk, int L, 
   }
   ResArena *st = &g_arena[dev];
   const size_t plane = (size_t)pl->g.rows * pl->g.nx * sizeof(double);
-  if (!st->chain_ev) GCMF_HIP(hipEventCreateWithFlags(&st->chain_ev, hipEventDisableTiming));
-  if (!st->flags) {
-    GCMF_HIP(hipExtMallocWithFlags((void **)&st->flags, 1024 * sizeof(unsigned), hipDeviceMallocUncached));
-    GCMF_HIP(hipMemset(st->flags, 0, 1024 * sizeof(unsigned)));
-    GCMF_HIP(hipHostMalloc((void **)&st->fail_host, 64, hipHostMallocMapped));
-    *st->fail_host = 0u;
-    GCMF_HIP(hipHostGetDevicePointer((void **)&st->fail_dev, st->fail_host, 0));
-  }
+  { const int rc_ = res_arena_ready(st); if (rc_) return rc_; }
   if (st->ex_bytes < 4 * plane) {
     // grow: a new, larger block; the old one stays where it is (an earlier launch may still be using it, and uncached memory is never
     // handed back -- see ResArena)

@@ -397,7 +397,10 @@ int gcmf_set_tuning(gcmf_plan *plan, int rows_per_wave, int xcd_remap, int multi
 /* Named per-plan switches (A/B testing, the parity tests): "cgrid_ring" 1 / 0 (the static-ring C-grid kernel of batched f32 levels,
  * gcmf_cgrid_ring.hip; 0 = k_cgrid_stream2c everywhere), "cgrid_ring_smax" 4 / 5 / 6 (levels per launch), "cgrid_ring_ncarry" 0 / 1 (1 = round 5's form: only
  * the last level keeps its previous row's scaled copies in registers; same bits), "cgrid_ring_hmax" (tallest strip, 0 = 96 rows), "ringc9" 1 / 0 (nine levels per k_ringc launch on whole f64 flux grids), "pack_batch" 1 / 0 (batches on short
- * grids: the fields as one column of rows per window, k_ringcp; same bits), "clenshaw_f32" 0 / 1 (GCMF_BACKWARD_F32
+ * grids: the fields as one column of rows per window, k_ringcp; same bits), "single_launch" 0 / 1 (whole f64 flux-form grids of ANY size
+ * whose n_steps is a multiple of 9 or 8: the whole polynomial in ONE persistent launch, csrc/gcmf_ringc_one.hip -- the passes over HBM
+ * separated by grid-wide barriers instead of launch boundaries; same bits, measured 7 % slower at 2400 x 3600, hence opt-in; also env
+ * GCMF_SINGLE_LAUNCH=1), "clenshaw_f32" 0 / 1 (GCMF_BACKWARD_F32
  * for every call of this plan, the slab drivers and gcmf_clenshaw_cut included), "ring_flux_f32" 1 / 0 (the forward ring kernel of the f32
  * flux kinds, gcmf_ring_flux_f32.hip; 0 = k_flux_multi2, same bits).  Unknown names: GCMF_ERR_INVALID_ARG. */
 int gcmf_set_option(gcmf_plan *plan, const char *name, int value);

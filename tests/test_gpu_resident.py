@@ -320,3 +320,78 @@ def test_a_process_with_a_cu_mask_stays_off_the_resident_kernel(tmp_path):
     (o,) = _run_two_workers(tmp_path, 1.0, {"HSA_CU_MASK": "0:0-255"}, nproc=1)
     assert o["n"] > 5 and o["wrong"] == 0 and o["nan_results"] == 0 and o["errors"] == [], o
     assert o["kernels"] and all(k.startswith("gcmf::k_ringc") or k.startswith("gcmf::k_land_fix") for k in o["kernels"]), o
+
+
+# ---- k_ringc_one (csrc/gcmf_ringc_one.hip): the whole polynomial of a BASELINE-size grid in ONE persistent launch (opt-in) ----------------
+@pytest.mark.parametrize("shape,n_steps", [((128, 256), 18), ((300, 520), 27), ((260, 1100), 16), ((700, 1100), 63), ((2400, 3600), 63), ((2400, 3600), 56)])
+def test_single_launch_gives_the_bits_of_the_back_to_back_launches(shape, n_steps, monkeypatch):
+    """The north star's literal form, "the whole n_steps polynomial fused into a single launch", for whole f64 flux-form grids that do NOT
+    fit the chip: the same strip marches, the passes separated by grid-wide barriers inside one persistent launch instead of by launch
+    boundaries.  Opt-in (plan option "single_launch" / GCMF_SINGLE_LAUNCH=1: it measures 7 % slower at 2400 x 3600); bit-identical."""
+    import warnings
+    monkeypatch.setenv("GCMF_RESIDENT", "0")          # (not the on-chip tile kernel: this is about grids of any size)
+    f, gv = T.scalar_case("IRREGULAR_WITH_LAND", shape)
+    f = np.where(gv["wet_mask"] == 0, np.nan, f)
+    dx = T.grid_dx_min("IRREGULAR_WITH_LAND", gv)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        flt = Filter(filter_scale=6 * dx, dx_min=dx, n_steps=n_steps, filter_shape=FilterShape.TAPER, grid_type=GridType.IRREGULAR_WITH_LAND, grid_vars=gv)
+    plan = ALL_KERNELS[GridType.IRREGULAR_WITH_LAND](**gv)._plan(_lib.F64, shape)
+    try:
+        plan.set_option("single_launch", 0)
+        plan.last_kernel()
+        want = flt.apply(f)
+        assert "k_ringc" in plan.last_kernel()          # (k_ringc, or its early-exit form k_ringcs on short strips)
+        plan.set_option("single_launch", 1)
+        got = flt.apply(f)
+        assert "k_ringc_one<" in plan.last_kernel(), plan.last_kernel()
+        plan.set_timing(True)
+        flt.apply(f)
+        assert plan.last_timing()[1] == 1               # ONE recurrence launch (k_land_fix, the isolated cells, is not counted)
+    finally:
+        plan.set_timing(False)
+        plan.set_option("single_launch", 0)
+    assert np.array_equal(got, want, equal_nan=True)
+    assert _lib.resident_status(0)["failures"] == 0
+
+
+def test_single_launch_times_out_loudly(tmp_path):
+    """A workgroup that never arrives at a barrier (debug switch): every wait is bounded, the result of that application is NaN
+    everywhere, the NEXT call of the plan says so once, and the process goes on with the back-to-back launches."""
+    import json
+    import subprocess
+    import sys
+    code = r"""
+import json, os, sys, warnings
+sys.path.insert(0, %r)
+import numpy as np
+from gcm_filters_amd import Filter, FilterShape, GridType, _lib, testing as T
+from gcm_filters_amd.kernels import ALL_KERNELS
+shape = (300, 520)
+f, gv = T.scalar_case("IRREGULAR_WITH_LAND", shape)
+dx = T.grid_dx_min("IRREGULAR_WITH_LAND", gv)
+warnings.simplefilter("ignore")
+flt = Filter(filter_scale=6 * dx, dx_min=dx, n_steps=27, filter_shape=FilterShape.TAPER, grid_type=GridType.IRREGULAR_WITH_LAND, grid_vars=gv)
+plan = ALL_KERNELS[GridType.IRREGULAR_WITH_LAND](**gv)._plan(_lib.F64, shape)
+want = flt.apply(f)
+plan.set_option("single_launch", 2)
+import torch
+d = torch.from_numpy(f).cuda()
+bad = flt.apply(d).cpu().numpy()          # device pointers: the call returns before the kernel has given up
+errors = []
+for _ in range(3):
+    try:
+        plan.last_kernel()
+        again = flt.apply(d).cpu().numpy()
+    except Exception as e:
+        errors.append(str(e)[:120])
+wet = gv["wet_mask"] == 1                  # (land cells get their own polynomial from k_land_fix afterwards)
+print(json.dumps({"all_nan": bool(np.isnan(bad[wet]).all()), "errors": errors, "recovered": bool(np.array_equal(again, want)),
+                  "kernel": plan.last_kernel(), "status": _lib.resident_status(0)}))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GCMF_RESIDENT="0", GCMF_RESIDENT_TIMEOUT_MS="50", GCMF_RESIDENT_LOCK_DIR=str(tmp_path))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    o = json.loads(out.stdout.strip().splitlines()[-1])
+    assert o["all_nan"] and len(o["errors"]) == 1 and "timed out" in o["errors"][0], o
+    assert o["recovered"] and o["kernel"].startswith("gcmf::k_ringc<") and o["status"] == {"state": "disabled", "failures": 1}, o
