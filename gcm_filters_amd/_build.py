@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "libgcmf.so")
-SOURCES = ["gcmf_api.hip", "gcmf_api_blocks.hip", "gcmf_api_options.hip", "gcmf_precompute.hip", "gcmf_scalar.hip", "gcmf_scalar_multi.hip", "gcmf_scalar_multi_reg.hip", "gcmf_scalar_multi_mask.hip", "gcmf_scalar_multi_maskz.hip", "gcmf_scalar_multi_flux.hip", "gcmf_flux_multi2.hip", "gcmf_vector.hip", "gcmf_cgrid_stream.hip", "gcmf_cgrid_stream2.hip", "gcmf_cgrid_ring.hip", "gcmf_cgrid_ringf.hip", "gcmf_bgrid_stream.hip", "gcmf_bgrid_stream2.hip", "gcmf_landfix.hip", "gcmf_exchange.hip", "gcmf_ring_flux.hip", "gcmf_ring_flux_f32.hip", "gcmf_ring_maskz.hip", "gcmf_ring_reg.hip", "gcmf_ringc_flux.hip", "gcmf_ringc_flux9.hip", "gcmf_ringc_one.hip", "gcmf_ringc_maskz.hip", "gcmf_ringc_reg.hip", "gcmf_foldband.hip", "gcmf_p2p.hip", "gcmf_ringc_flux_slab.hip", "gcmf_ringc_flux_slab_f32.hip", "gcmf_resident.hip"]
+SOURCES = ["gcmf_api.hip", "gcmf_api_blocks.hip", "gcmf_api_options.hip", "gcmf_precompute.hip", "gcmf_scalar.hip", "gcmf_scalar_multi.hip", "gcmf_scalar_multi_reg.hip", "gcmf_scalar_multi_mask.hip", "gcmf_scalar_multi_maskz.hip", "gcmf_scalar_multi_flux.hip", "gcmf_flux_multi2.hip", "gcmf_vector.hip", "gcmf_cgrid_stream.hip", "gcmf_cgrid_stream2.hip", "gcmf_cgrid_ring.hip", "gcmf_cgrid_ringf.hip", "gcmf_bgrid_stream.hip", "gcmf_bgrid_stream2.hip", "gcmf_landfix.hip", "gcmf_exchange.hip", "gcmf_ring_flux.hip", "gcmf_ring_flux_f32.hip", "gcmf_ring_maskz.hip", "gcmf_ring_reg.hip", "gcmf_ringc_flux.hip", "gcmf_ringc_flux_f32.hip", "gcmf_ringc_flux9.hip", "gcmf_ringc_one.hip", "gcmf_ringc_maskz.hip", "gcmf_ringc_maskz_f32.hip", "gcmf_ringc_reg.hip", "gcmf_ringc_reg_f32.hip", "gcmf_foldband.hip", "gcmf_p2p.hip", "gcmf_ringc_flux_slab.hip", "gcmf_ringc_flux_slab_b.hip", "gcmf_ringc_flux_slab_f32.hip", "gcmf_ringc_flux_slab_f32b.hip", "gcmf_resident.hip"]
 BUILD_ID_SOURCE = "gcmf_buildid.hip"   # compiled on every link with -DGCMF_BUILD_ID=<source_build_id()>
 HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(INCLUDE, "gcmf.h")]
 # -ffp-contract=off: no FMA contraction, so the REGULAR / land-mask / B-grid kernels reproduce the
@@ -94,22 +94,33 @@ def _build_library_locked(force: bool, verbose: bool) -> str:
     if not force and os.path.exists(LIB) and binary_build_id() != want_id and not any(
             _stale(os.path.join(CSRC, s.replace(".hip", ".o")), [os.path.join(CSRC, s)] + HEADERS) for s in SOURCES):
         force = True    # the objects look fresh by mtime but the binary was made from other sources: trust the hash
+    todo = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
-            cmd = [hipcc(), *FLAGS, "-c", s, "-o", o]
-            if verbose:
-                print(" ".join(cmd), file=sys.stderr)
-            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+            todo.append((src, [hipcc(), *FLAGS, "-c", s, "-o", o]))
+    # longest first, one compiler per core: the static-ring units (dozens of 400-register kernels each) take two to three minutes of one
+    # core, the others seconds -- started all at once they share the cores with everything else until the end
+    heavy = ("gcmf_ringc", "gcmf_ring_", "gcmf_cgrid_ring", "gcmf_resident", "gcmf_scalar_multi", "gcmf_bgrid_stream2", "gcmf_cgrid_stream2")
+    todo.sort(key=lambda t: (0 if t[0].startswith(heavy) else 1, t[0]))
+    from concurrent.futures import ThreadPoolExecutor
+
+    def compile_one(job):
+        src, cmd = job
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        return src, r.returncode, r.stdout
+    procs = todo
     failed = []
-    for src, p in procs:
-        out, _ = p.communicate()
-        if p.returncode != 0:
-            failed.append(f"--- {src} ---\n{out}")
-        elif verbose and out.strip():
-            print(out, file=sys.stderr)
+    with ThreadPoolExecutor(max_workers=max(2, os.cpu_count() or 2)) as pool:
+        for src, rc, out in pool.map(compile_one, todo):
+            if rc != 0:
+                failed.append(f"--- {src} ---\n{out}")
+            elif verbose and out.strip():
+                print(out, file=sys.stderr)
     if failed:
         raise RuntimeError("hipcc failed:\n" + "\n".join(failed))
     if force or procs or _stale(LIB, objs) or binary_build_id() != want_id:

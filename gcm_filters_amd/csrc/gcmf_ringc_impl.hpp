@@ -579,21 +579,24 @@ static int launch_ringc_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   return GCMF_OK;
 }
 
-template <int KIND> static int launch_ringc_kind(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
-  if (pl->d.dtype != GCMF_F64) {
-    // f32 state, four cells per lane, the whole polynomial carried in f32 (f64 result unless GCMF_OUT_F32): the flux kinds since round 3,
-    // the REGULAR / land-mask kinds since round 4
-    switch (a.S) {
-      case 5: return a.first ? launch_ringc_sf<float, KIND, 5, true>(pl, a, s) : launch_ringc_sf<float, KIND, 5, false>(pl, a, s);
-      case 6: return a.first ? launch_ringc_sf<float, KIND, 6, true>(pl, a, s) : launch_ringc_sf<float, KIND, 6, false>(pl, a, s);
-      case 7: return a.first ? launch_ringc_sf<float, KIND, 7, true>(pl, a, s) : launch_ringc_sf<float, KIND, 7, false>(pl, a, s);
-      case 8:   // (never a first launch: clenshaw_cut starts an f32 filter with at most seven levels -- eight spill there)
-        if (a.first) break;
-        return launch_ringc_sf<float, KIND, 8, false>(pl, a, s);
-    }
-    set_error("k_ringc<float>: depth %d%s is not offered", a.S, a.first ? " as a first launch" : "");
-    return GCMF_ERR_INVALID_ARG;
+// one stencil kind, one state type (their own translation units: gcmf_ringc_<kind>.hip = f64, gcmf_ringc_<kind>_f32.hip = f32 -- the
+// instantiations of a kind compile for four to five minutes in one unit)
+template <int KIND> static int launch_ringc_kind_f32(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
+  // f32 state, four cells per lane, the whole polynomial carried in f32 (f64 result unless GCMF_OUT_F32): the flux kinds since round 3,
+  // the REGULAR / land-mask kinds since round 4
+  switch (a.S) {
+    case 5: return a.first ? launch_ringc_sf<float, KIND, 5, true>(pl, a, s) : launch_ringc_sf<float, KIND, 5, false>(pl, a, s);
+    case 6: return a.first ? launch_ringc_sf<float, KIND, 6, true>(pl, a, s) : launch_ringc_sf<float, KIND, 6, false>(pl, a, s);
+    case 7: return a.first ? launch_ringc_sf<float, KIND, 7, true>(pl, a, s) : launch_ringc_sf<float, KIND, 7, false>(pl, a, s);
+    case 8:   // (never a first launch: clenshaw_cut starts an f32 filter with at most seven levels -- eight spill there)
+      if (a.first) break;
+      return launch_ringc_sf<float, KIND, 8, false>(pl, a, s);
   }
+  set_error("k_ringc<float>: depth %d%s is not offered", a.S, a.first ? " as a first launch" : "");
+  return GCMF_ERR_INVALID_ARG;
+}
+
+template <int KIND> static int launch_ringc_kind_f64(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   switch (a.S) {
     case 5: return a.first ? launch_ringc_sf<double, KIND, 5, true>(pl, a, s) : launch_ringc_sf<double, KIND, 5, false>(pl, a, s);
     case 6: return a.first ? launch_ringc_sf<double, KIND, 6, true>(pl, a, s) : launch_ringc_sf<double, KIND, 6, false>(pl, a, s);
