@@ -532,8 +532,7 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
     pl->last_path = path;
     ++pl->path_count[path];
     if (resident) {
-      pl->res_lo = resident_next_serial(pl->d.device);
-      pl->res_hi = pl->res_lo;
+      pl->res_lo = pl->res_hi = 0;   // (launch_resident notes the serial numbers of this application's launches)
       void *pool[4] = {A[0], B[0], Cb[0], Db[0]};
       const void *u = nullptr, *v = nullptr;
       double pkk[64];
@@ -550,7 +549,6 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
         for (int t = 0; t < L; ++t) pkk[t] = p[n_steps - (done + 1 + t)];
         m.p0 = p[n_steps]; m.c = c; m.nbatch = 1; m.row_lo = 0; m.row_hi = rows;
         if ((rc = dom_begin(pl, s))) return rc;
-        pl->res_hi = resident_next_serial(pl->d.device);   // (other plans of the process may have launched in between: a range, not a count)
         if ((rc = launch_resident(pl, m, pkk, L, s))) return rc;
         if ((rc = dom_end(pl, s))) return rc;
         ++launches;

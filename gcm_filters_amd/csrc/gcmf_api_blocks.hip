@@ -391,9 +391,6 @@ int gcmf_slab_apply_backward(gcmf_plan *pl, gcmf_comm *comm, gcmf_p2p *p2p, int 
         {
           std::lock_guard<std::mutex> lk(pl->mu);
           GCMF_HIP(hipSetDevice(pl->d.device));
-          const unsigned serial = resident_next_serial(pl->d.device);   // (whose launch it is, should it time out: gcmf_resident.hip)
-          if (!pl->res_lo) pl->res_lo = serial;
-          pl->res_hi = serial;
           if ((rc = launch_resident(pl, m, pk.data(), L, s))) return rc;
         }
         u = fr[0]; v = fr[1];

@@ -258,7 +258,6 @@ bool resident_fits(const gcmf_plan *pl, int row_lo, int row_hi, int L);
 int launch_resident(gcmf_plan *pl, const MultiArgs &a, const double *pk, int L, hipStream_t s);
 void resident_free(gcmf_plan *pl);
 bool resident_take_failure(int dev, unsigned lo, unsigned hi);   // did one of the resident launches with serials [lo, hi] time out?  (reported once)
-unsigned resident_next_serial(int dev);
 void resident_status(int dev, int *state, unsigned long long *failures);
 // another persistent kernel of this process (k_ringc_one): under the on-chip lock, chained behind the process's other persistent launches;
 // launch(flags, fail word (device address of mapped host memory), serial, first value of the arrival counter flags[1001]); nbar = arrivals it adds

@@ -863,13 +863,6 @@ bool resident_take_failure(int dev, unsigned lo, unsigned hi) {
   return true;
 }
 
-// serial number the NEXT resident launch on `dev` will carry (the plan brackets its launches with it)
-unsigned resident_next_serial(int dev) {
-  std::lock_guard<std::mutex> chain(g_chain_mu);
-  const unsigned s = g_arena[dev].serial + 1;
-  return s ? s : 1;
-}
-
 void resident_status(int dev, int *state, unsigned long long *failures) {
   std::lock_guard<std::mutex> chain(g_chain_mu);
   auto it = g_arena.find(dev);
@@ -975,6 +968,8 @@ int launch_resident(gcmf_plan *pl, const MultiArgs &a, const double *pk, int L, 
   st->last_use = std::chrono::steady_clock::now();
   if (++st->serial == 0) st->serial = 1;
   P.serial = st->serial;
+  if (!pl->res_lo) pl->res_lo = st->serial;   // (the plan's mutex is held: the launches of ITS application, should one of them time out)
+  pl->res_hi = st->serial;
   P.epoch0 = st->epoch;
   P.nx = gm.nx; P.rows = gm.rows;
   P.r_lo = r_lo; P.r_hi = r_hi; P.out_lo = a.row_lo; P.out_hi = a.row_hi;
