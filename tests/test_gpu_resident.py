@@ -274,6 +274,29 @@ def test_an_idle_process_gives_the_lock_back(tmp_path):
         assert o["wrong"] == 0 and o["nan_results"] == 0 and o["errors"] == [] and o["lock_warnings"] == [], outs
 
 
+def test_the_lock_file_is_not_followed_through_a_symlink(tmp_path):
+    """the lock file's name is predictable and its directory shared, so somebody may have put a symbolic link there
+    that points at a file of the victim's.  libgcmf opens it O_NOFOLLOW and sets a mode only on a file it created itself: the target keeps
+    its mode and its content, and the process still filters (it falls back to the next directory, or to no lock at all)."""
+    import glob
+    import stat
+    victim = tmp_path / "victim.txt"
+    victim.write_text("precious")
+    os.chmod(victim, 0o600)
+    lockdir = tmp_path / "locks"
+    lockdir.mkdir()
+    # the name depends on the PCI bus id: let one run create it, then replace it by a link and run again
+    (o,) = _run_two_workers(lockdir, 0.3, {}, nproc=1)
+    names = glob.glob(str(lockdir / "gcmf_resident_*.lock"))
+    assert len(names) == 1 and o["errors"] == [], (names, o)
+    os.remove(names[0])
+    os.symlink(victim, names[0])
+    (o,) = _run_two_workers(lockdir, 0.3, {}, nproc=1)
+    assert o["n"] > 0 and o["wrong"] == 0 and o["errors"] == [], o
+    assert stat.S_IMODE(os.stat(victim).st_mode) == 0o600 and victim.read_text() == "precious"
+    assert os.path.islink(names[0])                                       # (left alone)
+
+
 def test_last_path_and_counters(monkeypatch):
     """Filter.last_path / Plan.path_counts (include/gcmf.h: gcmf_plan_last_path): which of the two bit-identical paths ran."""
     shape = (256, 256)
