@@ -197,3 +197,32 @@ def test_forward_ring_against_the_oracle():
     for g, w in zip(got, (wu, wv)):
         assert np.array_equal(np.isnan(g), np.isnan(w))
         assert np.nanmax(np.abs(g - w)) <= 1e-5 * np.nanmax(np.abs(w))
+
+
+def test_unaligned_device_views_take_the_general_kernel():
+    """the caller's planes come straight from GCMF_DEVICE_PTRS; k_cgrid_ring / k_cgrid_ringf need them on 16-byte boundaries
+    (LDS-direct loads, 16-byte stores).  A contiguous view that starts 4 bytes into a buffer runs k_cgrid_stream2[c] instead -- at most
+    five levels per launch -- and gives the same bits."""
+    import torch
+    shape, nlev = (96, 160), 8
+    flt, plan, u, v, gv = _case(shape, nlev, 23)
+    n = u.size
+    bu, bv = torch.zeros(n + 4, dtype=torch.float32, device="cuda"), torch.zeros(n + 4, dtype=torch.float32, device="cuda")
+    du, dv = bu[1: 1 + n].view(u.shape), bv[1: 1 + n].view(v.shape)
+    du.copy_(torch.from_numpy(u));  dv.copy_(torch.from_numpy(v))
+    assert du.data_ptr() % 16 == 4 and du.is_contiguous()
+    au, av = torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda()
+    # (backward: every launch re-reads the caller's input; forward: only the first launch reads it -- that one takes k_cgrid_stream2, the
+    # later ones work on the plan's own aligned planes and stay on k_cgrid_ringf)
+    for ev, ring, general in (("auto", "k_cgrid_ring<", "k_cgrid_stream2c<"), ("reference", "k_cgrid_ringf<", "k_cgrid_ringf<")):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            f2 = Filter(filter_scale=flt.filter_scale, dx_min=flt.dx_min, n_steps=23, grid_type=GridType.VECTOR_C_GRID, grid_vars=gv, evaluation=ev)
+        plan.last_kernel()
+        want = f2.apply_to_vector(au, av)
+        assert ring in plan.last_kernel(), plan.last_kernel()
+        plan.last_kernel()
+        got = f2.apply_to_vector(du, dv)
+        assert general in plan.last_kernel(), plan.last_kernel()
+        for w, g in zip(want, got):
+            assert torch.equal(w, g)
