@@ -246,9 +246,11 @@ def run_single(cfg, args, dev, steps, warmup, scale=0.0, levels=None, tuned=Fals
     # ... and one untimed burst as long as a timed block, enqueued the same way (no synchronisation in between): the FIRST such burst of
     # a process stalls once for 30-60 ms inside the runtime (seen as one timed block 2-5 x slow on tripolar plans, whose launches fork /
     # join two queues; it never comes back) -- a one-off of the process, not a rate
-    for _ in range(max(1, min(40, -(-steps // max(1, min(5, steps)))))):
-        outs = run()
-    torch.cuda.synchronize()
+    for _ in range(3):   # (round 6: THREE such bursts -- the stall belongs to the n-th hundred launches of the process, not to the first burst:
+        #                   with one burst it landed in the second or third timed block of every full run, 47-80 ms instead of 18)
+        for _ in range(max(1, min(40, -(-steps // max(1, min(5, steps)))))):
+            outs = run()
+        torch.cuda.synchronize()
     plan.last_kernel()  # reset
     torch.cuda.synchronize()
     # The timed region: EXACTLY K applications, enqueued back to back with no host synchronisation between the applications of a
