@@ -95,3 +95,20 @@ def test_single_gpu_line_carries_parity_and_roofline():
     assert line["value_min"] <= line["value"] <= line["value_max"]
     assert line["timing"]["blocks"] == 2 and line["timing"]["plans_refolded_between_blocks"] == 1
     assert line["cpu_baseline"]["cores"] == 1
+    # round 6: the line ENDS with a compact summary (the driver's record keeps the tail): [G cell-steps/s, frac, traffic / algorithmic, parity]
+    assert list(line)[-1] == "summary" and len(json.dumps(line["summary"])) <= 1500
+    row = line["summary"]["cfg3"]
+    assert abs(row[0] - line["value"] / 1e9) < 0.06 and abs(row[1] - rf["frac"]) < 1e-3 and row[3] <= 1e-6
+
+
+def test_kinds_line_has_a_roofline_per_kind():
+    """`bench.py --kinds` (tools/bench_kinds.py): one record per Laplacian kind that is not a BASELINE config, each with
+    the dominant kernel, its launch time, `frac` and parity against the oracle (here on a small grid and two kinds, to keep it short)."""
+    r = _run(["--kinds", "--kinds-only", "mom5u,regular_area", "--ny", "240", "--nx", "360"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _json_line(r.stdout)
+    assert [k["kind"] for k in line["kinds"]] == ["mom5u", "regular_area"] and list(line)[-1] == "summary"
+    for k in line["kinds"]:
+        rf = k["roofline"]
+        assert k["value"] > 0 and rf["kernel"].startswith("gcmf::k_") and 0 < rf["frac"] < 1 and rf["launches_of_it_per_application"] >= 1
+        assert k["parity"]["rel_err"] <= 1e-12 and k["parity"]["nan_pattern_equal"] is True
