@@ -103,15 +103,22 @@ static int launch_ringc(gcmf_plan *pl, const MultiArgs &m, hipStream_t s) {
       // and every SIMD has a wave (330 -> 364 G cell-steps/s, tools/measure_midsize.py); an 8-way slab 28 instead of 36; BASELINE-size
       // f64 grids 96 either way (-> k_ringc), BASELINE-size f32 grids 52 instead of 60 (+4 %), 1080 x 1440 f32 24 either way (-> k_ringc,
       // the early-exit form measured 9 % slower there).
-      if (!pl->g.fold && m.S <= 8) {
+      if (!pl->g.fold) {
         const bool f64 = pl->d.dtype == GCMF_F64;
-        const int wi = f64 ? 112 : 240;   // useful columns of a window (f32: four cells per lane)
-        const long long nrows = m.row_hi - m.row_lo;
-        const long long nwx = (pl->g.nx + wi - 1) / wi, want = strips_per_column(nwx * std::max<long long>(1, m.nbatch), nrows, m.S, 12);
+        const int wi = f64 ? (m.S == 9 ? 108 : 112) : 240;   // useful columns of a window (f32: four cells per lane)
+        const long long nrows = m.row_hi - m.row_lo, per = ((pl->g.nx + wi - 1) / wi) * std::max<long long>(1, m.nbatch);
+        const long long want = strips_per_column(per, nrows, m.S, 12);
         const long long H0 = std::min(nrows, std::max(4LL, pl->strip_rows > 0 ? (long long)pl->strip_rows : (nrows + want - 1) / want));
         const long long need = H0 + 2 * m.S;
         const long long rows_xe = std::max(12LL, (need + 3) / 4 * 4), rows_pad = (need + 11) / 12 * 12;
-        if (H0 < pl->ringc_xe_rows && rows_xe * 100 <= rows_pad * (f64 ? 95 : 90)) return launch_ringc_flux_slab(pl, m, s);
+        const bool xe = m.S <= 8 && H0 < pl->ringc_xe_rows && rows_xe * 100 <= rows_pad * (f64 ? 95 : 90);
+        // Round 6: strips zipped in pairs at a shared seam (k_ringcz) march H + S + 1 rows instead of H + 2 S: where strips are as short as
+        // their ghost zones (1/4-degree grids: 15 rows behind 2 x 9; the 300-row slab of one of eight ranks: 11 behind 2 x 8)
+        const long long rounds = (per * ((nrows + H0 - 1) / H0) + 1023) / 1024;
+        const int mz = ringc_zip_march(pl, m, nullptr);
+        if (mz > 0 && H0 < pl->ringc_xe_rows && (long long)mz * 100 <= rounds * (xe ? rows_xe : rows_pad) * 90 && !(m.nbatch > 1 && pl->pack_batch))
+          return launch_ringc_zip(pl, m, s);
+        if (xe) return launch_ringc_flux_slab(pl, m, s);
       }
       if (m.S == 9) return launch_ringc_flux9(pl, m, s);
       return launch_ringc_flux(pl, m, s);
@@ -349,6 +356,7 @@ int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int 
   if (const char *e = getenv("GCMF_RINGC_XE_ROWS")) pl->ringc_xe_rows = atoi(e);
   if (const char *e = getenv("GCMF_CLENSHAW")) pl->clenshaw = atoi(e);
   if (const char *e = getenv("GCMF_RINGC9")) pl->ringc9 = atoi(e);
+  if (const char *e = getenv("GCMF_RINGC_ZIP")) pl->ringc_zip = atoi(e);
   if (const char *e = getenv("GCMF_PACK_BATCH")) pl->pack_batch = atoi(e);
   if (const char *e = getenv("GCMF_SINGLE_LAUNCH")) pl->single_launch = atoi(e);
   if (const char *e = getenv("GCMF_CLENSHAW_F32")) pl->clenshaw_f32 = atoi(e);

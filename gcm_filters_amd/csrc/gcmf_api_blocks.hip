@@ -40,7 +40,14 @@ int clenshaw_cut(const gcmf_plan *pl, int n_steps, int *depths, int max_depths, 
   if (!pl->ring || !pl->zero_row || pl->multi_s < 8 || !multi_supported(pl, 8)) return 0;
   if (pl->n_land > 0 && !land_ok(pl, n_steps)) return 0;
   if (!(n_steps >= 10 || (n_steps >= 5 && n_steps <= 8) || (n_steps == 9 && ringc9_ok(pl)))) return 0;
-  if (ringc9_ok(pl) && (n_steps + 8) / 9 < (n_steps + 7) / 8) {
+  if (pl->ringc_smax >= 5 && pl->ringc_smax <= 7) {   // tuning: at most ringc_smax levels per launch, as even as possible
+    const int L = (n_steps + pl->ringc_smax - 1) / pl->ringc_smax, q = n_steps / L, r = n_steps % L;
+    if (q >= 5 && L <= max_depths) {
+      for (int k = 0; k < L; ++k) depths[k] = q + (k < r ? 1 : 0);
+      return L;
+    }
+  }
+  if (ringc9_ok(pl) && pl->ringc_smax != 8 && (n_steps + 8) / 9 < (n_steps + 7) / 8) {
     // one launch fewer with up to nine levels each: as even as possible (63 = 7 x 9, 65 = 9 + 7 x 8), the nines first
     const int L = (n_steps + 8) / 9, q = n_steps / L, r = n_steps % L;
     if (L > max_depths) return 0;

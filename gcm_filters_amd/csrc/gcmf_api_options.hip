@@ -133,6 +133,8 @@ int gcmf_set_option(gcmf_plan *pl, const char *name, int value) {
   else if (n == "pack_batch") pl->pack_batch = value;
   else if (n == "single_launch") pl->single_launch = value;
   else if (n == "ringc9") pl->ringc9 = value;
+  else if (n == "ringc_zip") pl->ringc_zip = value;
+  else if (n == "ringc_smax") pl->ringc_smax = value;
   else if (n == "clenshaw_f32") pl->clenshaw_f32 = value;
   else if (n == "ring_flux_f32") pl->ring_flux_f32 = value;
   else {

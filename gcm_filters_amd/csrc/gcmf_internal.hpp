@@ -175,6 +175,8 @@ struct gcmf_plan {
   const void *zero_row = nullptr;  // nx zeros: what rows beyond a closed boundary read as coefficients / mask bits (k_ring)
   int single_launch = 0;  // whole f64 flux grids: the whole polynomial in ONE persistent launch (k_ringc_one; measured slower); gcmf_set_option / GCMF_SINGLE_LAUNCH
   int pack_batch = 1;     // k_ringc / k_ringcs: the fields of a batch as one column per window (ringc_walk, round 6); gcmf_set_option "pack_batch"
+  int ringc_zip = 1;      // f64 flux plans without a tripole seam: k_ringcz where it marches fewer rows (env GCMF_RINGC_ZIP, gcmf_set_option "ringc_zip")
+  int ringc_smax = 0;     // backward scalar launches: at most this many levels each (5..8; 0 = the default cut: nine where offered, else eight); gcmf_set_option "ringc_smax"
   int ringc9 = 1;         // whole f64 flux-form grids without a tripole seam: up to NINE levels per k_ringc launch (env GCMF_RINGC9, gcmf_set_option "ringc9")
   int clenshaw = 2;       // backward (Clenshaw) evaluation: 0 off, 1 the flux kinds + C-grid, 2 (default since round 4) every kind that has a
                           // backward kernel (f64 REGULAR / land-mask kinds, B-grid too); env GCMF_CLENSHAW.  Per call: GCMF_FORWARD_RECURRENCE
@@ -249,6 +251,8 @@ int launch_ringc_maskz(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_ringc_flux(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_ringc_flux9(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);   // nine levels: whole f64 flux grids without a seam (gcmf_ringc_flux9.hip)
 int launch_ringc_flux_slab(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
+int launch_ringc_zip(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);   // f64 flux plans without a tripole seam, short strips: pairs of strips zipped at a shared seam (k_ringcz, gcmf_ringc_zip.hip)
+int ringc_zip_march(const gcmf_plan *pl, const MultiArgs &a, int *pairs);  // rows a k_ringcz launch would march (all rounds), 0 = not offered
 int launch_ringc_flux_slab_f32(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);   // flux plans without a tripole seam, short strips: early exits (k_ringcs)
 int launch_flux_multi2(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 // the on-chip kernel (gcmf_resident.hip): L <= 64 levels of the backward evaluation in ONE launch on a field that fits the register

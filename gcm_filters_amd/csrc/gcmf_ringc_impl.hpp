@@ -39,9 +39,17 @@ template <int VEC> __device__ __forceinline__ unsigned cell_bytes(const uint8_t 
 // XE: early exits also for the flux kinds (k_ringcs: slabs that do not own a tripole seam, see below)
 // XE6: ONE early exit, in the middle of the ring period (whole f64 flux grids at nine levels, round 6: a strip marches a multiple of six
 // rows instead of twelve)
-// (wx: the wave's window; [a, b): the rows it owns; boff: its field's offset in the planes; odd: odd strips of the flux kinds march upwards)
-template <typename T, int KIND, int S, bool FIRST, bool SANI, bool XE = false, bool XE6 = false>
-__device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wx, const int a, const int b, const long long boff, const bool odd) {
+// ZIP: two strips of one window that share a boundary ("seam") march AWAY from it, side by side in one workgroup (k_ringcz, round 6): neither
+// warms its levels up over S ghost rows on that side -- at its first row every level takes the flux across the seam from the row the partner
+// has just produced (one row per level through LDS, a workgroup barrier per level: S - 1 of them in the first ring period), so a strip
+// marches H + S + 1 rows instead of H + 2 S and all its levels start within S + 1 phases.  Same operands, same operations: same bits.
+// (wx: the wave's window; [a, b): the rows it owns; boff: its field's offset in the planes; odd: odd strips of the flux kinds march upwards;
+// zmine / zpart: ZIP -- this wave's and its partner's S - 1 rows of LDS)
+template <bool ZIP> constexpr bool ringc_ramp_on(int t, int ph) { return ZIP ? (t == 1 ? ph >= 1 : ph >= t + 1) : ph >= 2 * t - 1; }
+
+template <typename T, int KIND, int S, bool FIRST, bool SANI, bool XE = false, bool XE6 = false, bool ZIP = false>
+__device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wx, const int a, const int b, const long long boff, const bool odd,
+                                            T *zmine = nullptr, const T *zpart = nullptr) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int W = 64 * VEC;
   constexpr int M = (S + VEC - 1) / VEC * VEC;
@@ -49,6 +57,7 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wx,
   constexpr int R = RingGeom::R, D = RingGeom::D, RU = RingGeom::RU, RV = RingGeom::RV;
   static_assert(R >= S + D && R % 3 == 0 && R % RU == 0 && R % RV == 0 && RU >= 3 + D && RV >= 1 + D, "ring periods");
   constexpr bool FLUX = (KIND == K_FLUX), MASK = (KIND == K_MASKZ);
+  static_assert(!ZIP || FLUX, "the seam exchange is the flux kinds' (a carried face flux per level)");
   constexpr bool WATCH = (KIND != K_REG) && !SANI;  // K_REG has no nan_to_num in the reference: NaN spreads by plain arithmetic
   constexpr bool FUSED = true;   // nothing here is bit-identical with numpy anyway: every multiply-add pair is one fma
 
@@ -74,6 +83,9 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wx,
   T V[RV][VEC];      // rows of b_{k+2}
   unsigned Zu[RU];   // FIRST: land bits of the rows of f that become b_n (slots of G0)
   T ARu[RU][VEC];    // FIRST, area-weighted types: their area
+  T cNs[VEC];        // ZIP: the seam face's coefficient
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) cNs[k] = T(0);
 #pragma unroll
   for (int t = 0; t < S; ++t) {
 #pragma unroll
@@ -99,7 +111,7 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wx,
   }
 
   const bool wrap = P.wrap;
-  const int r_begin = a - S, r_last = b + S - 1;
+  const int r_begin = ZIP ? a - 1 : a - S, r_last = b + S - 1;   // (ZIP: march row a - 1 is the partner's first row)
   // Odd strips of the flux kinds march UPWARDS (P.zigzag): the march below runs in "march order" m = r_begin - 1, r_begin, ... and
   // visits the grid row  mir - m  instead of m  (mir = a + b - 1 maps the strip and its ghost rows onto themselves).  Two strips that
   // share a boundary then reach it at the same time -- both at the start or both at the end of their marches -- so that the 2 S rows
@@ -107,7 +119,7 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wx,
   // marches read them a whole march apart).  The arithmetic is the same instruction stream: "north" in march order is the grid's
   // south, the row of cN that travels with a centre row j is that of row j - 1, the carried flux is minus the grid's north flux, and
   // (fe - fw) + (fn - fs) is bit-for-bit symmetric under that exchange.
-  const bool up = FLUX && P.zigzag && odd;
+  const bool up = FLUX && (ZIP || P.zigzag) && odd;
   const int mir = a + b - 1;
   int cj, cj_prev;
   bool cout_, cout_prev;
@@ -286,15 +298,34 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wx,
     // row a - (S - t) on -- phase 2 t.  One phase earlier the level has to run for the flux it carries to its next row (its value there
     // is never used); before that it would compute rows nobody reads.  S^2 of the (H + 2 S) S level-rows of a strip: 8 % at 80 rows, a
     // quarter of the instruction stream of a 12-row strip (8-way slabs, 1/4-degree grids).
-    if constexpr (!PRO || ph >= 1) level(ic<1>{}, ph_c);
-    if constexpr (S >= 2 && (!PRO || ph >= 3)) level(ic<2>{}, ph_c);
-    if constexpr (S >= 3 && (!PRO || ph >= 5)) level(ic<3>{}, ph_c);
-    if constexpr (S >= 4 && (!PRO || ph >= 7)) level(ic<4>{}, ph_c);
-    if constexpr (S >= 5 && (!PRO || ph >= 9)) level(ic<5>{}, ph_c);
-    if constexpr (S >= 6 && (!PRO || ph >= 11)) level(ic<6>{}, ph_c);
-    if constexpr (S >= 7 && !PRO) level(ic<7>{}, ph_c);
-    if constexpr (S >= 8 && !PRO) level(ic<8>{}, ph_c);
-    if constexpr (S >= 9 && !PRO) level(ic<9>{}, ph_c);
+    // ZIP: the strip starts AT the seam (q = 0 at march row a - 1, the partner's first row): level 1 runs from phase 1 (for the seam face's
+    // flux, out of its own two rows), level t >= 2 from phase t + 1 -- its first row, with the seam face's flux from the exchange below.
+    if constexpr (ZIP && PRO && ph == 1) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) cNs[k] = cN[1][k];   // (the coefficient row of march row a - 1: its face towards row a)
+    }
+    if constexpr (!PRO || ringc_ramp_on<ZIP>(1, ph)) level(ic<1>{}, ph_c);
+    if constexpr (S >= 2 && (!PRO || ringc_ramp_on<ZIP>(2, ph))) level(ic<2>{}, ph_c);
+    if constexpr (S >= 3 && (!PRO || ringc_ramp_on<ZIP>(3, ph))) level(ic<3>{}, ph_c);
+    if constexpr (S >= 4 && (!PRO || ringc_ramp_on<ZIP>(4, ph))) level(ic<4>{}, ph_c);
+    if constexpr (S >= 5 && (!PRO || ringc_ramp_on<ZIP>(5, ph))) level(ic<5>{}, ph_c);
+    if constexpr (S >= 6 && (!PRO || ringc_ramp_on<ZIP>(6, ph))) level(ic<6>{}, ph_c);
+    if constexpr (S >= 7 && (!PRO || ringc_ramp_on<ZIP>(7, ph))) level(ic<7>{}, ph_c);
+    if constexpr (S >= 8 && (!PRO || ringc_ramp_on<ZIP>(8, ph))) level(ic<8>{}, ph_c);
+    if constexpr (S >= 9 && (!PRO || ringc_ramp_on<ZIP>(9, ph))) level(ic<9>{}, ph_c);
+    if constexpr (ZIP && PRO && ph >= 2 && ph <= S) {
+      // level ph - 1 has just produced the strip's first row (slot 1 of its ring): the partner's level ph needs it for the flux across the
+      // seam, this wave's level ph needs the partner's -- what the march row before the first one would have left in FN[ph]
+      constexpr int t = ph - 1;
+      T own[VEC], oth[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) own[k] = G[t < S ? t : 1][1][k];
+      mstore<T, VEC>(zmine + (t - 1) * W + lane * VEC, own);
+      __syncthreads();
+      mload<T, VEC>(oth, zpart + (t - 1) * W + lane * VEC);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) FN[t + 1][k] = ((SANI ? msan(own[k]) : own[k]) - (SANI ? msan(oth[k]) : oth[k])) * cNs[k];
+    }
     const int ju = up ? mir - (r - S) : r - S;
     if (ju >= a && ju < b) {  // wave-uniform
       const long long off = boff + (long long)ju * nx;
@@ -339,6 +370,10 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wx,
   // The flux kinds march whole periods: every early exit costs this kernel dozens of registers (146 -> 204 AGPRs with an exit
   // every four rows), and on tripolar plans k_fold_band's waves have to fit on the SIMDs NEXT to these (gcmf_foldband.hip).
   constexpr bool EARLY = (KIND != K_FLUX) || XE;
+  // k_ringcz: an exit every second row.  Nine levels: 52 bytes of scratch that way; a second form with its exits after rows 2, 6, 10 instead of
+  // 4, 8, 12 (for strips whose march is 4 k + 2 rows) fits (506 registers) but runs 7 % longer per row -- 1080 x 1440: 26 rows in 34.4 us
+  // against 28 rows in 32.5 us -- and was dropped.
+  constexpr bool XE2 = ZIP && S <= 8;
   if constexpr (FLUX) {  // the first period, peeled: the ramp of the levels
     constexpr std::integral_constant<bool, true> pro{};
     phase(ic<0>{}, r_begin, pro);
@@ -362,17 +397,19 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wx,
     do {
       phase(ic<0>{}, r0, run);
       phase(ic<1>{}, r0 + 1, run);
+      if (XE2 && r0 + 1 >= r_last) break;
       phase(ic<2>{}, r0 + 2, run);
       phase(ic<3>{}, r0 + 3, run);
       if (EARLY && r0 + 3 >= r_last) break;     // (the last period is left after the strip's last row, see k_ring)
       phase(ic<4>{}, r0 + 4, run);
       phase(ic<5>{}, r0 + 5, run);
-      if (XE6 && r0 + 5 >= r_last) break;
+      if ((XE6 || XE2) && r0 + 5 >= r_last) break;
       phase(ic<6>{}, r0 + 6, run);
       phase(ic<7>{}, r0 + 7, run);
       if (EARLY && r0 + 7 >= r_last) break;
       phase(ic<8>{}, r0 + 8, run);
       phase(ic<9>{}, r0 + 9, run);
+      if (XE2 && r0 + 9 >= r_last) break;
       phase(ic<10>{}, r0 + 10, run);
       phase(ic<11>{}, r0 + 11, run);
       done = (r0 + 11 >= r_last);
@@ -450,6 +487,120 @@ __global__ __launch_bounds__(256, 1) void k_ringcs(const MultiP<T, T> P) {
   const int wid = bx * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wid >= P.nwaves) return;
   ringc_walk<T, K_FLUX, S, FIRST, true, false, false>(P, wid);
+}
+
+// k_ringcz: strips ZIPPED in pairs at a shared seam (ringc_march<ZIP>), early exits: mid-size whole grids and row slabs of the f64 flux kinds
+// without a tripole seam, where a strip is as short as its ghost zones.  The rows [out_lo, out_hi) of a window are cut into P.nstrips / 2
+// pairs of (almost) equal height; a pair is cut in the middle: the lower strip marches down the grid from the cut, the upper one up.  A
+// workgroup = the two pairs of two neighbouring windows (pair (2 bx + w / 2), member w % 2); a pair past the end idles through the barriers.
+// A non-finite value met by ANY wave of the workgroup sends all four through the nan_to_num march (they meet at its barriers).
+template <typename T, int S, bool FIRST>
+__global__ __launch_bounds__(256, 1) void k_ringcz(const MultiP<T, T> P) {
+  constexpr int VEC = 16 / sizeof(T), W = 64 * VEC;
+  __shared__ __attribute__((aligned(16))) T zl[4][(S - 1) * W];
+  int bx = blockIdx.x;
+  if (P.xcd_per > 0 && bx < 8 * P.xcd_per) bx = (bx & 7) * P.xcd_per + (bx >> 3);
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int np = P.nstrips >> 1, pid = bx * 2 + (w >> 1);
+  const bool active = pid < P.nwx * np;
+  const int wx = pid % P.nwx, pp = pid / P.nwx;
+  const long long nrows = P.out_hi - P.out_lo;
+  const int lo = P.out_lo + (int)((long long)pp * nrows / np), hi = P.out_lo + (int)((long long)(pp + 1) * nrows / np), mid = lo + (hi - lo) / 2;
+  const bool upper = (w & 1) != 0;
+  const int a = upper ? mid : lo, b = upper ? hi : mid;
+  const long long boff = (long long)blockIdx.y * P.bstride;
+  bool bad = false;
+  if (active) bad = ringc_march<T, K_FLUX, S, FIRST, false, true, false, true>(P, wx, a, b, boff, !upper, zl[w], zl[w ^ 1]);
+  else
+    for (int k = 0; k < S - 1; ++k) __syncthreads();
+  if (__syncthreads_or(bad ? 1 : 0)) {
+    if (active) {
+      if (P.nfb && (threadIdx.x & 63) == 0) atomicAdd(P.nfb, 1u);
+      ringc_march<T, K_FLUX, S, FIRST, true, true, false, true>(P, wx, a, b, boff, !upper, zl[w], zl[w ^ 1]);
+    } else {
+      for (int k = 0; k < S - 1; ++k) __syncthreads();
+    }
+  }
+}
+
+// pairs per window for k_ringcz: one resident round of waves (1024 slots), strips of at least two rows
+// rows a ZIP march of `need` rows runs: an exit every second row up to eight levels, every fourth at nine
+inline long long ringc_zip_rows(long long need, int S) {
+  const long long ex = S <= 8 ? 2 : 4;
+  return std::max(12LL, (need + ex - 1) / ex * ex);
+}
+inline int ringc_zip_pairs(long long nwx, long long nbatch, long long nrows, int S, int *march) {
+  long long best = 0, best_cost = 0;
+  for (int k = 1; k <= 8; ++k) {
+    long long np = (512LL * k) / std::max(1LL, nwx * nbatch);
+    np = std::min(np, nrows / 4);
+    if (np < 1) continue;
+    const long long H = (nrows + 2 * np - 1) / (2 * np);                 // the taller strips
+    const long long m = ringc_zip_rows(H + S + 1, S);
+    const long long rounds = (2 * np * nwx * nbatch + 1023) / 1024;
+    const long long cost = rounds * m * (100 + 4 * (rounds - 1));
+    if (!best || cost < best_cost) { best = np; best_cost = cost; if (march) *march = (int)(rounds * m); }
+    if (np >= nrows / 4) break;
+  }
+  return (int)best;
+}
+
+template <typename T, int S, bool FIRST>
+static int launch_ringc_zip_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
+  constexpr int VEC = 16 / sizeof(T), W = 64 * VEC, M = (S + VEC - 1) / VEC * VEC, WI = W - 2 * M;
+  const Geom &g = pl->g;
+  MultiP<T, T> P;
+  P.u0 = (const T *)a.u0;
+  P.v0 = (const T *)a.v0;
+  P.uo = (T *)a.uo;
+  P.vo = (T *)a.vo;
+  P.fb_in = (const T *)a.fb_in;
+  P.fb_out = (T *)a.fb_out;
+  P.d_out = nullptr;
+  if (sizeof(T) == 4 && !a.fb_is_f32) {
+    P.d_out = (double *)a.fb_out;
+    P.fb_out = nullptr;
+  }
+  P.cE = (const T *)g.coef[0];
+  P.cN = (const T *)g.coef[1];
+  P.ra = (const T *)g.coef[2];
+  P.zrow = (const T *)pl->zero_row;
+  P.nfb = pl->ring_nfb;
+  P.mbits = g.mbits;
+  P.lbits = (pl->n_land > 0) ? pl->lbits : nullptr;
+  P.area = (const T *)g.area;
+  P.nx = g.nx;
+  P.rows = g.rows;
+  P.out_lo = a.row_lo;
+  P.out_hi = a.row_hi;
+  const int nrows = a.row_hi - a.row_lo;
+  if (nrows <= 0 || a.nbatch <= 0) return GCMF_OK;
+  P.nwx = (g.nx + WI - 1) / WI;
+  const int np = ringc_zip_pairs(P.nwx, a.nbatch, nrows, S, nullptr);
+  if (np < 1) {
+    set_error("k_ringcz: %d rows cannot be cut into pairs of strips", nrows);
+    return GCMF_ERR_INVALID_ARG;
+  }
+  P.nstrips = 2 * np;
+  P.H = (nrows + 2 * np - 1) / (2 * np);
+  P.npack = 0;
+  P.nwaves = P.nwx * P.nstrips;
+  P.wrap = g.south_wrap && g.north_wrap;
+  P.first = FIRST ? 1 : 0;
+  P.last = a.last;
+  P.area_weighted = 0;
+  P.bstride = (long long)g.rows * g.nx;
+  for (int t = 0; t < MAX_PK; ++t) P.pk[t] = t < S ? a.pk[t] : 0.0;
+  P.p0 = a.p0;
+  P.c = a.c;
+  dim3 block(256), grid((P.nwx * np + 1) / 2, (unsigned)a.nbatch);
+  P.xcd_per = pl->xcd_remap ? (int)(grid.x / 8) : 0;
+  P.zigzag = 1;
+  hipLaunchKernelGGL((k_ringcz<T, S, FIRST>), grid, block, 0, s, P);
+  GCMF_HIP(hipGetLastError());
+  note_kernel(pl, std::string("gcmf::k_ringcz<") + tyname<T>() + ", " + std::to_string(S) + ", " + (FIRST ? "true" : "false") + ">", S,
+              launch_geom(P.H, P.nstrips, P.nwx, P.xcd_per > 0, grid.x, grid.y, nrows));
+  return GCMF_OK;
 }
 
 // k_ringc with the one mid-period exit (see ringc_march)

@@ -1,0 +1,21 @@
+// k_ringcz<double>: pairs of strips zipped at a shared seam (gcmf_ringc_impl.hpp), nine levels (both exit forms); seven and eight: gcmf_ringc_zip_b.hip, five and six: gcmf_ringc_zip_c.hip
+#include "gcmf_ringc_impl.hpp"
+
+namespace gcmf {
+int launch_ringc_zip_b(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
+int launch_ringc_zip(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
+  if (pl->d.dtype != GCMF_F64 || pl->kind != K_FLUX) return GCMF_ERR_INVALID_ARG;
+  switch (a.S) {
+    case 9: return a.first ? launch_ringc_zip_sf<double, 9, true>(pl, a, s) : launch_ringc_zip_sf<double, 9, false>(pl, a, s);
+  }
+  return launch_ringc_zip_b(pl, a, s);
+}
+int ringc_zip_march(const gcmf_plan *pl, const MultiArgs &a, int *pairs) {
+  if (!pl->ringc_zip || pl->d.dtype != GCMF_F64 || pl->kind != K_FLUX || pl->g.fold || pl->strip_rows > 0 || a.S < 5 || a.S > 9) return 0;
+  const int M = (a.S + 1) / 2 * 2, WI = 128 - 2 * M;
+  int march = 0;
+  const int np = ringc_zip_pairs((pl->g.nx + WI - 1) / WI, a.nbatch, a.row_hi - a.row_lo, a.S, &march);
+  if (pairs) *pairs = np;
+  return np >= 1 ? march : 0;
+}
+}  // namespace gcmf

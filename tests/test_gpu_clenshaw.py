@@ -66,7 +66,9 @@ def test_backward_evaluation_matches_the_reference_recurrence(grid, n_steps, kwa
     assert np.array_equal(np.isnan(got), np.isnan(want))
     assert np.nanmax(np.abs(got - want)) <= 1e-12 * np.nanmax(np.abs(want))
     if "nanwet" in kwargs and grid not in ("REGULAR", "REGULAR_AREA_WEIGHTED"):
-        assert 0 < nfb < 120     # the strips around the cells were redone inside the kernel (nan_to_num on the stencil operands): a few of the ~76 strips x 3 launches
+        # the strips around the cells were redone inside the kernel (nan_to_num on the stencil operands): a few of the ~76 strips x 3 launches
+        # (k_ringcz, round 6: 2-row strips in pairs, a whole workgroup of four redoes together -- 120 of 296 waves x 3 launches)
+        assert 0 < nfb < 200
     elif not (grid.startswith("MOM5") and kwargs.get("nanland")):   # MOM5: land cells with an open face keep their NaN in the state
         assert nfb == 0
 
@@ -100,7 +102,8 @@ def test_nine_levels_per_launch_give_the_same_bits(grid, n_steps, kwargs):
         assert 9 in cut9 and len(cut9) == -(-n_steps // 9), cut9
         plan.last_kernel()
         got9 = flt.apply(f)
-        assert "k_ringc<double, 2, 9" in plan.last_kernel(), plan.last_kernel()
+        kern9 = plan.last_kernel()
+        assert "k_ringc<double, 2, 9" in kern9 or "k_ringcz<double, 9" in kern9, kern9   # (short strips: zipped pairs, round 6)
         plan.set_option("ringc9", 0)
         cut8 = plan.clenshaw_cut(n_steps)
         assert 9 not in cut8

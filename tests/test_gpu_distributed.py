@@ -101,7 +101,7 @@ def _worker(rank, world, port, q, exchange="auto"):
                 assert not sf.backward_cut, name      # f32 scalar fields: the forward recurrence unless asked otherwise
             if sf.backward_cut:   # flux kinds: the slabs evaluate backwards like the one-GPU path (k_ringc; k_ringcs = its early-exit form for slabs)
                 kern = sf.engine.plan.last_kernel()
-                assert "k_ringc<" in kern or "k_ringcs<" in kern or "k_ringcp<" in kern, (grid, kern)   # (k_ringcp: packed batches, round 6)
+                assert any(k in kern for k in ("k_ringc<", "k_ringcs<", "k_ringcp<", "k_ringcz<")), (grid, kern)   # (k_ringcp: packed batches, k_ringcz: zipped pairs, round 6)
             if vec:   # the blocked vector kernels really ran on the slabs
                 assert sf.kernel_launches < sf.n_steps, (sf.kernel_launches, sf.n_steps)
             if rank == 0:

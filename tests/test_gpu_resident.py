@@ -417,4 +417,4 @@ print(json.dumps({"all_nan": bool(np.isnan(bad[wet]).all()), "errors": errors, "
     assert out.returncode == 0, out.stderr[-2000:]
     o = json.loads(out.stdout.strip().splitlines()[-1])
     assert o["all_nan"] and len(o["errors"]) == 1 and "timed out" in o["errors"][0], o
-    assert o["recovered"] and o["kernel"].startswith("gcmf::k_ringc<") and o["status"] == {"state": "disabled", "failures": 1}, o
+    assert o["recovered"] and o["kernel"].startswith("gcmf::k_ringc") and o["status"] == {"state": "disabled", "failures": 1}, o

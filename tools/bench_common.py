@@ -351,8 +351,8 @@ def roofline_of(cfg, r, steps, default_tuning):
     avg_ms = r["dom_ms"] / r["dom_n"]                       # HIP events around each launch of the dominant kernel
     # recurrence steps one launch of that kernel advances: its last (vector kernels: fourth) template argument
     targs = r["kernel"][r["kernel"].index("<") + 1: r["kernel"].rindex(">")].split(", ")
-    backward = any(k in r["kernel"] for k in ("k_ringc<", "k_ringcs<", "k_ringcp<", "k_cgrid_stream2c<", "k_cgrid_ring<"))
-    steps_per_launch = float(targs[1] if any(k in r["kernel"] for k in ("k_ringcs<", "k_cgrid_ring<", "k_cgrid_ringf<")) else   # (<T, S, ...>: the early-exit form of short strips, the static-ring C-grid kernel)
+    backward = any(k in r["kernel"] for k in ("k_ringc<", "k_ringcs<", "k_ringcp<", "k_ringcz<", "k_cgrid_stream2c<", "k_cgrid_ring<"))
+    steps_per_launch = float(targs[1] if any(k in r["kernel"] for k in ("k_ringcs<", "k_ringcz<", "k_cgrid_ring<", "k_cgrid_ringf<")) else   # (<T, S, ...>: the early-exit form of short strips, the static-ring C-grid kernel)
                              targs[2] if backward else
                              targs[3] if any(k in r["kernel"] for k in ("stream2", "k_scalar_multi", "k_ring")) else
                              (targs[-1] if "k_flux_multi2" in r["kernel"] else 1))

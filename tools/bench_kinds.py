@@ -88,7 +88,7 @@ def run_kind(name, grid, dt, nlev, shape_name, scale, n_par, dev, shape, no_cpu)
     tot_ms, launches = plan.last_timing()
     plan.set_timing(False)
     kern, geom = plan.last_kernel(), plan.last_kernel_geometry()
-    backward = any(k in kern for k in ("k_ringc<", "k_ringcs<", "k_ringcp<", "stream2c<", "k_cgrid_ring<", "k_resident<"))
+    backward = any(k in kern for k in ("k_ringc<", "k_ringcs<", "k_ringcp<", "k_ringcz<", "stream2c<", "k_cgrid_ring<", "k_resident<"))
     cells = shape[0] * shape[1] * nlev
     bpc = alg_bytes_per_cell_launch(grid, w, nlev, backward, 8)
     rec = {"kind": name, "grid": grid, "dtype": "f64" if w == 8 else "f32", "levels": nlev, "n_steps": n,

@@ -160,7 +160,7 @@ def main():
         names = demangle([k["name"] for k in kernels])
         for k, d in zip(kernels, names):
             k["dname"] = d.replace("void ", "").split("(")[0]
-        watched = [k for k in kernels if re.search(r"gcmf::k_(ring|ringc|ringcs|ringcp|ringc_one|fold_band|resident|cgrid_stream2c?|cgrid_ringf?|bgrid_stream2c?)<", k["dname"])]
+        watched = [k for k in kernels if re.search(r"gcmf::k_(ring|ringc|ringcs|ringcp|ringcz|ringc_one|fold_band|resident|cgrid_stream2c?|cgrid_ringf?|bgrid_stream2c?)<", k["dname"])]
         for k in sorted(watched, key=lambda k: k["dname"]):
             total = k["vgpr"]   # gfx90a and later: .vgpr_count is the unified total (architected + accumulation registers)
             alloc = (total + 7) // 8 * 8
@@ -176,12 +176,12 @@ def main():
                 failures.append(f"{k['dname']}: {alloc} registers > {BAND_BUDGET}: its waves no longer fit beside a k_ringc wave")
             if re.search(r"k_ringcp?<(double|float), 2,", k["dname"]) and not k["dname"].rstrip(">").endswith(", true") and alloc > RING_FLUX_BUDGET:   # (k_ringcp<..., XE = true>: slabs without a seam)
                 failures.append(f"{k['dname']}: {alloc} registers > {RING_FLUX_BUDGET}: no room for k_fold_band's waves on its SIMD (tripolar plans)")
-            if re.search(r"k_ringc?[sp]?<", k["dname"]) and alloc > 512:
+            if re.search(r"k_ringc?[spz]?<", k["dname"]) and alloc > 512:
                 failures.append(f"{k['dname']}: {alloc} registers > 512")
             # the on-chip kernel: 512 threads = two waves per SIMD, so 256 registers and not a byte of scratch (its cells LIVE in registers)
             if "k_resident<" in k["dname"] and alloc > 256:
                 failures.append(f"{k['dname']}: {alloc} registers > 256: a 512-thread workgroup no longer fits a CU")
-        n_ring = sum(1 for k in watched if re.search(r"k_ringc?[sp]?<", k["dname"]))
+        n_ring = sum(1 for k in watched if re.search(r"k_ringc?[spz]?<", k["dname"]))
         n_band = sum(1 for k in watched if "k_fold_band<" in k["dname"])
         n_res = sum(1 for k in watched if "k_resident<" in k["dname"])
         if n_res < 11:
