@@ -21,9 +21,9 @@ def timed(fn, reps=40):
     return best
 
 grid = "IRREGULAR_WITH_LAND"
-shapes = [(64, 200), (300, 3600), (720, 1440), (1080, 1440), (1440, 2880)]
+shapes = [(2400, 3600), (2000, 3600), (1440, 2880)]
 for shape in shapes:
-    for nan in (False, True):
+    for nan in (False,):
         f, gv = T.scalar_case(grid, shape)
         if nan:
             rng = np.random.default_rng(5)
@@ -32,21 +32,21 @@ for shape in shapes:
             f.reshape(-1)[idx] = np.nan
             f.reshape(-1)[rng.integers(0, f.size, 2)] = np.inf
         dx = T.grid_dx_min(grid, gv)
-        for scale in (16.0, 11.0):
+        for scale in (16.0,):
             flt = Filter(dx_min=dx, grid_type=GridType[grid], grid_vars=gv, filter_scale=scale * dx, filter_shape=FilterShape.TAPER)
             d = torch.from_numpy(f).cuda()
             plan = ALL_KERNELS[GridType[grid]](**gv)._plan(_lib.F64, shape)
             res = {}
-            for zip_ in (0, 1, 8, 7, 6):
-                plan.set_option("ringc_zip", 1 if zip_ else 0)
-                plan.set_option("ringc_smax", 0 if zip_ < 2 else zip_)
+            for zi, zip_ in enumerate(((0, 0), (2, 0), (3, 0), (1, 0), (0, 0), (1, 0))):
+                plan.set_option("ringc_zip", zip_[0])
+                plan.set_option("ringc_smax", zip_[1])
                 plan.last_kernel()
                 o = flt.apply(d)
                 torch.cuda.synchronize()
                 k = plan.last_kernel(); g = plan.last_kernel_geometry()
                 t = timed(lambda: flt.apply(d)) if not nan else 0.0
-                res[zip_] = (o.cpu().numpy(), k, g, t)
-            a, b = res[0][0], res[1][0]
+                res[(zi,) + zip_] = (o.cpu().numpy(), k, g, t)
+            a = res[(0, 0, 0)][0]
             same = all(np.array_equal(a, res[z][0], equal_nan=True) for z in res)
             print(f"{shape} n {flt.n_steps} nan {nan}: same bits {same}")
             if not nan:

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "libgcmf.so")
-SOURCES = ["gcmf_api.hip", "gcmf_api_blocks.hip", "gcmf_api_options.hip", "gcmf_precompute.hip", "gcmf_scalar.hip", "gcmf_scalar_multi.hip", "gcmf_scalar_multi_reg.hip", "gcmf_scalar_multi_mask.hip", "gcmf_scalar_multi_maskz.hip", "gcmf_scalar_multi_flux.hip", "gcmf_flux_multi2.hip", "gcmf_vector.hip", "gcmf_cgrid_stream.hip", "gcmf_cgrid_stream2.hip", "gcmf_cgrid_ring.hip", "gcmf_cgrid_ringf.hip", "gcmf_bgrid_stream.hip", "gcmf_bgrid_stream2.hip", "gcmf_landfix.hip", "gcmf_exchange.hip", "gcmf_ring_flux.hip", "gcmf_ring_flux_f32.hip", "gcmf_ring_maskz.hip", "gcmf_ring_reg.hip", "gcmf_ringc_flux.hip", "gcmf_ringc_flux_f32.hip", "gcmf_ringc_flux9.hip", "gcmf_ringc_one.hip", "gcmf_ringc_zip.hip", "gcmf_ringc_zip_b.hip", "gcmf_ringc_zip_c.hip", "gcmf_ringc_maskz.hip", "gcmf_ringc_maskz_f32.hip", "gcmf_ringc_reg.hip", "gcmf_ringc_reg_f32.hip", "gcmf_foldband.hip", "gcmf_p2p.hip", "gcmf_ringc_flux_slab.hip", "gcmf_ringc_flux_slab_b.hip", "gcmf_ringc_flux_slab_f32.hip", "gcmf_ringc_flux_slab_f32b.hip", "gcmf_resident.hip"]
+SOURCES = ["gcmf_api.hip", "gcmf_api_blocks.hip", "gcmf_api_options.hip", "gcmf_precompute.hip", "gcmf_scalar.hip", "gcmf_scalar_multi.hip", "gcmf_scalar_multi_reg.hip", "gcmf_scalar_multi_mask.hip", "gcmf_scalar_multi_maskz.hip", "gcmf_scalar_multi_flux.hip", "gcmf_flux_multi2.hip", "gcmf_vector.hip", "gcmf_cgrid_stream.hip", "gcmf_cgrid_stream2.hip", "gcmf_cgrid_ring.hip", "gcmf_cgrid_ringf.hip", "gcmf_bgrid_stream.hip", "gcmf_bgrid_stream2.hip", "gcmf_landfix.hip", "gcmf_exchange.hip", "gcmf_ring_flux.hip", "gcmf_ring_flux_f32.hip", "gcmf_ring_maskz.hip", "gcmf_ring_reg.hip", "gcmf_ringc_flux.hip", "gcmf_ringc_flux_f32.hip", "gcmf_ringc_flux9.hip", "gcmf_ringc_one.hip", "gcmf_ringc_zip.hip", "gcmf_ringc_zip_b.hip", "gcmf_ringc_zip_c.hip", "gcmf_ringc_zip_d.hip", "gcmf_ringc_maskz.hip", "gcmf_ringc_maskz_f32.hip", "gcmf_ringc_reg.hip", "gcmf_ringc_reg_f32.hip", "gcmf_foldband.hip", "gcmf_p2p.hip", "gcmf_ringc_flux_slab.hip", "gcmf_ringc_flux_slab_b.hip", "gcmf_ringc_flux_slab_f32.hip", "gcmf_ringc_flux_slab_f32b.hip", "gcmf_resident.hip"]
 BUILD_ID_SOURCE = "gcmf_buildid.hip"   # compiled on every link with -DGCMF_BUILD_ID=<source_build_id()>
 HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(INCLUDE, "gcmf.h")]
 # -ffp-contract=off: no FMA contraction, so the REGULAR / land-mask / B-grid kernels reproduce the

@@ -113,10 +113,12 @@ static int launch_ringc(gcmf_plan *pl, const MultiArgs &m, hipStream_t s) {
         const long long rows_xe = std::max(12LL, (need + 3) / 4 * 4), rows_pad = (need + 11) / 12 * 12;
         const bool xe = m.S <= 8 && H0 < pl->ringc_xe_rows && rows_xe * 100 <= rows_pad * (f64 ? 95 : 90);
         // Round 6: strips zipped in pairs at a shared seam (k_ringcz) march H + S + 1 rows instead of H + 2 S: where strips are as short as
-        // their ghost zones (1/4-degree grids: 15 rows behind 2 x 9; the 300-row slab of one of eight ranks: 11 behind 2 x 8)
+        // their ghost zones (1/4-degree grids: 15 rows behind 2 x 9; the 300-row slab of one of eight ranks: 11 behind 2 x 8) -- and, for
+        // less, at BASELINE size (2400 x 3600: 30 strips of 80 rows marching 92 instead of 27 of 90 marching 108: 890.5 against 906 us,
+        // same box, alternating; the launch is bound by HBM there)
         const long long rounds = (per * ((nrows + H0 - 1) / H0) + 1023) / 1024;
         const int mz = ringc_zip_march(pl, m, nullptr);
-        if (mz > 0 && H0 < pl->ringc_xe_rows && (long long)mz * 100 <= rounds * (xe ? rows_xe : rows_pad) * 90 && !(m.nbatch > 1 && pl->pack_batch))
+        if (mz > 0 && (long long)mz * 100 <= rounds * (xe ? rows_xe : rows_pad) * 90 && !(m.nbatch > 1 && pl->pack_batch))
           return launch_ringc_zip(pl, m, s);
         if (xe) return launch_ringc_flux_slab(pl, m, s);
       }
@@ -514,7 +516,7 @@ static int run_whole_locked(gcmf_plan *pl, const double *p, int n_steps, double 
     int depths[1024];
     const bool fwd_only = flags & GCMF_FORWARD_RECURRENCE;   // the caller wants the reference's forward recurrence / accumulation
     const bool back_f32 = pl->clenshaw_f32 || (flags & GCMF_BACKWARD_F32);   // f32 B-grid / scalar state backwards: only when asked for
-    const int n_clen = (use_multi && !fwd_only) ? clenshaw_cut(pl, n_steps, depths, 1024, back_f32) : 0;
+    const int n_clen = (use_multi && !fwd_only) ? clenshaw_cut(pl, n_steps, depths, 1024, back_f32, nbatch) : 0;
     // Small fields: the whole polynomial on the chip in ONE launch (64 levels at a time; gcmf_resident.hip) -- the field, both states
     // and the coefficients live in registers / LDS, nothing but the result goes back to memory.  Same bits as the launches below.
     bool resident = false;

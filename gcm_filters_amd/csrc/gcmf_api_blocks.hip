@@ -25,7 +25,7 @@ bool ringc9_ok(const gcmf_plan *pl) {
 // launches run at memcpy rate and gain the plane they no longer move (config 3: +10 %); 2: every scalar kind (the land-mask
 // kernel is bound by its instruction stream and gains nothing: 93 -> 92-95 us per launch).  Needs the isolated cells fixed up
 // by k_land_fix when there is land (land_ok).
-int clenshaw_cut(const gcmf_plan *pl, int n_steps, int *depths, int max_depths, bool f32_asked) {
+int clenshaw_cut(const gcmf_plan *pl, int n_steps, int *depths, int max_depths, bool f32_asked, int64_t nbatch) {
   if (!pl || pl->ncomp != 1 || !(pl->clenshaw >= 2 || (pl->clenshaw == 1 && pl->kind == K_FLUX))) return 0;
   // f32 state (round 5): only when asked for (plan option clenshaw_f32 / GCMF_BACKWARD_F32 per call).  Summed backwards in f32 the
   // polynomial is 15-45 x further from f64 arithmetic than the reference's own f32 path (f32 T_k, f64 running sum; measured:
@@ -40,14 +40,30 @@ int clenshaw_cut(const gcmf_plan *pl, int n_steps, int *depths, int max_depths, 
   if (!pl->ring || !pl->zero_row || pl->multi_s < 8 || !multi_supported(pl, 8)) return 0;
   if (pl->n_land > 0 && !land_ok(pl, n_steps)) return 0;
   if (!(n_steps >= 10 || (n_steps >= 5 && n_steps <= 8) || (n_steps == 9 && ringc9_ok(pl)))) return 0;
-  if (pl->ringc_smax >= 5 && pl->ringc_smax <= 7) {   // tuning: at most ringc_smax levels per launch, as even as possible
-    const int L = (n_steps + pl->ringc_smax - 1) / pl->ringc_smax, q = n_steps / L, r = n_steps % L;
+  int smax = pl->ringc_smax;
+  if (!smax && nbatch == 1 && ringc9_ok(pl) && pl->ringc_zip && (long long)pl->g.rows * pl->g.nx <= 2500000LL && n_steps >= 10) {
+    // Whole grids that live in the caches and run k_ringcz (1/4-degree grids): a launch is paced by the rows its strips march, not by the
+    // bytes it moves, so fewer launches are not always faster -- a strip marches H + S + 1 rows whose cost grows with S, and fewer
+    // levels mean narrower ghost columns (sometimes a window less).  Measured (experiments/scripts/zip_ab.py, us per launch):
+    // ~4 + rows x (0.6 + 0.045 S); 1080 x 1440 n 63: 7 x 9 levels 225, 8 launches of <= 8 215, 9 x 7 217; 720 x 1440: 158 / 170 / 169.
+    double best = 0.0;
+    for (int S = 9; S >= 7; --S) {
+      const int M = (S + 1) / 2 * 2, WI = 128 - 2 * M, L = (n_steps + S - 1) / S;
+      int march = 0;
+      if (ringc_zip_pairs((pl->g.nx + WI - 1) / WI, 1, pl->g.rows, S, &march) < 1) continue;
+      const double t = L * (4.0 + march * (0.6 + 0.045 * S));
+      if (best == 0.0 || t < 0.98 * best) { best = t; smax = S; }
+    }
+    if (smax == 9) smax = 0;
+  }
+  if (smax >= 5 && smax <= 7) {   // at most smax levels per launch, as even as possible
+    const int L = (n_steps + smax - 1) / smax, q = n_steps / L, r = n_steps % L;
     if (q >= 5 && L <= max_depths) {
       for (int k = 0; k < L; ++k) depths[k] = q + (k < r ? 1 : 0);
       return L;
     }
   }
-  if (ringc9_ok(pl) && pl->ringc_smax != 8 && (n_steps + 8) / 9 < (n_steps + 7) / 8) {
+  if (ringc9_ok(pl) && smax != 8 && (n_steps + 8) / 9 < (n_steps + 7) / 8) {
     // one launch fewer with up to nine levels each: as even as possible (63 = 7 x 9, 65 = 9 + 7 x 8), the nines first
     const int L = (n_steps + 8) / 9, q = n_steps / L, r = n_steps % L;
     if (L > max_depths) return 0;
@@ -147,7 +163,7 @@ int gcmf_cheb_multi(gcmf_plan *pl, const void *u, const void *v, void *uo, void 
     int probe[2];
     // (is the backward evaluation on offer for this plan at all: a 10-level polynomial can always be cut, [5, 5]; an f32 filter never
     // starts with eight levels, see clenshaw_cut)
-    if (pl->ncomp != 1 || S < 5 || S > (ringc9_ok(pl) ? 9 : 8) || !pl->ring || !pl->zero_row || clenshaw_cut(pl, 10, probe, 2) != 2 ||
+    if (pl->ncomp != 1 || S < 5 || S > (ringc9_ok(pl) ? 9 : 8) || !pl->ring || !pl->zero_row || clenshaw_cut(pl, 10, probe, 2, false, 2) != 2 ||
         (first && S == 8 && pl->d.dtype != GCMF_F64)) {
       set_error("gcmf_cheb_multi: the backward evaluation is not available for this plan / depth %d", S);
       return GCMF_ERR_UNSUPPORTED;

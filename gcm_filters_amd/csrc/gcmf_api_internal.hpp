@@ -16,7 +16,7 @@ int dom_collect(gcmf_plan *pl);
 // gcmf_api_blocks.hip
 bool land_ok(const gcmf_plan *pl, int n_steps);
 bool ringc9_ok(const gcmf_plan *pl);
-int clenshaw_cut(const gcmf_plan *pl, int n_steps, int *depths, int max_depths, bool f32_asked = false);
+int clenshaw_cut(const gcmf_plan *pl, int n_steps, int *depths, int max_depths, bool f32_asked = false, int64_t nbatch = 1);   // (nbatch: a lone field on a cache-resident grid may be cut into shallower launches)
 bool ptr_al16(const void *p);
 int vec_backward_next_depth(const gcmf_plan *pl, int64_t nbatch, int left, int smax);
 }  // namespace gcmf

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -237,6 +238,33 @@ inline long long strips_per_column(long long per_strip, long long nrows, int S, 
   }
   return best;
 }
+// k_ringcz (gcmf_ringc_impl.hpp): strips zipped in pairs
+// rows a ZIP march of `need` rows runs -- with early exits: one every second row up to eight levels, every fourth at nine; without: whole
+// ring periods (taken when it is no longer: 80 fewer registers, the same time per row -- 1080 x 1440 at eight levels, 24 rows either way:
+// 215.2 against 214.7 us)
+inline long long ringc_zip_rows(long long need, int S, bool *xe) {
+  const long long ex = S <= 8 ? 2 : 4;
+  const long long mx = std::max(12LL, (need + ex - 1) / ex * ex), mp = (need + 11) / 12 * 12;
+  if (xe) *xe = mx < mp;
+  return std::min(mx, mp);
+}
+// pairs per window: whole rounds of the 1024 wave slots, strips of at least two rows; *march = rows the launch marches (all rounds)
+inline int ringc_zip_pairs(long long nwx, long long nbatch, long long nrows, int S, int *march) {
+  long long best = 0, best_cost = 0;
+  for (int k = 1; k <= 8; ++k) {
+    long long np = (512LL * k) / std::max(1LL, nwx * nbatch);
+    np = std::min(np, nrows / 4);
+    if (np < 1) continue;
+    const long long H = (nrows + 2 * np - 1) / (2 * np);                 // the taller strips
+    const long long m = ringc_zip_rows(H + S + 1, S, nullptr);
+    const long long rounds = (2 * np * nwx * nbatch + 1023) / 1024;
+    const long long cost = rounds * m * (100 + 4 * (rounds - 1));
+    if (!best || cost < best_cost) { best = np; best_cost = cost; if (march) *march = (int)(rounds * m); }
+    if (np >= nrows / 4) break;
+  }
+  return (int)best;
+}
+
 // kernel launchers (defined in gcmf_scalar.hip / gcmf_vector.hip)
 int launch_scalar_step(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 int launch_vector_step(gcmf_plan *pl, const StepArgs &a, hipStream_t s);

@@ -373,7 +373,7 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wx,
   // k_ringcz: an exit every second row.  Nine levels: 52 bytes of scratch that way; a second form with its exits after rows 2, 6, 10 instead of
   // 4, 8, 12 (for strips whose march is 4 k + 2 rows) fits (506 registers) but runs 7 % longer per row -- 1080 x 1440: 26 rows in 34.4 us
   // against 28 rows in 32.5 us -- and was dropped.
-  constexpr bool XE2 = ZIP && S <= 8;
+  constexpr bool XE2 = ZIP && XE && S <= 8;
   if constexpr (FLUX) {  // the first period, peeled: the ramp of the levels
     constexpr std::integral_constant<bool, true> pro{};
     phase(ic<0>{}, r_begin, pro);
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256, 1) void k_ringcs(const MultiP<T, T> P) {
 // pairs of (almost) equal height; a pair is cut in the middle: the lower strip marches down the grid from the cut, the upper one up.  A
 // workgroup = the two pairs of two neighbouring windows (pair (2 bx + w / 2), member w % 2); a pair past the end idles through the barriers.
 // A non-finite value met by ANY wave of the workgroup sends all four through the nan_to_num march (they meet at its barriers).
-template <typename T, int S, bool FIRST>
+template <typename T, int S, bool FIRST, bool XE>
 __global__ __launch_bounds__(256, 1) void k_ringcz(const MultiP<T, T> P) {
   constexpr int VEC = 16 / sizeof(T), W = 64 * VEC;
   __shared__ __attribute__((aligned(16))) T zl[4][(S - 1) * W];
@@ -510,39 +510,17 @@ __global__ __launch_bounds__(256, 1) void k_ringcz(const MultiP<T, T> P) {
   const int a = upper ? mid : lo, b = upper ? hi : mid;
   const long long boff = (long long)blockIdx.y * P.bstride;
   bool bad = false;
-  if (active) bad = ringc_march<T, K_FLUX, S, FIRST, false, true, false, true>(P, wx, a, b, boff, !upper, zl[w], zl[w ^ 1]);
+  if (active) bad = ringc_march<T, K_FLUX, S, FIRST, false, XE, false, true>(P, wx, a, b, boff, !upper, zl[w], zl[w ^ 1]);
   else
     for (int k = 0; k < S - 1; ++k) __syncthreads();
   if (__syncthreads_or(bad ? 1 : 0)) {
     if (active) {
       if (P.nfb && (threadIdx.x & 63) == 0) atomicAdd(P.nfb, 1u);
-      ringc_march<T, K_FLUX, S, FIRST, true, true, false, true>(P, wx, a, b, boff, !upper, zl[w], zl[w ^ 1]);
+      ringc_march<T, K_FLUX, S, FIRST, true, XE, false, true>(P, wx, a, b, boff, !upper, zl[w], zl[w ^ 1]);
     } else {
       for (int k = 0; k < S - 1; ++k) __syncthreads();
     }
   }
-}
-
-// pairs per window for k_ringcz: one resident round of waves (1024 slots), strips of at least two rows
-// rows a ZIP march of `need` rows runs: an exit every second row up to eight levels, every fourth at nine
-inline long long ringc_zip_rows(long long need, int S) {
-  const long long ex = S <= 8 ? 2 : 4;
-  return std::max(12LL, (need + ex - 1) / ex * ex);
-}
-inline int ringc_zip_pairs(long long nwx, long long nbatch, long long nrows, int S, int *march) {
-  long long best = 0, best_cost = 0;
-  for (int k = 1; k <= 8; ++k) {
-    long long np = (512LL * k) / std::max(1LL, nwx * nbatch);
-    np = std::min(np, nrows / 4);
-    if (np < 1) continue;
-    const long long H = (nrows + 2 * np - 1) / (2 * np);                 // the taller strips
-    const long long m = ringc_zip_rows(H + S + 1, S);
-    const long long rounds = (2 * np * nwx * nbatch + 1023) / 1024;
-    const long long cost = rounds * m * (100 + 4 * (rounds - 1));
-    if (!best || cost < best_cost) { best = np; best_cost = cost; if (march) *march = (int)(rounds * m); }
-    if (np >= nrows / 4) break;
-  }
-  return (int)best;
 }
 
 template <typename T, int S, bool FIRST>
@@ -596,9 +574,14 @@ static int launch_ringc_zip_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s)
   dim3 block(256), grid((P.nwx * np + 1) / 2, (unsigned)a.nbatch);
   P.xcd_per = pl->xcd_remap ? (int)(grid.x / 8) : 0;
   P.zigzag = 1;
-  hipLaunchKernelGGL((k_ringcz<T, S, FIRST>), grid, block, 0, s, P);
+  bool xe = true;
+  ringc_zip_rows(P.H + S + 1, S, &xe);
+  if (pl->ringc_zip == 2) xe = true;    // (tuning: 2 = always the early-exit form, 3 = always whole periods)
+  if (pl->ringc_zip == 3) xe = false;
+  if (xe) hipLaunchKernelGGL((k_ringcz<T, S, FIRST, true>), grid, block, 0, s, P);
+  else hipLaunchKernelGGL((k_ringcz<T, S, FIRST, false>), grid, block, 0, s, P);
   GCMF_HIP(hipGetLastError());
-  note_kernel(pl, std::string("gcmf::k_ringcz<") + tyname<T>() + ", " + std::to_string(S) + ", " + (FIRST ? "true" : "false") + ">", S,
+  note_kernel(pl, std::string("gcmf::k_ringcz<") + tyname<T>() + ", " + std::to_string(S) + ", " + (FIRST ? "true" : "false") + ", " + (xe ? "true" : "false") + ">", S,
               launch_geom(P.H, P.nstrips, P.nwx, P.xcd_per > 0, grid.x, grid.y, nrows));
   return GCMF_OK;
 }

@@ -1,4 +1,4 @@
-// k_ringcz<double>: pairs of strips zipped at a shared seam (gcmf_ringc_impl.hpp), nine levels (both exit forms); seven and eight: gcmf_ringc_zip_b.hip, five and six: gcmf_ringc_zip_c.hip
+// k_ringcz<double>: pairs of strips zipped at a shared seam (gcmf_ringc_impl.hpp), nine levels (with early exits and in whole ring periods); eight, seven, six and five: gcmf_ringc_zip_{b,c,d}.hip
 #include "gcmf_ringc_impl.hpp"
 
 namespace gcmf {

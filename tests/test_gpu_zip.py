@@ -116,11 +116,22 @@ def test_zipped_strips_in_a_batch(nb):
     assert np.abs(outs[1][clean][ok] - want[clean][ok]).max() <= 1e-12 * np.abs(want[clean][ok]).max()
 
 
-def test_zipped_strips_are_the_default_where_strips_are_short_only():
+def test_depth_of_a_lone_field_on_a_cache_resident_grid():
+    """gcmf_api_blocks.hip: clenshaw_cut -- 1080 x 1440 (the reference's tutorial grid) n 63 runs 8 launches of <= 8 levels (13 windows of 112
+    columns, strips of 14 rows marching 24) instead of 7 x 9 (14 windows of 108, 15 rows marching 28); 720 x 1440 stays at 7 x 9; batches and
+    grids beyond the caches keep the fewest launches."""
+    for shape, n, want in (((1080, 1440), 63, [8] * 7 + [7]), ((720, 1440), 63, [9] * 7), ((2400, 3600), 63, [9] * 7)):
+        f, gv = T.scalar_case("IRREGULAR_WITH_LAND", shape)
+        plan = ALL_KERNELS[GridType.IRREGULAR_WITH_LAND](**gv)._plan(_lib.F64, shape)
+        assert plan.clenshaw_cut(n) == want, (shape, plan.clenshaw_cut(n))
+
+
+def test_zipped_strips_are_the_default_where_they_march_fewer_rows():
     """Policy (gcmf_api.hip: launch_ringc): k_ringcz where it marches at least 10 % fewer rows than the plain / early-exit strips -- 1/4-degree
-    grids, the slab of one of eight ranks; never on tripolar plans (k_fold_band's waves run beside the launch), never at BASELINE size."""
+    grids, the slab of one of eight ranks, and (92 rows against 108) BASELINE config 3; never on tripolar plans (k_fold_band's waves run
+    beside the launch), never a packed batch."""
     for grid, shape, zipped in (("IRREGULAR_WITH_LAND", (300, 3600), True), ("IRREGULAR_WITH_LAND", (720, 1440), True),
-                                ("TRIPOLAR_POP_WITH_LAND", (300, 520), False), ("IRREGULAR_WITH_LAND", (2400, 3600), False)):
+                                ("TRIPOLAR_POP_WITH_LAND", (300, 520), False), ("IRREGULAR_WITH_LAND", (2400, 3600), True)):
         f, gv = T.scalar_case(grid, shape)
         dx = T.grid_dx_min(grid, gv)
         with warnings.catch_warnings():
