@@ -468,7 +468,8 @@ class Plan:
 
 
     def set_option(self, name: str, value: int):
-        """Named per-plan switch (gcmf_set_option): "cgrid_ring", "cgrid_ring_smax", "cgrid_ring_hmax"."""
+        """Named per-plan switch (gcmf_set_option, include/gcmf.h): "cgrid_ring", "cgrid_ring_smax", "cgrid_ring_hmax", "cgrid_ring_ncarry", "pack_batch",
+        "single_launch", "ringc9", "ringc_zip", "ringc_smax", "clenshaw_f32", "ring_flux_f32"."""
         check(load().gcmf_set_option(self._h, name.encode(), int(value)))
 
 

@@ -45,6 +45,11 @@ template <int VEC> __device__ __forceinline__ unsigned cell_bytes(const uint8_t 
 // marches H + S + 1 rows instead of H + 2 S and all its levels start within S + 1 phases.  Same operands, same operations: same bits.
 // (wx: the wave's window; [a, b): the rows it owns; boff: its field's offset in the planes; odd: odd strips of the flux kinds march upwards;
 // zmine / zpart: ZIP -- this wave's and its partner's S - 1 rows of LDS)
+// (Tried on top of it, round 6: the three coefficient rings of a wave in LDS instead of accumulation registers -- a VALU instruction cannot
+// read an accumulation register, so every level pays twelve v_accvgpr_read per row, a third of its non-arithmetic VALU work; from LDS
+// they are three 16-byte reads.  3 983 -> 1 460 v_accvgpr_read in the eight-level kernel, 30 registers fewer, and SLOWER everywhere: 300 x
+// 3600 424 -> 360 G, 1080 x 1440 457 -> 432 G, 1440 x 2880 617 -> 535 G -- one wave per SIMD has nothing to hide the LDS latency behind.
+// Removed.)
 template <bool ZIP> constexpr bool ringc_ramp_on(int t, int ph) { return ZIP ? (t == 1 ? ph >= 1 : ph >= t + 1) : ph >= 2 * t - 1; }
 
 template <typename T, int KIND, int S, bool FIRST, bool SANI, bool XE = false, bool XE6 = false, bool ZIP = false>
