@@ -103,7 +103,7 @@ static int launch_ringc(gcmf_plan *pl, const MultiArgs &m, hipStream_t s) {
       // and every SIMD has a wave (330 -> 364 G cell-steps/s, tools/measure_midsize.py); an 8-way slab 28 instead of 36; BASELINE-size
       // f64 grids 96 either way (-> k_ringc), BASELINE-size f32 grids 52 instead of 60 (+4 %), 1080 x 1440 f32 24 either way (-> k_ringc,
       // the early-exit form measured 9 % slower there).
-      if (!pl->g.fold) {
+      if (!pl->g.fold || pl->alone_now) {   // (nothing has to fit beside these waves: no seam in this launch, or its band runs afterwards)
         const bool f64 = pl->d.dtype == GCMF_F64;
         const int wi = f64 ? (m.S == 9 ? 108 : 112) : 240;   // useful columns of a window (f32: four cells per lane)
         const long long nrows = m.row_hi - m.row_lo, per = ((pl->g.nx + wi - 1) / wi) * std::max<long long>(1, m.nbatch);
@@ -136,6 +136,11 @@ int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launche
   const bool band = g.fold && m.row_hi == rows;
   int rc;
   auto blocked = [&](const MultiArgs &a) { return backward ? launch_ringc(pl, a, s) : launch_scalar_multi(pl, a, s); };
+  // Short launches on the seam's plan (round 6): the band AFTER the blocked launch, in its stream, 1024 threads per tile.  Beside a launch
+  // that lasts no longer than itself the band is the slower of the two (its waves share the SIMDs with the marching waves) and the fork /
+  // join costs ~5 us on top: a 1080 x 1440 tripolar grid took 294 us against 215 us for the same grid without a seam.
+  const bool seq = band && pl->band_seq_cells > 0 && (long long)m.nbatch * (m.row_hi - m.row_lo) * g.nx <= pl->band_seq_cells;
+  pl->alone_now = !band || seq;
   if (!band) {
     if ((rc = dom_begin(pl, s))) return rc;
     if ((rc = blocked(m))) return rc;
@@ -158,6 +163,17 @@ int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launche
   }
   // The seam rows in ONE launch (k_fold_band, gcmf_foldband.hip) on a side stream beside the blocked launch: neither reads what
   // the other writes (the band reads rows >= rows - 2S of the input planes, the two write disjoint rows of the output planes).
+  if (seq) {
+    if (mm.row_hi > mm.row_lo) {
+      if ((rc = dom_begin(pl, s))) return rc;
+      if ((rc = blocked(mm))) return rc;
+      if ((rc = dom_end(pl, s))) return rc;
+      if (launches) ++*launches;
+    }
+    if ((rc = launch_fold_band(pl, m, backward, s, true))) return rc;
+    if (launches) ++*launches;
+    return GCMF_OK;
+  }
   if (!pl->side) {
     // both streams are on this device and nothing between fork and join is read by the host or a peer: no system-scope
     // fence on these events (agent scope orders the two queues; measured +2 % on config 4: the fork / join packets are
@@ -359,6 +375,7 @@ int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int 
   if (const char *e = getenv("GCMF_CLENSHAW")) pl->clenshaw = atoi(e);
   if (const char *e = getenv("GCMF_RINGC9")) pl->ringc9 = atoi(e);
   if (const char *e = getenv("GCMF_RINGC_ZIP")) pl->ringc_zip = atoi(e);
+  if (const char *e = getenv("GCMF_BAND_SEQ_CELLS")) pl->band_seq_cells = atoll(e);
   if (const char *e = getenv("GCMF_PACK_BATCH")) pl->pack_batch = atoi(e);
   if (const char *e = getenv("GCMF_SINGLE_LAUNCH")) pl->single_launch = atoi(e);
   if (const char *e = getenv("GCMF_CLENSHAW_F32")) pl->clenshaw_f32 = atoi(e);

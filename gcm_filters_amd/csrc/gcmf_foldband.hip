@@ -50,8 +50,12 @@ template <typename T, typename FB> struct FoldBandP {
   double p0, c;
 };
 
-template <typename T, typename FB, int KIND, bool BACK>
-__global__ __launch_bounds__(256) void k_fold_band(const FoldBandP<T, FB> P) {
+// NT = 256: the form that runs BESIDE the blocked launch (four tile rows per pass, few registers).  NT = 1024 (round 6): one cell per thread,
+// run AFTER the blocked launch in its stream where that launch is short (1/4-degree grids, the top rank's slab of an 8-way run): alone on
+// the chip the band is a few microseconds, beside a launch that lasts no longer than itself it is the slower of the two and costs a
+// fork / join on top.
+template <typename T, typename FB, int KIND, bool BACK, int NT>
+__global__ __launch_bounds__(NT) void k_fold_band(const FoldBandP<T, FB> P) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr bool FLUX = (KIND == K_FLUX);
   constexpr bool FUSED = FLUX || BACK;   // gcmf_recurrence.hpp; the backward evaluation fuses every multiply-add pair
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(256) void k_fold_band(const FoldBandP<T, FB> P) {
   uint8_t *smb = reinterpret_cast<uint8_t *>(sFB + (BACK ? 0 : FB_CELLS));   // K_MASK: mask bytes
 
   const int tid = threadIdx.x;
-  constexpr int RSTEP = 256 / (2 * FB_WW);   // tile rows a pass of the workgroup covers
+  constexpr int RSTEP = NT / (2 * FB_WW);   // tile rows a pass of the workgroup covers
   constexpr int NPASS = FB_TR / RSTEP;
   const int q = tid & (FB_WW - 1), w = (tid / FB_WW) & 1, tr0 = tid / (2 * FB_WW);
   const int S = P.S, nx = P.nx, rows = P.rows;
@@ -234,8 +238,8 @@ __global__ __launch_bounds__(256) void k_fold_band(const FoldBandP<T, FB> P) {
   }
 }
 
-template <typename T, typename FB, int KIND, bool BACK>
-static int launch_fb(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
+template <typename T, typename FB, int KIND, bool BACK, int NT>
+static int launch_fb_nt(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   const Geom &g = pl->g;
   FoldBandP<T, FB> P{};
   P.u0 = (const T *)a.u0;
@@ -277,13 +281,17 @@ static int launch_fb(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
                (KIND == K_FLUX ? 0 : (size_t)FB_CELLS);
   static bool attr_set = false;  // per instantiation
   if (!attr_set && lds > 48 * 1024) {
-    GCMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fold_band<T, FB, KIND, BACK>),
+    GCMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fold_band<T, FB, KIND, BACK, NT>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_fold_band<T, FB, KIND, BACK>), dim3((unsigned)P.npairs, (unsigned)a.nbatch), dim3(256), lds, s, P);
+  hipLaunchKernelGGL((k_fold_band<T, FB, KIND, BACK, NT>), dim3((unsigned)P.npairs, (unsigned)a.nbatch), dim3(NT), lds, s, P);
   GCMF_HIP(hipGetLastError());
   return GCMF_OK;
+}
+template <typename T, typename FB, int KIND, bool BACK>
+static int launch_fb(gcmf_plan *pl, const MultiArgs &a, hipStream_t s, bool wide) {
+  return wide ? launch_fb_nt<T, FB, KIND, BACK, 1024>(pl, a, s) : launch_fb_nt<T, FB, KIND, BACK, 256>(pl, a, s);
 }
 
 bool fold_band_supported(const gcmf_plan *pl, const MultiArgs &a) {
@@ -293,19 +301,20 @@ bool fold_band_supported(const gcmf_plan *pl, const MultiArgs &a) {
 
 // The top S rows of an S-step launch on a plan whose last row is the tripole seam.  `backward`: a = the arguments of a k_ringc
 // launch (a.fb_in = the constant input f), otherwise of a forward launch.
-int launch_fold_band(gcmf_plan *pl, const MultiArgs &a, bool backward, hipStream_t s) {
+// (wide: 1024 threads per tile, for a band that runs alone)
+int launch_fold_band(gcmf_plan *pl, const MultiArgs &a, bool backward, hipStream_t s, bool wide) {
   if (!fold_band_supported(pl, a)) {
     set_error("k_fold_band: not a tripolar scalar plan / depth %d", a.S);
     return GCMF_ERR_UNSUPPORTED;
   }
   const bool f64 = pl->d.dtype == GCMF_F64, flux = pl->kind == K_FLUX;
   if (backward) {
-    if (f64) return flux ? launch_fb<double, double, K_FLUX, true>(pl, a, s) : launch_fb<double, double, K_MASK, true>(pl, a, s);
-    return flux ? launch_fb<float, float, K_FLUX, true>(pl, a, s) : launch_fb<float, float, K_MASK, true>(pl, a, s);
+    if (f64) return flux ? launch_fb<double, double, K_FLUX, true>(pl, a, s, wide) : launch_fb<double, double, K_MASK, true>(pl, a, s, wide);
+    return flux ? launch_fb<float, float, K_FLUX, true>(pl, a, s, wide) : launch_fb<float, float, K_MASK, true>(pl, a, s, wide);
   }
-  if (f64) return flux ? launch_fb<double, double, K_FLUX, false>(pl, a, s) : launch_fb<double, double, K_MASK, false>(pl, a, s);
-  if (a.fb_is_f32) return flux ? launch_fb<float, float, K_FLUX, false>(pl, a, s) : launch_fb<float, float, K_MASK, false>(pl, a, s);
-  return flux ? launch_fb<float, double, K_FLUX, false>(pl, a, s) : launch_fb<float, double, K_MASK, false>(pl, a, s);
+  if (f64) return flux ? launch_fb<double, double, K_FLUX, false>(pl, a, s, wide) : launch_fb<double, double, K_MASK, false>(pl, a, s, wide);
+  if (a.fb_is_f32) return flux ? launch_fb<float, float, K_FLUX, false>(pl, a, s, wide) : launch_fb<float, float, K_MASK, false>(pl, a, s, wide);
+  return flux ? launch_fb<float, double, K_FLUX, false>(pl, a, s, wide) : launch_fb<float, double, K_MASK, false>(pl, a, s, wide);
 }
 
 }  // namespace gcmf

@@ -177,6 +177,8 @@ struct gcmf_plan {
   int single_launch = 0;  // whole f64 flux grids: the whole polynomial in ONE persistent launch (k_ringc_one; measured slower); gcmf_set_option / GCMF_SINGLE_LAUNCH
   int pack_batch = 1;     // k_ringc / k_ringcs: the fields of a batch as one column per window (ringc_walk, round 6); gcmf_set_option "pack_batch"
   int ringc_zip = 1;      // f64 flux plans without a tripole seam: k_ringcz where it marches fewer rows (env GCMF_RINGC_ZIP, gcmf_set_option "ringc_zip")
+  long long band_seq_cells = 3000000;   // tripolar plans: blocked launches over at most this many cells run k_fold_band AFTER themselves (its 1024-thread form), not beside (env GCMF_BAND_SEQ_CELLS; 0 = never)
+  bool alone_now = true;  // (set by advance_multi for the blocked launch it issues: no k_fold_band waves will share its SIMDs)
   int ringc_smax = 0;     // backward scalar launches: at most this many levels each (5..8; 0 = the default cut: nine where offered, else eight); gcmf_set_option "ringc_smax"
   int ringc9 = 1;         // whole f64 flux-form grids without a tripole seam: up to NINE levels per k_ringc launch (env GCMF_RINGC9, gcmf_set_option "ringc9")
   int clenshaw = 2;       // backward (Clenshaw) evaluation: 0 off, 1 the flux kinds + C-grid, 2 (default since round 4) every kind that has a
@@ -325,7 +327,7 @@ inline int launch_vec_multi(gcmf_plan *pl, const VecMultiArgs &a, hipStream_t s)
 int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launches, bool backward = false);
 // the tripole seam rows of an S-step launch in one launch (gcmf_foldband.hip)
 bool fold_band_supported(const gcmf_plan *pl, const MultiArgs &a);
-int launch_fold_band(gcmf_plan *pl, const MultiArgs &a, bool backward, hipStream_t s);
+int launch_fold_band(gcmf_plan *pl, const MultiArgs &a, bool backward, hipStream_t s, bool wide = false);
 int launch_prepare(gcmf_plan *pl, const void *const *in, void *const *out, int64_t nbatch, int row_lo,
                    int row_hi, hipStream_t s);
 // the isolated cells' own polynomial, written over out (gcmf_landfix.hip); dp = p[0..n_steps] on the device

@@ -11,7 +11,7 @@ int launch_ringc_zip(gcmf_plan *pl, const MultiArgs &a, hipStream_t s) {
   return launch_ringc_zip_b(pl, a, s);
 }
 int ringc_zip_march(const gcmf_plan *pl, const MultiArgs &a, int *pairs) {
-  if (!pl->ringc_zip || pl->d.dtype != GCMF_F64 || pl->kind != K_FLUX || pl->g.fold || pl->strip_rows > 0 || a.S < 5 || a.S > 9) return 0;
+  if (!pl->ringc_zip || pl->d.dtype != GCMF_F64 || pl->kind != K_FLUX || (pl->g.fold && !pl->alone_now) || pl->strip_rows > 0 || a.S < 5 || a.S > 9) return 0;
   const int M = (a.S + 1) / 2 * 2, WI = 128 - 2 * M;
   int march = 0;
   const int np = ringc_zip_pairs((pl->g.nx + WI - 1) / WI, a.nbatch, a.row_hi - a.row_lo, a.S, &march);

@@ -128,10 +128,11 @@ def test_depth_of_a_lone_field_on_a_cache_resident_grid():
 
 def test_zipped_strips_are_the_default_where_they_march_fewer_rows():
     """Policy (gcmf_api.hip: launch_ringc): k_ringcz where it marches at least 10 % fewer rows than the plain / early-exit strips -- 1/4-degree
-    grids, the slab of one of eight ranks, and (92 rows against 108) BASELINE config 3; never on tripolar plans (k_fold_band's waves run
-    beside the launch), never a packed batch."""
+    grids, the slab of one of eight ranks, and (92 rows against 108) BASELINE config 3; on tripolar plans only where the seam's band runs
+    AFTER the launch (short launches: nothing has to fit beside the marching waves), never a packed batch."""
     for grid, shape, zipped in (("IRREGULAR_WITH_LAND", (300, 3600), True), ("IRREGULAR_WITH_LAND", (720, 1440), True),
-                                ("TRIPOLAR_POP_WITH_LAND", (300, 520), False), ("IRREGULAR_WITH_LAND", (2400, 3600), True)):
+                                ("TRIPOLAR_POP_WITH_LAND", (300, 520), True), ("TRIPOLAR_POP_WITH_LAND", (2400, 3600), False),
+                                ("IRREGULAR_WITH_LAND", (2400, 3600), True)):
         f, gv = T.scalar_case(grid, shape)
         dx = T.grid_dx_min(grid, gv)
         with warnings.catch_warnings():
@@ -141,3 +142,32 @@ def test_zipped_strips_are_the_default_where_they_march_fewer_rows():
         plan.last_kernel()
         flt.apply(f)
         assert ("k_ringcz" in plan.last_kernel()) == zipped, (grid, shape, plan.last_kernel())
+
+
+@pytest.mark.parametrize("grid", ["TRIPOLAR_POP_WITH_LAND", "TRIPOLAR_REGULAR_WITH_LAND_AREA_WEIGHTED"])
+@pytest.mark.parametrize("backward", [True, False])
+@pytest.mark.parametrize("n_steps,kwargs", [(16, {}), (21, dict(nb=3, nanland=True)), (29, dict(nanwet=[np.nan, np.nan]))])
+def test_the_seam_band_after_or_beside_the_launch(grid, backward, n_steps, kwargs):
+    """Round 6 (csrc/gcmf_api.hip advance_multi, csrc/gcmf_foldband.hip): on short launches the tripole seam's k_fold_band runs AFTER the blocked
+    launch in its stream with 1024 threads per tile, on long ones beside it on a side stream with 256 -- the same tile arithmetic: the same
+    bits (reference fold: kernels.py:33-40, 517-585), forward and backward evaluation, batches, NaN in wet cells; and with the band out of
+    the way the flux kind's strips may be zipped."""
+    flt, plan, f, want = _case(grid, (180, 392), n_steps, **kwargs)
+    outs, kernels = [], []
+    try:
+        plan.set_tuning(multi_s=8, clenshaw=2 if backward else 0)
+        for cells in (0, 3000000):
+            plan.set_option("band_seq_cells", cells)
+            plan.last_kernel()
+            with np.errstate(all="ignore"):
+                outs.append(flt.apply(f))
+            kernels.append(plan.last_kernel())
+    finally:
+        plan.set_option("band_seq_cells", 3000000)
+        plan.set_tuning(multi_s=8, clenshaw=1)      # (the plan's default: backward for the flux kinds)
+    assert np.array_equal(outs[0], outs[1], equal_nan=True), kernels
+    if backward and grid == "TRIPOLAR_POP_WITH_LAND" and kwargs.get("nb", 1) == 1:
+        assert "k_ringcz" not in kernels[0] and "k_ringcz" in kernels[1], kernels
+    ok = ~np.isnan(want)
+    assert np.array_equal(np.isnan(outs[1]), np.isnan(want))
+    assert np.abs(outs[1][ok] - want[ok]).max() <= 1e-12 * np.abs(want[ok]).max()
