@@ -129,18 +129,19 @@ def run_small_onchip(dev, no_cpu):
     return rec
 
 
-def run_midsize(dev):
+def run_midsize(dev, grid="IRREGULAR_WITH_LAND"):
     """The reference's own tutorial size (1080 x 1440, /docs/examples/example_tripole_grid.ipynb: a 1/4-degree ocean) with the headline's
-    grid type and filter (IRREGULAR_WITH_LAND f64, Taper, filter_scale 16 dx_min, n_steps 63): too big for the on-chip kernel, small enough
-    that the strips of the marching launches are short.  Not a BASELINE config; reported in `summary`."""
+    grid type and filter (IRREGULAR_WITH_LAND f64, Taper, filter_scale 16 dx_min, n_steps 63) -- and, second call, with the tutorial's own
+    grid type (TRIPOLAR_POP_WITH_LAND, the seam included): too big for the on-chip kernel, small enough that the strips of the marching
+    launches are short.  Not a BASELINE config; reported in `summary`."""
     import torch
 
     from gcm_filters_amd import Filter, FilterShape, GridType, testing as T
 
     shape = (1080, 1440)
-    f, gv = T.scalar_case("IRREGULAR_WITH_LAND", shape)
-    dx = T.grid_dx_min("IRREGULAR_WITH_LAND", gv)
-    flt = Filter(filter_scale=16 * dx, dx_min=dx, filter_shape=FilterShape.TAPER, grid_type=GridType.IRREGULAR_WITH_LAND, grid_vars=gv)
+    f, gv = T.scalar_case(grid, shape)
+    dx = T.grid_dx_min(grid, gv)
+    flt = Filter(filter_scale=16 * dx, dx_min=dx, filter_shape=FilterShape.TAPER, grid_type=GridType[grid], grid_vars=gv)
     d = torch.from_numpy(f).to(dev)
     for _ in range(5):
         flt.apply(d)
@@ -154,7 +155,7 @@ def run_midsize(dev):
         blocks.append((time.perf_counter() - t0) / 50)
     t = sorted(blocks)[2]
     n = int(flt.n_steps)
-    return {"config": f"extra: IRREGULAR_WITH_LAND 1080x1440 f64, Taper filter_scale=16 dx_min, n_steps={n} (the reference's tutorial size)",
+    return {"config": f"extra: {grid} 1080x1440 f64, Taper filter_scale=16 dx_min, n_steps={n} (the reference's tutorial size)",
             "n_steps": n, "value": shape[0] * shape[1] * n / t, "unit": "cell-steps/s", "us_per_application": 1e6 * t, "dtype": "f64"}
 
 
@@ -224,7 +225,7 @@ def build_summary(out):
         elif "512x512" in name:
             key = "onchip_512"
         elif "1080x1440" in name:
-            key = "mid_1080x1440"
+            key = "mid_1080x1440_pop" if "TRIPOLAR" in name else "mid_1080x1440"
         elif "ONE persistent launch" in name:
             key = "cfg3_one_launch"
         else:
@@ -411,6 +412,7 @@ def main_single(args):
             extras.append(rec)
         extras.append(small)
         extras.append(run_midsize(dev))
+        extras.append(run_midsize(dev, "TRIPOLAR_POP_WITH_LAND"))
         if args.config == 3 and (args.ny, args.nx) == (2400, 3600):
             one = run_single_launch(dev, args)
             if not one["same_bits"] or "k_ringc_one" not in one["kernel"]:

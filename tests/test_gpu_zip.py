@@ -164,7 +164,7 @@ def test_the_seam_band_after_or_beside_the_launch(grid, backward, n_steps, kwarg
             kernels.append(plan.last_kernel())
     finally:
         plan.set_option("band_seq_cells", 3000000)
-        plan.set_tuning(multi_s=8, clenshaw=1)      # (the plan's default: backward for the flux kinds)
+        plan.set_tuning(multi_s=8, clenshaw=2)      # (the plan's default)
     assert np.array_equal(outs[0], outs[1], equal_nan=True), kernels
     if backward and grid == "TRIPOLAR_POP_WITH_LAND" and kwargs.get("nb", 1) == 1:
         assert "k_ringcz" not in kernels[0] and "k_ringcz" in kernels[1], kernels
