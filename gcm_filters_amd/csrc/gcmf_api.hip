@@ -148,6 +148,16 @@ int advance_multi(gcmf_plan *pl, const MultiArgs &m, hipStream_t s, int *launche
     if (launches) ++*launches;
     return GCMF_OK;
   }
+  if (backward && ringc_zip_fold_ok(pl, m)) {   // (round 6) the seam's rows inside the launch: strips that start at the seam, zipped with their mirror windows
+    MultiArgs mz = m;
+    mz.zip_fold = 1;
+    pl->alone_now = true;
+    if ((rc = dom_begin(pl, s))) return rc;
+    if ((rc = launch_ringc_zip(pl, mz, s))) return rc;
+    if ((rc = dom_end(pl, s))) return rc;
+    if (launches) ++*launches;
+    return GCMF_OK;
+  }
   const int blo = rows - S;  // first band row
   // k_fold_band reads rows [rows - 2S, rows) of the input planes (valid: the caller's ghost zone covers [row_lo - S, ...)) and owns
   // [rows - S, rows); the blocked launch gets [row_lo, rows - S), possibly nothing
@@ -376,6 +386,7 @@ int gcmf_plan_create(const gcmf_plan_desc *desc, const void *const *planes, int 
   if (const char *e = getenv("GCMF_RINGC9")) pl->ringc9 = atoi(e);
   if (const char *e = getenv("GCMF_RINGC_ZIP")) pl->ringc_zip = atoi(e);
   if (const char *e = getenv("GCMF_BAND_SEQ_CELLS")) pl->band_seq_cells = atoll(e);
+  if (const char *e = getenv("GCMF_ZIP_FOLD")) pl->zip_fold = atoi(e);
   if (const char *e = getenv("GCMF_PACK_BATCH")) pl->pack_batch = atoi(e);
   if (const char *e = getenv("GCMF_SINGLE_LAUNCH")) pl->single_launch = atoi(e);
   if (const char *e = getenv("GCMF_CLENSHAW_F32")) pl->clenshaw_f32 = atoi(e);

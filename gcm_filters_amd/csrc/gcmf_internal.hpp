@@ -84,6 +84,7 @@ struct MultiArgs {
   int land_zero;  // the caller guarantees that isolated (land) cells of u0 and v0 are zero: GCMF_STEP_LAND_ZERO
   int ring_first; // first launch: the caller will overwrite the result of the isolated (land) cells (k_land_fix) or there are
                   // none, so the launch may take them as zero while it loads the field (k_ring<..., FIRST>)
+  int zip_fold = 0;  // k_ringcz: [row_lo, row_hi) ends at the tripole seam and the launch advances the seam rows itself (no k_fold_band)
 };
 
 // Arguments of one S-step vector launch (gcmf_cgrid_stream2.hip / gcmf_bgrid_stream2.hip): T_{k-1}, T_{k-2} -> T_{k+S-2}, T_{k+S-1}.
@@ -179,6 +180,7 @@ struct gcmf_plan {
   int ringc_zip = 1;      // f64 flux plans without a tripole seam: k_ringcz where it marches fewer rows (env GCMF_RINGC_ZIP, gcmf_set_option "ringc_zip")
   long long band_seq_cells = 3000000;   // tripolar plans: blocked launches over at most this many cells run k_fold_band AFTER themselves (its 1024-thread form), not beside (env GCMF_BAND_SEQ_CELLS; 0 = never)
   bool alone_now = true;  // (set by advance_multi for the blocked launch it issues: no k_fold_band waves will share its SIMDs)
+  int zip_fold = 1;       // tripolar f64 flux plans, backward evaluation: k_ringcz advances the seam's rows itself (no k_fold_band); gcmf_set_option "zip_fold", env GCMF_ZIP_FOLD
   int ringc_smax = 0;     // backward scalar launches: at most this many levels each (5..8; 0 = the default cut: nine where offered, else eight); gcmf_set_option "ringc_smax"
   int ringc9 = 1;         // whole f64 flux-form grids without a tripole seam: up to NINE levels per k_ringc launch (env GCMF_RINGC9, gcmf_set_option "ringc9")
   int clenshaw = 2;       // backward (Clenshaw) evaluation: 0 off, 1 the flux kinds + C-grid, 2 (default since round 4) every kind that has a
@@ -282,7 +284,8 @@ int launch_ringc_flux(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_ringc_flux9(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);   // nine levels: whole f64 flux grids without a seam (gcmf_ringc_flux9.hip)
 int launch_ringc_flux_slab(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 int launch_ringc_zip(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);   // f64 flux plans without a tripole seam, short strips: pairs of strips zipped at a shared seam (k_ringcz, gcmf_ringc_zip.hip)
-int ringc_zip_march(const gcmf_plan *pl, const MultiArgs &a, int *pairs);  // rows a k_ringcz launch would march (all rounds), 0 = not offered
+int ringc_zip_march(const gcmf_plan *pl, const MultiArgs &a, int *pairs);
+bool ringc_zip_fold_ok(const gcmf_plan *pl, const MultiArgs &a);   // can k_ringcz advance the tripole seam's rows of this launch itself?  // rows a k_ringcz launch would march (all rounds), 0 = not offered
 int launch_ringc_flux_slab_f32(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);   // flux plans without a tripole seam, short strips: early exits (k_ringcs)
 int launch_flux_multi2(gcmf_plan *pl, const MultiArgs &a, hipStream_t s);
 // the on-chip kernel (gcmf_resident.hip): L <= 64 levels of the backward evaluation in ONE launch on a field that fits the register

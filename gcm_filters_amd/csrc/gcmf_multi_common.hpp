@@ -113,6 +113,8 @@ template <typename T, typename FB> struct MultiP {
   int zigzag;        // k_ringc, flux kinds: odd strips march upwards (gcmf_ringc_impl.hpp)
   int npack;         // k_ringc / k_ringcs, batches (round 6): > 0 = the npack fields of the batch are ONE column of npack * (out_hi - out_lo) rows
                      // per window, cut into runs of H rows -- a wave walks its run, at most two (field, row range) segments (0: gridDim.y = batch)
+  int fold_rows;     // k_ringcz on the plan that owns the tripole seam (round 6): the top fold_rows rows are strips that START at the seam, each
+  int nfw;           // zipped with the strip of its MIRROR window (nfw such window pairs cover the two halves of a row); 0 = none
   long long bstride;
   double pk[MAX_PK];  // coefficient of level t (1-based) at pk[t-1]
   double p0;         // first only

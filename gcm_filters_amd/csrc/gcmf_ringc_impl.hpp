@@ -52,9 +52,15 @@ template <int VEC> __device__ __forceinline__ unsigned cell_bytes(const uint8_t 
 // Removed.)
 template <bool ZIP> constexpr bool ringc_ramp_on(int t, int ph) { return ZIP ? (t == 1 ? ph >= 1 : ph >= t + 1) : ph >= 2 * t - 1; }
 
+// ZIP, fold (wave-uniform, k_ringcz on the plan that owns the TRIPOLE SEAM): the strip starts at the grid's top row and its partner is the
+// strip of the MIRROR window -- the northern neighbour of cell (rows - 1, i) is (rows - 1, nx - 1 - i) (reference kernels.py:33-40,
+// 517-585) -- so the row the partner hands over is read with the lanes (and a lane's cells) reversed, level 1's seam flux comes from the
+// partner's row of the input state as well (one more exchange), and the face coefficient is the top row's own north face (folded at plan
+// time).  pos_at: the window's first column instead of wx * WI - M; [klo, khi): the columns this window keeps.
 template <typename T, int KIND, int S, bool FIRST, bool SANI, bool XE = false, bool XE6 = false, bool ZIP = false>
 __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wx, const int a, const int b, const long long boff, const bool odd,
-                                            T *zmine = nullptr, const T *zpart = nullptr) {
+                                            T *zmine = nullptr, const T *zpart = nullptr, const bool fold = false, const int pos_at = 0,
+                                            const int klo = -(1 << 30), const int khi = 1 << 30) {
   constexpr int VEC = 16 / sizeof(T);
   constexpr int W = 64 * VEC;
   constexpr int M = (S + VEC - 1) / VEC * VEC;
@@ -68,12 +74,12 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wx,
 
   const int lane = threadIdx.x & 63;
   const int nx = P.nx, rows = P.rows;
-  const int pos = wx * WI - M + lane * VEC;
+  const int pos = ((ZIP && fold) ? pos_at : wx * WI - M) + lane * VEC;
   int col_s = pos % nx;
   if (col_s < 0) col_s += nx;
   const unsigned col = (unsigned)col_s;
   const unsigned colT = col * (unsigned)sizeof(T);
-  const bool keep = (lane * VEC >= M) && (lane * VEC < W - M) && (pos < nx);
+  const bool keep = (lane * VEC >= M) && (lane * VEC < W - M) && (pos < nx) && (!ZIP || (pos >= klo && pos < khi));
   const T c = (T)P.c;
   const bool last = P.last;
 
@@ -306,8 +312,11 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wx,
     // ZIP: the strip starts AT the seam (q = 0 at march row a - 1, the partner's first row): level 1 runs from phase 1 (for the seam face's
     // flux, out of its own two rows), level t >= 2 from phase t + 1 -- its first row, with the seam face's flux from the exchange below.
     if constexpr (ZIP && PRO && ph == 1) {
+      if (fold) mload<T, VEC>(cNs, lane_ptr(P.cN + (long long)(rows - 1) * nx, colT));   // the top row's north face: the fold
+      else {
 #pragma unroll
-      for (int k = 0; k < VEC; ++k) cNs[k] = cN[1][k];   // (the coefficient row of march row a - 1: its face towards row a)
+        for (int k = 0; k < VEC; ++k) cNs[k] = cN[1][k];   // (the coefficient row of march row a - 1: its face towards row a)
+      }
     }
     if constexpr (!PRO || ringc_ramp_on<ZIP>(1, ph)) level(ic<1>{}, ph_c);
     if constexpr (S >= 2 && (!PRO || ringc_ramp_on<ZIP>(2, ph))) level(ic<2>{}, ph_c);
@@ -318,6 +327,20 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wx,
     if constexpr (S >= 7 && (!PRO || ringc_ramp_on<ZIP>(7, ph))) level(ic<7>{}, ph_c);
     if constexpr (S >= 8 && (!PRO || ringc_ramp_on<ZIP>(8, ph))) level(ic<8>{}, ph_c);
     if constexpr (S >= 9 && (!PRO || ringc_ramp_on<ZIP>(9, ph))) level(ic<9>{}, ph_c);
+    if constexpr (ZIP && PRO && ph == 1) {
+      if (fold) {   // level 1's seam flux: the partner's top row of the input state (slot 1 of the ring of b_{k+1}; a first launch has just formed it)
+        T own[VEC], oth[VEC], rev[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) own[k] = G0[1][k];
+        mstore<T, VEC>(zmine + (S - 1) * W + lane * VEC, own);
+        __syncthreads();
+        mload<T, VEC>(rev, zpart + (S - 1) * W + (63 - lane) * VEC);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) oth[k] = rev[VEC - 1 - k];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) FN[1][k] = ((SANI ? msan(own[k]) : own[k]) - (SANI ? msan(oth[k]) : oth[k])) * cNs[k];
+      }
+    }
     if constexpr (ZIP && PRO && ph >= 2 && ph <= S) {
       // level ph - 1 has just produced the strip's first row (slot 1 of its ring): the partner's level ph needs it for the flux across the
       // seam, this wave's level ph needs the partner's -- what the march row before the first one would have left in FN[ph]
@@ -327,7 +350,12 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wx,
       for (int k = 0; k < VEC; ++k) own[k] = G[t < S ? t : 1][1][k];
       mstore<T, VEC>(zmine + (t - 1) * W + lane * VEC, own);
       __syncthreads();
-      mload<T, VEC>(oth, zpart + (t - 1) * W + lane * VEC);
+      {
+        T got[VEC];
+        mload<T, VEC>(got, zpart + (t - 1) * W + (fold ? 63 - lane : lane) * VEC);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) oth[k] = fold ? got[VEC - 1 - k] : got[k];
+      }
 #pragma unroll
       for (int k = 0; k < VEC; ++k) FN[t + 1][k] = ((SANI ? msan(own[k]) : own[k]) - (SANI ? msan(oth[k]) : oth[k])) * cNs[k];
     }
@@ -501,29 +529,49 @@ __global__ __launch_bounds__(256, 1) void k_ringcs(const MultiP<T, T> P) {
 // A non-finite value met by ANY wave of the workgroup sends all four through the nan_to_num march (they meet at its barriers).
 template <typename T, int S, bool FIRST, bool XE>
 __global__ __launch_bounds__(256, 1) void k_ringcz(const MultiP<T, T> P) {
-  constexpr int VEC = 16 / sizeof(T), W = 64 * VEC;
-  __shared__ __attribute__((aligned(16))) T zl[4][(S - 1) * W];
+  constexpr int VEC = 16 / sizeof(T), W = 64 * VEC, M = (S + VEC - 1) / VEC * VEC, WI = W - 2 * M;
+  __shared__ __attribute__((aligned(16))) T zl[4][S * W];   // (row S - 1: the fold strips' exchange of the input state)
   int bx = blockIdx.x;
   if (P.xcd_per > 0 && bx < 8 * P.xcd_per) bx = (bx & 7) * P.xcd_per + (bx >> 3);
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int np = P.nstrips >> 1, pid = bx * 2 + (w >> 1);
-  const bool active = pid < P.nwx * np;
-  const int wx = pid % P.nwx, pp = pid / P.nwx;
-  const long long nrows = P.out_hi - P.out_lo;
-  const int lo = P.out_lo + (int)((long long)pp * nrows / np), hi = P.out_lo + (int)((long long)(pp + 1) * nrows / np), mid = lo + (hi - lo) / 2;
-  const bool upper = (w & 1) != 0;
-  const int a = upper ? mid : lo, b = upper ? hi : mid;
+  const int np = P.nstrips >> 1, nnorm = P.nwx * np, nnorm_wg = (nnorm + 1) >> 1;
+  const bool fold = bx >= nnorm_wg;   // (workgroup-uniform: the fold strips' workgroups follow the pairs')
   const long long boff = (long long)blockIdx.y * P.bstride;
+  const bool upper = (w & 1) != 0;
+  bool active, odd;
+  int wx = 0, a, b, pos_at = 0, klo = -(1 << 30), khi = 1 << 30;
+  if (!fold) {
+    const int pid = bx * 2 + (w >> 1);
+    active = pid < nnorm;
+    wx = pid % P.nwx;
+    const int pp = pid / P.nwx;
+    const long long nrows = P.out_hi - P.fold_rows - P.out_lo;
+    const int lo = P.out_lo + (int)((long long)pp * nrows / np), hi = P.out_lo + (int)((long long)(pp + 1) * nrows / np), mid = lo + (hi - lo) / 2;
+    a = upper ? mid : lo;
+    b = upper ? hi : mid;
+    odd = !upper;
+  } else {   // a window of the western half (even wave) and its mirror image (odd wave), both marching down the grid from the seam
+    const int fid = (bx - nnorm_wg) * 2 + (w >> 1);
+    active = fid < P.nfw;
+    a = P.out_hi - P.fold_rows;
+    b = P.out_hi;
+    odd = true;
+    const int pw = fid * WI - M;
+    pos_at = upper ? P.nx - pw - W : pw;
+    klo = upper ? P.nx / 2 : 0;
+    khi = upper ? P.nx : P.nx / 2;
+  }
+  const int nbar = fold ? S : S - 1;
   bool bad = false;
-  if (active) bad = ringc_march<T, K_FLUX, S, FIRST, false, XE, false, true>(P, wx, a, b, boff, !upper, zl[w], zl[w ^ 1]);
+  if (active) bad = ringc_march<T, K_FLUX, S, FIRST, false, XE, false, true>(P, wx, a, b, boff, odd, zl[w], zl[w ^ 1], fold, pos_at, klo, khi);
   else
-    for (int k = 0; k < S - 1; ++k) __syncthreads();
+    for (int k = 0; k < nbar; ++k) __syncthreads();
   if (__syncthreads_or(bad ? 1 : 0)) {
     if (active) {
       if (P.nfb && (threadIdx.x & 63) == 0) atomicAdd(P.nfb, 1u);
-      ringc_march<T, K_FLUX, S, FIRST, true, XE, false, true>(P, wx, a, b, boff, !upper, zl[w], zl[w ^ 1]);
+      ringc_march<T, K_FLUX, S, FIRST, true, XE, false, true>(P, wx, a, b, boff, odd, zl[w], zl[w ^ 1], fold, pos_at, klo, khi);
     } else {
-      for (int k = 0; k < S - 1; ++k) __syncthreads();
+      for (int k = 0; k < nbar; ++k) __syncthreads();
     }
   }
 }
@@ -559,13 +607,30 @@ static int launch_ringc_zip_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s)
   const int nrows = a.row_hi - a.row_lo;
   if (nrows <= 0 || a.nbatch <= 0) return GCMF_OK;
   P.nwx = (g.nx + WI - 1) / WI;
-  const int np = ringc_zip_pairs(P.nwx, a.nbatch, nrows, S, nullptr);
-  if (np < 1) {
+  int np = ringc_zip_pairs(P.nwx, a.nbatch, nrows, S, nullptr);
+  P.fold_rows = 0;
+  P.nfw = 0;
+  if (a.zip_fold) {   // the top rows: strips that start at the tripole seam, zipped with their mirror windows (one more "half pair" per window)
+    P.nfw = (g.nx / 2 + WI - 1) / WI;
+    // as many pairs as fill whole rounds of the 256 CUs together with the fold strips' workgroups (two units per workgroup: 257 workgroups
+    // would be two rounds -- config 4 measured 1.32 ms that way against 0.90)
+    const long long fwg = (P.nfw + 1) / 2;
+    long long npmax = 0;
+    for (long long k = 1; k <= 8 && npmax < 1; ++k) {
+      const long long cap = 256 * k / std::max<long long>(1, std::min<long long>(a.nbatch, 256 * k));
+      npmax = cap > fwg ? 2 * (cap - fwg) / P.nwx : 0;
+    }
+    np = (int)std::max(1LL, std::min<long long>(npmax, (nrows - S) / 4));
+    // (at least S rows: the ghost rows the pairs below march beyond their last row must stay on this side of the seam)
+    P.fold_rows = std::max(S, (int)((nrows + 2 * np) / (2 * np + 1)));
+    np = (int)std::max(1LL, std::min<long long>(np, (nrows - P.fold_rows) / 4));
+  }
+  if (np < 1 || nrows - P.fold_rows < 2 * np) {
     set_error("k_ringcz: %d rows cannot be cut into pairs of strips", nrows);
     return GCMF_ERR_INVALID_ARG;
   }
   P.nstrips = 2 * np;
-  P.H = (nrows + 2 * np - 1) / (2 * np);
+  P.H = (nrows - P.fold_rows + 2 * np - 1) / (2 * np);
   P.npack = 0;
   P.nwaves = P.nwx * P.nstrips;
   P.wrap = g.south_wrap && g.north_wrap;
@@ -576,11 +641,11 @@ static int launch_ringc_zip_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s)
   for (int t = 0; t < MAX_PK; ++t) P.pk[t] = t < S ? a.pk[t] : 0.0;
   P.p0 = a.p0;
   P.c = a.c;
-  dim3 block(256), grid((P.nwx * np + 1) / 2, (unsigned)a.nbatch);
+  dim3 block(256), grid((P.nwx * np + 1) / 2 + (P.nfw + 1) / 2, (unsigned)a.nbatch);
   P.xcd_per = pl->xcd_remap ? (int)(grid.x / 8) : 0;
   P.zigzag = 1;
   bool xe = true;
-  ringc_zip_rows(P.H + S + 1, S, &xe);
+  ringc_zip_rows(std::max(P.H, P.fold_rows) + S + 1, S, &xe);
   if (pl->ringc_zip == 2) xe = true;    // (tuning: 2 = always the early-exit form, 3 = always whole periods)
   if (pl->ringc_zip == 3) xe = false;
   if (xe) hipLaunchKernelGGL((k_ringcz<T, S, FIRST, true>), grid, block, 0, s, P);

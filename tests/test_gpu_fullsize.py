@@ -90,13 +90,20 @@ def test_tripolar_pop_fullsize_fold_band(monkeypatch):
         plan.set_tuning(multi_s=8, clenshaw=0)    # the forward recurrence: blocked launches + the seam rows by k_fold_band
         got = flt.apply(f)
         assert "k_ring<" in plan.last_kernel()
-        plan.set_tuning(multi_s=8, clenshaw=2)    # the default: backward evaluation, the seam rows by k_fold_band's backward form
+        plan.set_tuning(multi_s=8, clenshaw=2)    # backward evaluation, the seam rows by k_fold_band's backward form (the default until round 6)
+        plan.set_option("zip_fold", 0)
         back = flt.apply(f)
         assert "k_ringc<" in plan.last_kernel()
+        plan.set_option("zip_fold", 1)            # the default since round 6: the seam inside the launch (k_ringcz's fold strips), no k_fold_band
+        plan.last_kernel()
+        back2 = flt.apply(f)
+        assert "k_ringcz<double, 8" in plan.last_kernel()
     finally:
+        plan.set_option("zip_fold", 1)
         plan.set_tuning(multi_s=8, clenshaw=2)
     assert np.array_equal(ref, got)                # bit-identical with 56 single steps, seam included
     assert np.abs(back - ref).max() <= 1e-13 * np.abs(ref).max()
+    assert np.array_equal(back, back2)             # ... and the same bits whichever way the seam is advanced
     for o in (got, back):
         np.testing.assert_allclose((o * gv["tarea"] * gv["wet_mask"]).sum(), (f * gv["tarea"] * gv["wet_mask"]).sum(), rtol=1e-10)
 

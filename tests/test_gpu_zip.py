@@ -131,7 +131,7 @@ def test_zipped_strips_are_the_default_where_they_march_fewer_rows():
     grids, the slab of one of eight ranks, and (92 rows against 108) BASELINE config 3; on tripolar plans only where the seam's band runs
     AFTER the launch (short launches: nothing has to fit beside the marching waves), never a packed batch."""
     for grid, shape, zipped in (("IRREGULAR_WITH_LAND", (300, 3600), True), ("IRREGULAR_WITH_LAND", (720, 1440), True),
-                                ("TRIPOLAR_POP_WITH_LAND", (300, 520), True), ("TRIPOLAR_POP_WITH_LAND", (2400, 3600), False),
+                                ("TRIPOLAR_POP_WITH_LAND", (300, 520), True), ("TRIPOLAR_POP_WITH_LAND", (2400, 3600), True),   # (the seam inside the launch)
                                 ("IRREGULAR_WITH_LAND", (2400, 3600), True)):
         f, gv = T.scalar_case(grid, shape)
         dx = T.grid_dx_min(grid, gv)
@@ -155,6 +155,7 @@ def test_the_seam_band_after_or_beside_the_launch(grid, backward, n_steps, kwarg
     flt, plan, f, want = _case(grid, (180, 392), n_steps, **kwargs)
     outs, kernels = [], []
     try:
+        plan.set_option("zip_fold", 0)           # (the f64 flux kind evaluated backwards would advance the seam inside its launches)
         plan.set_tuning(multi_s=8, clenshaw=2 if backward else 0)
         for cells in (0, 3000000):
             plan.set_option("band_seq_cells", cells)
@@ -164,6 +165,7 @@ def test_the_seam_band_after_or_beside_the_launch(grid, backward, n_steps, kwarg
             kernels.append(plan.last_kernel())
     finally:
         plan.set_option("band_seq_cells", 3000000)
+        plan.set_option("zip_fold", 1)
         plan.set_tuning(multi_s=8, clenshaw=2)      # (the plan's default)
     assert np.array_equal(outs[0], outs[1], equal_nan=True), kernels
     if backward and grid == "TRIPOLAR_POP_WITH_LAND" and kwargs.get("nb", 1) == 1:
@@ -171,3 +173,33 @@ def test_the_seam_band_after_or_beside_the_launch(grid, backward, n_steps, kwarg
     ok = ~np.isnan(want)
     assert np.array_equal(np.isnan(outs[1]), np.isnan(want))
     assert np.abs(outs[1][ok] - want[ok]).max() <= 1e-12 * np.abs(want[ok]).max()
+
+
+@pytest.mark.parametrize("shape", [(180, 392), (300, 520), (97, 256), (260, 1100)])
+@pytest.mark.parametrize("n_steps,kwargs", [(8, {}), (16, dict(nanland=True)), (21, dict(nb=3, nanland=True)), (29, dict(nanwet=[np.nan, np.nan])),
+                                            (56, dict(nanland=True, nanwet=[np.inf]))])
+def test_the_tripole_seam_inside_the_launch(shape, n_steps, kwargs):
+    """Round 6 (csrc/gcmf_ringc_impl.hpp: ringc_march<ZIP>, fold): on the f64 flux kind of a tripolar plan (TRIPOLAR_POP_WITH_LAND: reference
+    kernels.py:517-585, the fold of :33-40) the top rows of a backward launch are strips that START at the seam, each zipped with the strip of
+    its MIRROR window -- the northern neighbour of (ny - 1, i) is (ny - 1, nx - 1 - i) -- so k_fold_band is not launched at all.  Same bits as
+    the launches with the band (option "zip_fold" 0), the oracle within 1e-12."""
+    flt, plan, f, want = _case("TRIPOLAR_POP_WITH_LAND", shape, n_steps, **kwargs)
+    outs, kernels = [], []
+    try:
+        if kwargs.get("nb", 1) > 1:
+            plan.set_option("pack_batch", 0)
+        for zf in (0, 1):
+            plan.set_option("zip_fold", zf)
+            plan.last_kernel()
+            with np.errstate(all="ignore"):
+                outs.append(flt.apply(f))
+            kernels.append((plan.last_kernel(), plan.last_kernel_geometry()))
+    finally:
+        plan.set_option("zip_fold", 1)
+        plan.set_option("pack_batch", 1)
+    assert "k_ringcz<double" in kernels[1][0], kernels
+    assert np.array_equal(outs[0], outs[1], equal_nan=True), kernels
+    if not any(isinstance(v, list) and np.isinf(v).any() for v in kwargs.values()):
+        ok = ~np.isnan(want)
+        assert np.array_equal(np.isnan(outs[1]), np.isnan(want))
+        assert np.abs(outs[1][ok] - want[ok]).max() <= 1e-12 * np.abs(want[ok]).max()
