@@ -20,6 +20,18 @@ bool ringc9_ok(const gcmf_plan *pl) {
   return pl && pl->ringc9 && pl->kind == K_FLUX && pl->d.dtype == GCMF_F64 && pl->full && !pl->tripolar && !pl->g.fold && pl->g.rows >= 64;
 }
 
+// ... and whole tripolar f64 flux grids whose launches advance the seam themselves (k_ringcz's fold strips, round 6): no k_fold_band (which
+// stops at eight levels) is involved then.  Depends on the batch: a packed batch keeps the band.
+static bool ringc9_fold_ok(const gcmf_plan *pl, int64_t nbatch) {
+  if (!(pl && pl->ringc9 && pl->kind == K_FLUX && pl->d.dtype == GCMF_F64 && pl->full && pl->g.fold && pl->g.rows >= 64)) return false;
+  MultiArgs a{};
+  a.S = 9;
+  a.nbatch = nbatch;
+  a.row_lo = 0;
+  a.row_hi = pl->g.rows;
+  return ringc_zip_fold_ok(pl, a);
+}
+
 // Backward (Clenshaw) evaluation (gcmf_ringc_impl.hpp): whether gcmf_apply uses it for this plan and polynomial, and how the
 // n_steps levels are cut into launches of 5..8 (never leaving 1..4 or 9 behind).  plan->clenshaw = 1: the flux kinds, whose
 // launches run at memcpy rate and gain the plane they no longer move (config 3: +10 %); 2: every scalar kind (the land-mask
@@ -39,9 +51,10 @@ int clenshaw_cut(const gcmf_plan *pl, int n_steps, int *depths, int max_depths, 
   // (f32 state: the flux kinds since round 3, the REGULAR / land-mask kinds since round 4)
   if (!pl->ring || !pl->zero_row || pl->multi_s < 8 || !multi_supported(pl, 8)) return 0;
   if (pl->n_land > 0 && !land_ok(pl, n_steps)) return 0;
-  if (!(n_steps >= 10 || (n_steps >= 5 && n_steps <= 8) || (n_steps == 9 && ringc9_ok(pl)))) return 0;
+  const bool nines = ringc9_ok(pl) || ringc9_fold_ok(pl, nbatch);
+  if (!(n_steps >= 10 || (n_steps >= 5 && n_steps <= 8) || (n_steps == 9 && nines))) return 0;
   int smax = pl->ringc_smax;
-  if (!smax && nbatch == 1 && ringc9_ok(pl) && pl->ringc_zip && (long long)pl->g.rows * pl->g.nx <= 2500000LL && n_steps >= 10) {
+  if (!smax && nbatch == 1 && nines && pl->ringc_zip && (long long)pl->g.rows * pl->g.nx <= 2500000LL && n_steps >= 10) {
     // Whole grids that live in the caches and run k_ringcz (1/4-degree grids): a launch is paced by the rows its strips march, not by the
     // bytes it moves, so fewer launches are not always faster -- a strip marches H + S + 1 rows whose cost grows with S, and fewer
     // levels mean narrower ghost columns (sometimes a window less).  Measured (experiments/scripts/zip_ab.py, us per launch):
@@ -63,7 +76,7 @@ int clenshaw_cut(const gcmf_plan *pl, int n_steps, int *depths, int max_depths, 
       return L;
     }
   }
-  if (ringc9_ok(pl) && smax != 8 && (n_steps + 8) / 9 < (n_steps + 7) / 8) {
+  if (nines && smax != 8 && (n_steps + 8) / 9 < (n_steps + 7) / 8) {
     // one launch fewer with up to nine levels each: as even as possible (63 = 7 x 9, 65 = 9 + 7 x 8), the nines first
     const int L = (n_steps + 8) / 9, q = n_steps / L, r = n_steps % L;
     if (L > max_depths) return 0;

@@ -22,6 +22,6 @@ int ringc_zip_march(const gcmf_plan *pl, const MultiArgs &a, int *pairs) {
 // kind evaluated backwards, rows up to the seam, a lane's two cells on one side of the row's centre, no packed batch.
 bool ringc_zip_fold_ok(const gcmf_plan *pl, const MultiArgs &a) {
   return pl->ringc_zip && pl->zip_fold && pl->g.fold && a.row_hi == pl->g.rows && pl->d.dtype == GCMF_F64 && pl->kind == K_FLUX && pl->strip_rows <= 0 &&
-         a.S >= 5 && a.S <= 8 && (pl->g.nx % 4) == 0 && pl->g.nx >= 256 && a.row_hi - a.row_lo >= 24 && !(a.nbatch > 1 && pl->pack_batch) && a.nbatch <= 64;
+         a.S >= 5 && a.S <= 9 && (pl->g.nx % 4) == 0 && pl->g.nx >= 256 && a.row_hi - a.row_lo >= 24 && !(a.nbatch > 1 && pl->pack_batch) && a.nbatch <= 64;
 }
 }  // namespace gcmf

@@ -203,3 +203,33 @@ def test_the_tripole_seam_inside_the_launch(shape, n_steps, kwargs):
         ok = ~np.isnan(want)
         assert np.array_equal(np.isnan(outs[1]), np.isnan(want))
         assert np.abs(outs[1][ok] - want[ok]).max() <= 1e-12 * np.abs(want[ok]).max()
+
+
+@pytest.mark.parametrize("n_steps,kwargs", [(9, {}), (27, dict(nanland=True)), (63, dict(nanland=True, nanwet=[np.nan])), (17, dict(nb=2))])
+def test_nine_levels_per_launch_on_tripolar_grids(n_steps, kwargs):
+    """With the seam inside the launch no k_fold_band (<= 8 levels) is involved, so whole f64 TRIPOLAR_POP grids take nine levels per launch
+    where that saves one (63 = 7 x 9), like the flux grids without a seam; a packed batch keeps the band and the eights.  Same bits as the
+    cut into launches of <= 8 (n = 9 cannot be cut otherwise: the forward recurrence, within tolerance)."""
+    flt, plan, f, want = _case("TRIPOLAR_POP_WITH_LAND", (200, 392), n_steps, **kwargs)
+    nb = kwargs.get("nb", 1)
+    try:
+        cut9 = plan.clenshaw_cut(n_steps)
+        assert 9 in cut9 and len(cut9) == -(-n_steps // 9), cut9
+        plan.last_kernel()
+        with np.errstate(all="ignore"):
+            got9 = flt.apply(f)
+        k9 = plan.last_kernel()
+        plan.set_option("ringc9", 0)
+        with np.errstate(all="ignore"):
+            got8 = flt.apply(f)
+    finally:
+        plan.set_option("ringc9", 1)
+    if nb == 1:
+        assert "k_ringcz<double, 9" in k9, k9
+    else:
+        assert "k_ringcz" not in k9, k9        # (the batch is packed: the band, at most eight levels -- gcmf_apply cuts with the batch in hand)
+    ok = ~np.isnan(want)
+    assert np.array_equal(np.isnan(got9), np.isnan(want))
+    assert np.abs(got9[ok] - want[ok]).max() <= 1e-12 * np.abs(want[ok]).max()
+    if n_steps != 9:
+        assert np.array_equal(got9, got8, equal_nan=True)
