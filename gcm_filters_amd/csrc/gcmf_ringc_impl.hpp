@@ -328,6 +328,8 @@ __device__ __forceinline__ bool ringc_march(const MultiP<T, T> &P, const int wx,
     if constexpr (S >= 8 && (!PRO || ringc_ramp_on<ZIP>(8, ph))) level(ic<8>{}, ph_c);
     if constexpr (S >= 9 && (!PRO || ringc_ramp_on<ZIP>(9, ph))) level(ic<9>{}, ph_c);
     if constexpr (ZIP && PRO && ph == 1) {
+      // (launch-uniform: in a launch with fold strips EVERY workgroup meets at this barrier -- pairs and fold strips share workgroups)
+      if (P.fold_rows > 0 && !fold) __syncthreads();
       if (fold) {   // level 1's seam flux: the partner's top row of the input state (slot 1 of the ring of b_{k+1}; a first launch has just formed it)
         T own[VEC], oth[VEC], rev[VEC];
 #pragma unroll
@@ -534,15 +536,16 @@ __global__ __launch_bounds__(256, 1) void k_ringcz(const MultiP<T, T> P) {
   int bx = blockIdx.x;
   if (P.xcd_per > 0 && bx < 8 * P.xcd_per) bx = (bx & 7) * P.xcd_per + (bx >> 3);
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int np = P.nstrips >> 1, nnorm = P.nwx * np, nnorm_wg = (nnorm + 1) >> 1;
-  const bool fold = bx >= nnorm_wg;   // (workgroup-uniform: the fold strips' workgroups follow the pairs')
+  const int np = P.nstrips >> 1, nnorm = P.nwx * np;
+  const int unit = bx * 2 + (w >> 1);   // a pair of waves: a pair of strips, or (after the pairs) a window of the top rows and its mirror image
+  const bool fold = unit >= nnorm;
   const long long boff = (long long)blockIdx.y * P.bstride;
   const bool upper = (w & 1) != 0;
   bool active, odd;
   int wx = 0, a, b, pos_at = 0, klo = -(1 << 30), khi = 1 << 30;
   if (!fold) {
-    const int pid = bx * 2 + (w >> 1);
-    active = pid < nnorm;
+    const int pid = unit;
+    active = true;
     wx = pid % P.nwx;
     const int pp = pid / P.nwx;
     const long long nrows = P.out_hi - P.fold_rows - P.out_lo;
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(256, 1) void k_ringcz(const MultiP<T, T> P) {
     b = upper ? hi : mid;
     odd = !upper;
   } else {   // a window of the western half (even wave) and its mirror image (odd wave), both marching down the grid from the seam
-    const int fid = (bx - nnorm_wg) * 2 + (w >> 1);
+    const int fid = unit - nnorm;
     active = fid < P.nfw;
     a = P.out_hi - P.fold_rows;
     b = P.out_hi;
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(256, 1) void k_ringcz(const MultiP<T, T> P) {
     klo = upper ? P.nx / 2 : 0;
     khi = upper ? P.nx : P.nx / 2;
   }
-  const int nbar = fold ? S : S - 1;
+  const int nbar = P.fold_rows > 0 ? S : S - 1;   // (barriers of a march: one more in a launch with fold strips)
   bool bad = false;
   if (active) bad = ringc_march<T, K_FLUX, S, FIRST, false, XE, false, true>(P, wx, a, b, boff, odd, zl[w], zl[w ^ 1], fold, pos_at, klo, khi);
   else
@@ -612,13 +615,12 @@ static int launch_ringc_zip_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s)
   P.nfw = 0;
   if (a.zip_fold) {   // the top rows: strips that start at the tripole seam, zipped with their mirror windows (one more "half pair" per window)
     P.nfw = (g.nx / 2 + WI - 1) / WI;
-    // as many pairs as fill whole rounds of the 256 CUs together with the fold strips' workgroups (two units per workgroup: 257 workgroups
-    // would be two rounds -- config 4 measured 1.32 ms that way against 0.90)
-    const long long fwg = (P.nfw + 1) / 2;
+    // as many pairs as fill whole rounds of the 256 CUs together with the fold strips (two units per workgroup, pairs and fold strips mixed:
+    // 257 workgroups would be two rounds -- config 4 measured 1.32 ms that way against 0.90)
     long long npmax = 0;
     for (long long k = 1; k <= 8 && npmax < 1; ++k) {
-      const long long cap = 256 * k / std::max<long long>(1, std::min<long long>(a.nbatch, 256 * k));
-      npmax = cap > fwg ? 2 * (cap - fwg) / P.nwx : 0;
+      const long long cap = 256 * k / std::max<long long>(1, std::min<long long>(a.nbatch, 256 * k));   // workgroups per field
+      npmax = 2 * cap > P.nfw ? (2 * cap - P.nfw) / P.nwx : 0;                                        // (two units per workgroup)
     }
     np = (int)std::max(1LL, std::min<long long>(npmax, (nrows - S) / 4));
     // (at least S rows: the ghost rows the pairs below march beyond their last row must stay on this side of the seam)
@@ -641,7 +643,7 @@ static int launch_ringc_zip_sf(gcmf_plan *pl, const MultiArgs &a, hipStream_t s)
   for (int t = 0; t < MAX_PK; ++t) P.pk[t] = t < S ? a.pk[t] : 0.0;
   P.p0 = a.p0;
   P.c = a.c;
-  dim3 block(256), grid((P.nwx * np + 1) / 2 + (P.nfw + 1) / 2, (unsigned)a.nbatch);
+  dim3 block(256), grid((P.nwx * np + P.nfw + 1) / 2, (unsigned)a.nbatch);
   P.xcd_per = pl->xcd_remap ? (int)(grid.x / 8) : 0;
   P.zigzag = 1;
   bool xe = true;
