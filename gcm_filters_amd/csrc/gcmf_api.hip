@@ -118,7 +118,10 @@ static int launch_ringc(gcmf_plan *pl, const MultiArgs &m, hipStream_t s) {
         // same box, alternating; the launch is bound by HBM there)
         const long long rounds = (per * ((nrows + H0 - 1) / H0) + 1023) / 1024;
         const int mz = ringc_zip_march(pl, m, nullptr);
-        if (mz > 0 && (long long)mz * 100 <= rounds * (xe ? rows_xe : rows_pad) * 90 && !(m.nbatch > 1 && pl->pack_batch))
+        if (mz > 0 && m.nbatch <= 1 && (long long)mz * 100 <= rounds * (xe ? rows_xe : rows_pad) * 90) return launch_ringc_zip(pl, m, s);
+        // batches: against the better of whole strips per field and the packed column (1/4-degree grids, 2 .. 8 fields: + 3 .. 20 %)
+        if (mz > 0 && m.nbatch > 1 && f64 &&
+            mz * 100.0 <= ringc_batch_cost((pl->g.nx + wi - 1) / wi, m.nbatch, nrows, m.S, xe ? 4 : 12, pl->pack_batch != 0) * 90.0)
           return launch_ringc_zip(pl, m, s);
         if (xe) return launch_ringc_flux_slab(pl, m, s);
       }

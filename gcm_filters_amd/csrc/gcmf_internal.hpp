@@ -269,6 +269,29 @@ inline int ringc_zip_pairs(long long nwx, long long nbatch, long long nrows, int
   return (int)best;
 }
 
+// What a batch costs WITHOUT k_ringcz, in rows marched (x 1.04 per extra round of the wave slots): the better of whole strips per field and
+// the packed column of launch_ringc_sf (gcmf_ringc_impl.hpp: the same formulas) -- for the policies that weigh the zipped strips against it
+inline double ringc_batch_cost(long long nwx, long long nbatch, long long nrows, int S, int exitp, bool pack) {
+  auto padded = [&](long long m) { return (m + exitp - 1) / exitp * exitp; };
+  const long long want = strips_per_column(nwx * nbatch, nrows, S, exitp);
+  long long H = std::max(4LL, (nrows + want - 1) / want);
+  if (exitp == 12) H += (12 - (H + 2 * S) % 12) % 12;
+  H = std::min(H, nrows);
+  const long long nstrips = (nrows + H - 1) / H, rounds_u = (nwx * nbatch * nstrips + 1023) / 1024;
+  double best = (double)(rounds_u * padded(H + 2 * S)) * (1.0 + 0.04 * (rounds_u - 1));
+  if (!pack || nbatch <= 1) return best;
+  const long long total = nbatch * nrows, slots = std::max(1LL, 1024LL / nwx);
+  for (long long k = 1; k <= 16; ++k) {
+    const long long w = std::min(total, slots * k), q = (total + w - 1) / w;
+    if (q > nrows || q > 320) continue;
+    const long long rounds = (w * nwx + 1023) / 1024;
+    const bool crosses = (nrows % q) != 0;
+    const double cost = (double)(rounds * (padded(q + 2 * S) + (crosses ? padded(2 * S + exitp / 2) : 0))) * (1.0 + 0.04 * (rounds - 1));
+    if (cost < 0.97 * best) best = cost;
+    if (w >= total) break;
+  }
+  return best;
+}
 // kernel launchers (defined in gcmf_scalar.hip / gcmf_vector.hip)
 int launch_scalar_step(gcmf_plan *pl, const StepArgs &a, hipStream_t s);
 int launch_vector_step(gcmf_plan *pl, const StepArgs &a, hipStream_t s);

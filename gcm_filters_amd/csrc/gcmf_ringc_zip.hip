@@ -21,7 +21,23 @@ int ringc_zip_march(const gcmf_plan *pl, const MultiArgs &a, int *pairs) {
 // The tripole seam inside the launch (round 6): whole-launch conditions for k_ringcz's fold strips (gcmf_ringc_impl.hpp) -- the f64 flux
 // kind evaluated backwards, rows up to the seam, a lane's two cells on one side of the row's centre, no packed batch.
 bool ringc_zip_fold_ok(const gcmf_plan *pl, const MultiArgs &a) {
-  return pl->ringc_zip && pl->zip_fold && pl->g.fold && a.row_hi == pl->g.rows && pl->d.dtype == GCMF_F64 && pl->kind == K_FLUX && pl->strip_rows <= 0 &&
-         a.S >= 5 && a.S <= 9 && (pl->g.nx % 4) == 0 && pl->g.nx >= 256 && a.row_hi - a.row_lo >= 24 && !(a.nbatch > 1 && pl->pack_batch) && a.nbatch <= 64;
+  if (!(pl->ringc_zip && pl->zip_fold && pl->g.fold && a.row_hi == pl->g.rows && pl->d.dtype == GCMF_F64 && pl->kind == K_FLUX && pl->strip_rows <= 0 &&
+        a.S >= 5 && a.S <= 9 && (pl->g.nx % 4) == 0 && pl->g.nx >= 256 && a.row_hi - a.row_lo >= 24 && a.nbatch <= 64))
+    return false;
+  if (a.nbatch <= 1 || !pl->pack_batch) return true;
+  // a batch that may be packed: the fold strips (gridDim.y = the batch) against the packed column + k_fold_band -- in rows marched, as
+  // launch_ringc weighs it (1080 x 1440 POP, 8 fields: 1167 -> 995 us; 16 fields stay packed: 2126 against 2613 us)
+  const int M = (a.S + 1) / 2 * 2, WI = 128 - 2 * M;
+  const long long nwx = (pl->g.nx + WI - 1) / WI, nrows = a.row_hi - a.row_lo, nfw = (pl->g.nx / 2 + WI - 1) / WI;
+  long long npmax = 0, k = 1;
+  for (; k <= 8 && npmax < 1; ++k) {
+    const long long cap = 256 * k / std::max<long long>(1, std::min<long long>(a.nbatch, 256 * k));
+    npmax = 2 * cap > nfw ? (2 * cap - nfw) / nwx : 0;
+  }
+  if (npmax < 1) return false;
+  const long long rounds = k - 1, np = std::max(1LL, std::min(npmax, (nrows - a.S) / 4));
+  const long long fold_rows = std::max<long long>(a.S, (nrows + 2 * np) / (2 * np + 1)), H = std::max(fold_rows, (nrows - fold_rows + 2 * np - 1) / (2 * np));
+  const double zip = (double)(rounds * ringc_zip_rows(H + a.S + 1, a.S, nullptr)) * (1.0 + 0.04 * (rounds - 1));
+  return zip <= ringc_batch_cost(nwx, a.nbatch, nrows - a.S, std::min(a.S, 8), 12, true);
 }
 }  // namespace gcmf

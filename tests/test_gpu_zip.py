@@ -208,7 +208,7 @@ def test_the_tripole_seam_inside_the_launch(shape, n_steps, kwargs):
 @pytest.mark.parametrize("n_steps,kwargs", [(9, {}), (27, dict(nanland=True)), (63, dict(nanland=True, nanwet=[np.nan])), (17, dict(nb=2))])
 def test_nine_levels_per_launch_on_tripolar_grids(n_steps, kwargs):
     """With the seam inside the launch no k_fold_band (<= 8 levels) is involved, so whole f64 TRIPOLAR_POP grids take nine levels per launch
-    where that saves one (63 = 7 x 9), like the flux grids without a seam; a packed batch keeps the band and the eights.  Same bits as the
+    where that saves one (63 = 7 x 9), like the flux grids without a seam.  Same bits as the
     cut into launches of <= 8 (n = 9 cannot be cut otherwise: the forward recurrence, within tolerance)."""
     flt, plan, f, want = _case("TRIPOLAR_POP_WITH_LAND", (200, 392), n_steps, **kwargs)
     nb = kwargs.get("nb", 1)
@@ -224,12 +224,39 @@ def test_nine_levels_per_launch_on_tripolar_grids(n_steps, kwargs):
             got8 = flt.apply(f)
     finally:
         plan.set_option("ringc9", 1)
-    if nb == 1:
-        assert "k_ringcz<double, 9" in k9, k9
-    else:
-        assert "k_ringcz" not in k9, k9        # (the batch is packed: the band, at most eight levels -- gcmf_apply cuts with the batch in hand)
+    # (gcmf_apply cuts with the batch in hand: a batch that the launcher would rather pack keeps the band and the eights -- 16 fields on a
+    # 1/4-degree grid; this small one has its fields zipped side by side)
+    assert "k_ringcz<double, 9" in k9, k9
     ok = ~np.isnan(want)
     assert np.array_equal(np.isnan(got9), np.isnan(want))
     assert np.abs(got9[ok] - want[ok]).max() <= 1e-12 * np.abs(want[ok]).max()
     if n_steps != 9:
         assert np.array_equal(got9, got8, equal_nan=True)
+
+
+@pytest.mark.parametrize("grid", ["IRREGULAR_WITH_LAND", "TRIPOLAR_POP_WITH_LAND"])
+@pytest.mark.parametrize("shape,nb", [((300, 520), 3), ((260, 1100), 5), ((720, 1440), 6), ((200, 392), 16)])
+def test_batches_zipped_or_packed_give_the_same_bits(grid, shape, nb):
+    """The launcher weighs the zipped strips of a batch (every field's pairs side by side, gridDim.y = the batch; on tripolar plans with the
+    seam inside the launch) against whole strips / the packed column (+ k_fold_band) in rows marched: small batches on 1/4-degree grids take
+    the zipped strips (720 x 1440 POP, 6 fields: 1141 -> 611 us), big ones stay packed.  Whatever it picks: the bits of the plain strips."""
+    flt, plan, f, want = _case(grid, shape, 21, nanland=True, nb=nb)
+    f = f.copy()
+    wet = np.argwhere(~np.isnan(f[0]))
+    j, i = wet[len(wet) // 3]
+    f[nb - 1, j, i] = np.nan
+    outs, kernels = [], []
+    try:
+        for z in (0, 1):
+            plan.set_option("ringc_zip", z)
+            plan.last_kernel()
+            with np.errstate(all="ignore"):
+                outs.append(flt.apply(f))
+            kernels.append(plan.last_kernel())
+    finally:
+        plan.set_option("ringc_zip", 1)
+    assert "k_ringcz" not in kernels[0] and "k_ringc" in kernels[1], kernels
+    assert np.array_equal(outs[0], outs[1], equal_nan=True), kernels
+    clean = list(range(nb - 1))
+    ok = ~np.isnan(want[clean])
+    assert np.abs(outs[1][clean][ok] - want[clean][ok]).max() <= 1e-12 * np.abs(want[clean][ok]).max()
