@@ -469,7 +469,7 @@ class Plan:
 
     def set_option(self, name: str, value: int):
         """Named per-plan switch (gcmf_set_option, include/gcmf.h): "cgrid_ring", "cgrid_ring_smax", "cgrid_ring_hmax", "cgrid_ring_ncarry", "pack_batch",
-        "single_launch", "ringc9", "ringc_zip", "ringc_smax", "band_seq_cells", "zip_fold", "clenshaw_f32", "ring_flux_f32"."""
+        "single_launch", "ringc9", "ringc_zip", "ringc_smax", "band_seq_cells", "zip_fold", "slab_nines", "clenshaw_f32", "ring_flux_f32"."""
         check(load().gcmf_set_option(self._h, name.encode(), int(value)))
 
 

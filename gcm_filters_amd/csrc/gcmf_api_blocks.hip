@@ -32,6 +32,13 @@ static bool ringc9_fold_ok(const gcmf_plan *pl, int64_t nbatch) {
   return ringc_zip_fold_ok(pl, a);
 }
 
+// ... and ROW SLABS of f64 flux grids without a tripole seam, when the slab's owner says so (option "slab_nines": SlabFilter sets it on every
+// rank or on none -- the ranks of a run must cut alike, and only they know whether all of them qualify and the ghost zone is nine rows deep).
+// Nothing here may depend on the slab's size beyond the 64-row floor: edge and interior ranks own different numbers of rows.
+static bool ringc9_slab_ok(const gcmf_plan *pl) {
+  return pl && pl->slab_nines && pl->ringc9 && pl->kind == K_FLUX && pl->d.dtype == GCMF_F64 && !pl->full && !pl->tripolar && !pl->g.fold && pl->g.rows >= 64;
+}
+
 // Backward (Clenshaw) evaluation (gcmf_ringc_impl.hpp): whether gcmf_apply uses it for this plan and polynomial, and how the
 // n_steps levels are cut into launches of 5..8 (never leaving 1..4 or 9 behind).  plan->clenshaw = 1: the flux kinds, whose
 // launches run at memcpy rate and gain the plane they no longer move (config 3: +10 %); 2: every scalar kind (the land-mask
@@ -51,10 +58,10 @@ int clenshaw_cut(const gcmf_plan *pl, int n_steps, int *depths, int max_depths, 
   // (f32 state: the flux kinds since round 3, the REGULAR / land-mask kinds since round 4)
   if (!pl->ring || !pl->zero_row || pl->multi_s < 8 || !multi_supported(pl, 8)) return 0;
   if (pl->n_land > 0 && !land_ok(pl, n_steps)) return 0;
-  const bool nines = ringc9_ok(pl) || ringc9_fold_ok(pl, nbatch);
+  const bool nines_full = ringc9_ok(pl) || ringc9_fold_ok(pl, nbatch), nines = nines_full || ringc9_slab_ok(pl);
   if (!(n_steps >= 10 || (n_steps >= 5 && n_steps <= 8) || (n_steps == 9 && nines))) return 0;
   int smax = pl->ringc_smax;
-  if (!smax && nbatch == 1 && nines && pl->ringc_zip && (long long)pl->g.rows * pl->g.nx <= 2500000LL && n_steps >= 10) {
+  if (!smax && nbatch == 1 && nines_full && pl->ringc_zip && (long long)pl->g.rows * pl->g.nx <= 2500000LL && n_steps >= 10) {
     // Whole grids that live in the caches and run k_ringcz (1/4-degree grids): a launch is paced by the rows its strips march, not by the
     // bytes it moves, so fewer launches are not always faster -- a strip marches H + S + 1 rows whose cost grows with S, and fewer
     // levels mean narrower ghost columns (sometimes a window less).  Measured (experiments/scripts/zip_ab.py, us per launch):
@@ -176,7 +183,7 @@ int gcmf_cheb_multi(gcmf_plan *pl, const void *u, const void *v, void *uo, void 
     int probe[2];
     // (is the backward evaluation on offer for this plan at all: a 10-level polynomial can always be cut, [5, 5]; an f32 filter never
     // starts with eight levels, see clenshaw_cut)
-    if (pl->ncomp != 1 || S < 5 || S > (ringc9_ok(pl) ? 9 : 8) || !pl->ring || !pl->zero_row || clenshaw_cut(pl, 10, probe, 2, false, 2) != 2 ||
+    if (pl->ncomp != 1 || S < 5 || S > ((ringc9_ok(pl) || ringc9_slab_ok(pl)) ? 9 : 8) || !pl->ring || !pl->zero_row || clenshaw_cut(pl, 10, probe, 2, false, 2) != 2 ||
         (first && S == 8 && pl->d.dtype != GCMF_F64)) {
       set_error("gcmf_cheb_multi: the backward evaluation is not available for this plan / depth %d", S);
       return GCMF_ERR_UNSUPPORTED;

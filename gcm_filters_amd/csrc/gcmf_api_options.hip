@@ -137,6 +137,7 @@ int gcmf_set_option(gcmf_plan *pl, const char *name, int value) {
   else if (n == "ringc_smax") pl->ringc_smax = value;
   else if (n == "band_seq_cells") pl->band_seq_cells = value;
   else if (n == "zip_fold") pl->zip_fold = value;
+  else if (n == "slab_nines") pl->slab_nines = value;
   else if (n == "clenshaw_f32") pl->clenshaw_f32 = value;
   else if (n == "ring_flux_f32") pl->ring_flux_f32 = value;
   else {

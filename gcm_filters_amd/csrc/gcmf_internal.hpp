@@ -181,6 +181,7 @@ struct gcmf_plan {
   long long band_seq_cells = 3000000;   // tripolar plans: blocked launches over at most this many cells run k_fold_band AFTER themselves (its 1024-thread form), not beside (env GCMF_BAND_SEQ_CELLS; 0 = never)
   bool alone_now = true;  // (set by advance_multi for the blocked launch it issues: no k_fold_band waves will share its SIMDs)
   int zip_fold = 1;       // tripolar f64 flux plans, backward evaluation: k_ringcz advances the seam's rows itself (no k_fold_band); gcmf_set_option "zip_fold", env GCMF_ZIP_FOLD
+  int slab_nines = 0;     // row slabs of f64 flux grids without a tripole seam: nine levels per launch where that saves one (gcmf_set_option "slab_nines"; every rank or none)
   int ringc_smax = 0;     // backward scalar launches: at most this many levels each (5..8; 0 = the default cut: nine where offered, else eight); gcmf_set_option "ringc_smax"
   int ringc9 = 1;         // whole f64 flux-form grids without a tripole seam: up to NINE levels per k_ringc launch (env GCMF_RINGC9, gcmf_set_option "ringc9")
   int clenshaw = 2;       // backward (Clenshaw) evaluation: 0 off, 1 the flux kinds + C-grid, 2 (default since round 4) every kind that has a

@@ -222,6 +222,27 @@ class SlabFilter:
         # "backward": the backward evaluation also for f32 scalar / B-grid state (the slab plan's clenshaw_f32 switch; all f32, faster)
         if evaluation == "backward" and hasattr(getattr(self.engine, "plan", None), "set_option"):
             self.engine.plan.set_option("clenshaw_f32", 1)
+        # Nine levels per launch on the slabs of f64 flux grids without a tripole seam where that saves a launch (round 6: 63 = 7 x 9 instead of
+        # 8 launches; k_ringcz / k_ringc at nine levels).  The plans only offer it when told to (option "slab_nines"), and the ranks of a run
+        # must cut alike: decided here collectively -- every rank must qualify (64 rows, the kind, the dtype; a ghost zone nine rows deep) --
+        # and taken per application by the batch and the slab's height (_cut_for), which every rank knows alike.
+        plan = getattr(self.engine, "plan", None)
+        self._cut9 = []
+        if hasattr(plan, "set_option") and hasattr(self.engine, "clenshaw_cut") and evaluation != "reference":
+            nines = 0
+            try:
+                plan.set_option("slab_nines", 1)
+                c9 = list(self.engine.clenshaw_cut(self.n_steps))
+                nines = 1 if (c9 and max(c9) == 9 and (not self.multi or self.halo >= 9) and os.environ.get("GCMF_SLAB_NINES", "1") != "0") else 0
+            except _lib.GcmfError:
+                c9, nines = [], 0
+            rows_min = torch.tensor([nines, -int(self.rows_owned)], dtype=torch.int32)
+            if self.world > 1 and dist.is_initialized():
+                rows_min = rows_min.to(self.device if dist.get_backend(group) == "nccl" else torch.device("cpu"))
+                dist.all_reduce(rows_min, op=dist.ReduceOp.MIN, group=group)
+            nines, self._rows_owned_max = int(rows_min[0].item()), -int(rows_min[1].item())
+            plan.set_option("slab_nines", 0)
+            self._cut9 = c9 if nines else []
         cut = self.engine.clenshaw_cut(self.n_steps) if (hasattr(self.engine, "clenshaw_cut") and evaluation != "reference") else []
         use = 1 if (cut and (not self.multi or self.halo >= max(cut))) else 0
         if self.world > 1 and dist.is_initialized():
@@ -612,6 +633,17 @@ class SlabFilter:
     # -- the filter ----------------------------------------------------------------------------
     MULTI_DEPTHS = (8, 7, 6, 5, 4, 3, 2)  # scalar kinds support all of them, the vector kinds 4 / 3 / 2
 
+    def _cut_for(self, nbatch):
+        """The launch depths of a backward application of `nbatch` fields: nines where they were agreed on (__init__) and pay -- a batch, or a
+        lone field on slabs of 700 rows and more (measured, experiments/scripts/slab_nines_ab.py: one field 600 rows 301 against 295 us,
+        800 rows 358 against 372, 1200 rows 490 against 543; four fields 8-9 % at every height).  Every rank takes the same branch: the
+        batch is the same everywhere and the tallest slab of the run was reduced over the ranks."""
+        use9 = bool(self._cut9) and (nbatch >= 2 or getattr(self, "_rows_owned_max", 0) >= int(os.environ.get("GCMF_SLAB_NINES_MIN_ROWS", "700")))
+        plan = getattr(self.engine, "plan", None)
+        if hasattr(plan, "set_option") and self._cut9:
+            plan.set_option("slab_nines", 1 if use9 else 0)     # (every time: plans are cached and shared between SlabFilters)
+        return self._cut9 if use9 else self.backward_cut
+
     def apply_local(self, local: Sequence):
         """Filter this rank's rows.  `local`: ncomp tensors (nbatch, rows_owned, nx) on the device.  Returns
         ncomp float64 tensors of the same shape (views into an internal buffer, valid until the next call).
@@ -639,9 +671,10 @@ class SlabFilter:
         keep_land_out = can_multi and hasattr(self.engine, "has_land") and self.engine.has_land()
         land_zeroed = False
         if self.backward_cut:
+            cut = self._cut_for(nbatch)
             if self.native_driver and self.ncomp == 1 and isinstance(self.engine, HipSlabEngine) and self.exchange_kind in ("native", "p2p"):
-                return self._apply_backward_native(self.backward_cut, st, p, nbatch)
-            return self._apply_backward(self.backward_cut, st, p, nbatch)
+                return self._apply_backward_native(cut, st, p, nbatch)
+            return self._apply_backward(cut, st, p, nbatch)
         if self._vector_backward_ok(nbatch):
             return self._apply_backward_vec_native(st, p, nbatch)
         u, v = X, None          # T_{k-1}, T_{k-2}

@@ -399,7 +399,8 @@ int gcmf_set_tuning(gcmf_plan *plan, int rows_per_wave, int xcd_remap, int multi
  * the last level keeps its previous row's scaled copies in registers; same bits), "cgrid_ring_hmax" (tallest strip, 0 = 96 rows), "ringc9" 1 / 0 (nine levels per k_ringc launch on whole f64 flux grids), "ringc_zip" 1 / 0 (k_ringcz: strips of f64 flux plans without a tripole
  * seam marched in pairs away from a shared seam wherever that marches fewer rows; same bits; 2 / 3 = always its early-exit / whole-period form), "ringc_smax" 0 / 5..9
  * (backward scalar launches of at most this many levels; 0 = the default cut), "zip_fold" 1 / 0 (tripolar f64 flux plans evaluated backwards: k_ringcz advances the seam's rows itself -- strips that start
- * at the seam, zipped with the strips of their mirror windows -- instead of k_fold_band beside / after the launch; same bits), "band_seq_cells" N (tripolar plans: a blocked launch over at most N cells runs the seam's
+ * at the seam, zipped with the strips of their mirror windows -- instead of k_fold_band beside / after the launch; same bits), "slab_nines" 0 / 1 (row-slab plans of f64 flux grids without a tripole seam: gcmf_clenshaw_cut offers nine levels per launch where that saves one; the
+ * ranks of a run must set it alike and own a ghost zone of at least nine rows -- SlabFilter decides it collectively), "band_seq_cells" N (tripolar plans: a blocked launch over at most N cells runs the seam's
  * k_fold_band after itself -- 1024 threads per tile -- instead of beside itself on a side stream; default 3000000, 0 = never; same bits), "pack_batch" 1 / 0 (batches on short
  * grids: the fields as one column of rows per window, k_ringcp; same bits), "single_launch" 0 / 1 (whole f64 flux-form grids of ANY size
  * whose n_steps is a multiple of 9 or 8: the whole polynomial in ONE persistent launch, csrc/gcmf_ringc_one.hip -- the passes over HBM

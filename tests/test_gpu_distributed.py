@@ -33,6 +33,10 @@ CASES = [
     ("TRIPOLAR_REGULAR_WITH_LAND_AREA_WEIGHTED", (58, 16), 5, 5, "f8"),
     ("REGULAR_WITH_LAND", (58, 16), 5, 2, "f4"),
     ("REGULAR_WITH_LAND", (58, 16), 5, 2, "f4b"),
+    # round 6: nine levels per launch on the slabs of an f64 flux grid without a tripole seam (a ghost zone of >= 9 rows, every rank >= 64
+    # rows, decided collectively; a batch takes them at any height): 27 = 3 x 9
+    ("IRREGULAR_WITH_LAND", (216, 64), 12, 2, "f8", 27),
+    ("MOM5U", (216, 64), 9, 3, "f8", 36),
     # f32 POP, n_steps 19 = launches of 7 + 7 + 5 levels on slabs of 14 rows with 14 ghost rows: the second launch of the top rank starts
     # exactly 2 S rows below the seam (k_fold_band's input rows; found by tools/fuzz_slabs.py -- the row-range check was one row too strict)
     ("TRIPOLAR_POP_WITH_LAND", (28, 44), 16, 5, "f4b", 19),
@@ -47,6 +51,7 @@ CASES_8 = [
     ("REGULAR_WITH_LAND", (131, 64), 5, 2, "f4"),
     ("REGULAR_WITH_LAND", (131, 64), 5, 2, "f4b"),
     ("VECTOR_C_GRID", (128, 64), 4, 4, "f4"),
+    ("IRREGULAR_WITH_LAND", (560, 64), 10, 2, "f8", 27),    # nine levels per launch on eight slabs
 ]
 
 
@@ -72,7 +77,7 @@ def _worker(rank, world, port, q, exchange="auto"):
     res = {}
     try:
         for grid, shape, halo, nbatch, dt, *rest in (CASES_8 if world == 8 else CASES):
-            if rest and world != 2:
+            if rest and world not in (2, 8):
                 res[f"{grid}-{shape}-h{halo}-b{nbatch}-{dt}"] = (0.0, 0.0)   # (a two-rank geometry)
                 continue
             name, back32 = f"{grid}-{shape}-h{halo}-b{nbatch}-{dt}", dt == "f4b"
@@ -102,6 +107,8 @@ def _worker(rank, world, port, q, exchange="auto"):
             if sf.backward_cut:   # flux kinds: the slabs evaluate backwards like the one-GPU path (k_ringc; k_ringcs = its early-exit form for slabs)
                 kern = sf.engine.plan.last_kernel()
                 assert any(k in kern for k in ("k_ringc<", "k_ringcs<", "k_ringcp<", "k_ringcz<")), (grid, kern)   # (k_ringcp: packed batches, k_ringcz: zipped pairs, round 6)
+            if rest and rest[0] in (27, 36) and halo >= 9:   # the nines were agreed on and taken (SlabFilter._cut_for)
+                assert sf._cut9 and max(sf._cut_for(nbatch)) == 9, (name, sf._cut9, sf.backward_cut)
             if vec:   # the blocked vector kernels really ran on the slabs
                 assert sf.kernel_launches < sf.n_steps, (sf.kernel_launches, sf.n_steps)
             if rank == 0:
