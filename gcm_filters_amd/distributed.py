@@ -227,22 +227,24 @@ class SlabFilter:
         # must cut alike: decided here collectively -- every rank must qualify (64 rows, the kind, the dtype; a ghost zone nine rows deep) --
         # and taken per application by the batch and the slab's height (_cut_for), which every rank knows alike.
         plan = getattr(self.engine, "plan", None)
-        self._cut9 = []
-        if hasattr(plan, "set_option") and hasattr(self.engine, "clenshaw_cut") and evaluation != "reference":
-            nines = 0
+        self._cut9, c9, nines = [], [], 0
+        can9 = hasattr(plan, "set_option") and hasattr(self.engine, "clenshaw_cut") and evaluation != "reference"
+        if can9:
             try:
                 plan.set_option("slab_nines", 1)
                 c9 = list(self.engine.clenshaw_cut(self.n_steps))
                 nines = 1 if (c9 and max(c9) == 9 and (not self.multi or self.halo >= 9) and os.environ.get("GCMF_SLAB_NINES", "1") != "0") else 0
             except _lib.GcmfError:
                 c9, nines = [], 0
-            rows_min = torch.tensor([nines, -int(self.rows_owned)], dtype=torch.int32)
-            if self.world > 1 and dist.is_initialized():
-                rows_min = rows_min.to(self.device if dist.get_backend(group) == "nccl" else torch.device("cpu"))
-                dist.all_reduce(rows_min, op=dist.ReduceOp.MIN, group=group)
-            nines, self._rows_owned_max = int(rows_min[0].item()), -int(rows_min[1].item())
+        # (every rank takes part in the reduction, whatever its engine: a rank that cannot run nines votes 0)
+        rows_min = torch.tensor([nines, -int(self.rows_owned)], dtype=torch.int32)
+        if self.world > 1 and dist.is_initialized():
+            rows_min = rows_min.to(self.device if dist.get_backend(group) == "nccl" else torch.device("cpu"))
+            dist.all_reduce(rows_min, op=dist.ReduceOp.MIN, group=group)
+        nines, self._rows_owned_max = int(rows_min[0].item()), -int(rows_min[1].item())
+        if can9:
             plan.set_option("slab_nines", 0)
-            self._cut9 = c9 if nines else []
+        self._cut9 = c9 if nines else []
         cut = self.engine.clenshaw_cut(self.n_steps) if (hasattr(self.engine, "clenshaw_cut") and evaluation != "reference") else []
         use = 1 if (cut and (not self.multi or self.halo >= max(cut))) else 0
         if self.world > 1 and dist.is_initialized():
